@@ -1,0 +1,297 @@
+/*
+ * sd_amd.h — C ABI of the MI355X (gfx950) speculative-decoding hot path.
+ *
+ * Every entry point is `extern "C"`, takes raw DEVICE pointers plus sizes and a
+ * HIP stream, returns 0 on success or a negative sd_status, never throws, never
+ * synchronises the device and never allocates device memory: the caller owns
+ * every buffer (scratch included — ask sd_*_workspace_bytes and pass it in).
+ * Work is stream-ordered; asynchronous HIP faults surface on the caller's next
+ * synchronisation.  One process per GPU; calls on different streams of one GPU
+ * may overlap only if they use different workspaces.
+ *
+ * What each group replaces.  The reference tree holds no speculative-decoding
+ * code: the path lives in its un-vendored dependency `vllm`
+ * (/root/reference/pyproject.toml:31, observed 0.10.2 with
+ * speculative_config=None at
+ * /root/reference/src/performance_enhancement/test.ipynb:148).  The seam this
+ * library sits behind is the worker-injection seam the reference uses
+ * (/root/reference/src/qwen_image_gen/executor.py:14-26,
+ * /root/reference/src/qwen_image_gen/worker.py:34-58) and the step contract at
+ * /root/reference/src/doc/engine_core.md:117-122,280-340.  Upstream symbol
+ * names quoted below are the vLLM-V0 names the plugin surface keeps.
+ */
+#ifndef SD_AMD_H
+#define SD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sd_stream_t; /* a hipStream_t, passed as an opaque pointer */
+
+typedef enum {
+  SD_OK = 0,
+  SD_ERR_INVALID = -1,   /* bad argument (shape, alignment, null pointer) */
+  SD_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for */
+  SD_ERR_HIP = -3,       /* a HIP runtime call failed at launch time */
+  SD_ERR_WORKSPACE = -4  /* workspace too small */
+} sd_status;
+
+/* Library version (major*10000 + minor*100 + patch). */
+int sd_version(void);
+/* Copies the calling thread's last error text (NUL-terminated) into buf. */
+int sd_last_error(char* buf, size_t n);
+/* Number of CUs / name of the current device; also proves HIP is usable. */
+int sd_device_info(int* cu_count, char* name, size_t n);
+
+/* ------------------------------------------------------------------------
+ * Acceptance (replaces vllm.model_executor.layers.rejection_sampler
+ * RejectionSampler.forward, which the task statement calls
+ * `_custom_ops.rejection_sample`; contract rows at
+ * /root/reference/src/doc/engine_core.md:323-324 — one variable-length token
+ * list per request).
+ * ---------------------------------------------------------------------- */
+
+/* Modified rejection sampling (Leviathan et al. 2023, Alg. 1), batched.
+ *   target_probs   [B, k+1, V] f32   p_i, row k is the bonus position
+ *   bonus_ids      [B]        i64    token already sampled from p_k
+ *   draft_probs    [B, k, V]  f32    q_i
+ *   draft_ids      [B, k]     i64    x_i ~ q_i
+ *   u_accept       [B, k]     f32    uniforms in [0,1)
+ *   u_recover      [B, k+1]   f32    uniforms in [0,1) for the resampled token
+ *   proposal_lens  [B] i32 or NULL   (NULL = every sequence proposes k)
+ *   out_ids        [B, k+1]   i64    accepted prefix, then one more token,
+ *                                    then -1
+ *   counters       [3] i64 or NULL   += {accepted, emitted, draft} tokens
+ * Accept x_i iff u_i * q_i(x_i) < p_i(x_i).  At the first rejected position j
+ * the token is drawn from norm(max(p_j - q_j, 0)) by inverse CDF with
+ * u_recover[b, j] (f64 running sum, first index whose sum exceeds
+ * u * total).  With all L = proposal_lens[b] accepted: L == k emits
+ * bonus_ids[b]; L < k draws from p_L with u_recover[b, L].
+ * Requires 1 <= k <= 63, V % 4 == 0, 16-byte aligned rows.                */
+int sd_rejection_sample(const float* target_probs, const int64_t* bonus_ids,
+                        const float* draft_probs, const int64_t* draft_ids,
+                        const float* u_accept, const float* u_recover,
+                        const int32_t* proposal_lens, int64_t* out_ids,
+                        int64_t* counters, int B, int k, int V,
+                        sd_stream_t stream);
+
+/* Greedy acceptance: accept x_i while x_i == target_ids[b, i]; then emit
+ * target_ids[b, j] at the first mismatch j (or at j == L).  Same outputs and
+ * counters as above.  target_ids [B, k+1] i64, draft_ids [B, k] i64.       */
+int sd_greedy_verify(const int64_t* target_ids, const int64_t* draft_ids,
+                     const int32_t* proposal_lens, int64_t* out_ids,
+                     int64_t* counters, int B, int k, sd_stream_t stream);
+
+/* Row-wise helpers over logits [R, V] f32 (row stride ld, in elements).
+ * argmax: smallest index among equal maxima.  softmax: exp((x-max)/T)/sum.
+ * sample: inverse CDF of probs with one uniform per row (f64 running sum).  */
+int sd_argmax_rows(const float* logits, int64_t ld, int64_t* ids, int R, int V,
+                   sd_stream_t stream);
+int sd_softmax_rows(const float* logits, int64_t ld, float temperature,
+                    float* probs, int64_t ld_probs, int R, int V,
+                    sd_stream_t stream);
+int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
+                   int64_t* ids, int R, int V, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Paged KV cache and attention (replaces vLLM's paged_attention_v1/v2 as used
+ * by spec_decode.batch_expansion's scorer, with k+1 query tokens per sequence
+ * scored in ONE pass instead of k+1 expanded single-query sequences).
+ *
+ * Page = 16 tokens of one KV head.  Layouts (bf16), chosen so that a wave's
+ * MFMA operand fragments are contiguous 16-byte pieces of a page:
+ *   K page  [D/8][16 tokens][8]      (8-element chunks of the head dim)
+ *   V page  [D][16 slots]            (transposed; token t sits in slot
+ *                                     (t&3) | ((t>>3)&1)<<2 | ((t>>2)&1)<<3)
+ *   cache   [num_pages][Hkv][page]
+ * The cache must be zero-filled when allocated (unwritten slots are read and
+ * masked, so they must hold finite values).
+ * ---------------------------------------------------------------------- */
+
+/* Rotary embedding + append.  For token t of sequence b (t < q_len) at
+ * position pos = seq_lens[b] + pos_offset + t: rotates q in place, rotates k,
+ * and writes k, v into the page block_tables[b][pos/16].
+ *   qkv        [B*q_len, (Hq + 2*Hkv) * D] bf16, q heads then k then v
+ *   rope_cs    [max_pos, D] f32: cos (D/2) then sin (D/2); NULL = no rotation
+ *   rot_dim    number of leading dims rotated (== D for Llama/Qwen2)         */
+int sd_rope_append(void* qkv, const float* rope_cs, int max_pos, void* k_cache,
+                   void* v_cache, const int32_t* block_tables,
+                   int max_blocks_per_seq, const int32_t* seq_lens,
+                   int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
+                   sd_stream_t stream);
+
+/* Bytes of scratch sd_paged_attention needs for these bounds. */
+size_t sd_paged_attention_workspace_bytes(int B, int q_len, int Hq, int D,
+                                          int max_ctx, int split_tokens);
+
+/* Causal attention of q_len new query tokens per sequence over its paged KV.
+ * Query token t of sequence b sits at position seq_lens[b] + pos_offset + t
+ * and attends keys 0..that position (its own K/V must already be appended).
+ *   q    [B*q_len, Hq, D] bf16 with row stride ldq (elements)
+ *   out  [B*q_len, Hq*D]  bf16 with row stride ldo
+ *   max_ctx       host upper bound of seq_lens[b] + pos_offset + q_len
+ *   split_tokens  keys per workgroup (multiple of 128); results for a given
+ *                 query depend on split_tokens but not on B, q_len or max_ctx
+ * Supported: D in {64, 128}, q_len * (Hq/Hkv) <= 64.                        */
+int sd_paged_attention(const void* q, int64_t ldq, const void* k_cache,
+                       const void* v_cache, const int32_t* block_tables,
+                       int max_blocks_per_seq, const int32_t* seq_lens,
+                       int pos_offset, void* out, int64_t ldo, int B, int q_len,
+                       int Hq, int Hkv, int D, float scale, int max_ctx,
+                       int split_tokens, void* workspace,
+                       size_t workspace_bytes, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Dense ops of a decoder layer at <= 8 token rows (weight streaming; replaces
+ * the per-step model execution inside spec_decode.multi_step_worker and the
+ * scorer's target forward).
+ * ---------------------------------------------------------------------- */
+
+typedef enum {
+  SD_EPI_STORE = 0,     /* out = bf16(acc + bias)                           */
+  SD_EPI_RESIDUAL = 1,  /* out = bf16(bf16(acc + bias) + residual)          */
+  SD_EPI_SILU_MUL = 2,  /* W holds 2N rows: out = silu(row n) * row (N+n)   */
+  SD_EPI_RELU = 3,      /* out = bf16(max(acc + bias, 0))                   */
+  SD_EPI_F32 = 4,       /* out (f32) = acc + bias                           */
+  SD_EPI_GELU_TANH = 5  /* out = bf16(gelu_tanh(acc + bias))                */
+} sd_epilogue;
+
+/* out[m, n] = epilogue(sum_k x[m, k] * W[n, k]),  m < M <= 8.
+ *   W [N(or 2N), K] bf16 row-major; x [M, K] bf16 (row stride ldx);
+ *   bias [N] bf16 or NULL; residual [M, N] bf16 (row stride ldo) or NULL.
+ * Each output element is accumulated in an order that depends only on K, so
+ * a row's result does not depend on M or on the other rows.
+ * Requires K % 8 == 0 and 16-byte aligned rows.                             */
+int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
+              const void* residual, void* out, int64_t ldo, int M, int N, int K,
+              int epilogue, sd_stream_t stream);
+
+/* out = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w) per row; rows x H bf16. */
+int sd_rmsnorm(const void* x, int64_t ldx, const void* w, void* out,
+               int64_t ldo, int rows, int H, float eps, sd_stream_t stream);
+/* out = bf16((x - mean) * rsqrt(var + eps) * w + b) per row.               */
+int sd_layernorm(const void* x, int64_t ldx, const void* w, const void* b,
+                 void* out, int64_t ldo, int rows, int H, float eps,
+                 sd_stream_t stream);
+/* out[r] = table[ids[r*id_stride]] (+ pos_table[pos(r) + pos_bias]) bf16.
+ * pos(r) = seq_lens[r / q_len] + pos_offset + r % q_len.                    */
+int sd_embed(const int32_t* ids, int64_t id_stride_seq, int64_t id_offset,
+             const void* table, const void* pos_table, int pos_bias,
+             const int32_t* seq_lens, int pos_offset, void* out, int B,
+             int q_len, int H, int vocab, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Decoder model: a host-side descriptor over caller-owned device weights.
+ * ---------------------------------------------------------------------- */
+
+typedef enum { SD_ARCH_LLAMA = 0, SD_ARCH_OPT = 1 } sd_arch;
+
+typedef struct {
+  const void* attn_norm_w;  /* [H] */
+  const void* attn_norm_b;  /* [H] or NULL (OPT) */
+  const void* qkv_w;        /* [(Hq+2Hkv)*D, H] */
+  const void* qkv_b;        /* or NULL */
+  const void* o_w;          /* [H, Hq*D] */
+  const void* o_b;          /* or NULL */
+  const void* mlp_norm_w;   /* [H] */
+  const void* mlp_norm_b;   /* or NULL */
+  const void* up_w;         /* LLAMA: [2F, H] gate rows then up rows; OPT: [F, H] */
+  const void* up_b;         /* or NULL */
+  const void* down_w;       /* [H, F] */
+  const void* down_b;       /* or NULL */
+} sd_layer_weights;
+
+typedef struct {
+  int arch;        /* sd_arch */
+  int n_layers, hidden, n_heads, n_kv_heads, head_dim, ffn, vocab;
+  int max_pos;     /* rows of rope_cs / pos_table */
+  int pos_bias;    /* OPT learned positions start at row 2 */
+  float norm_eps;
+  float attn_scale;        /* usually head_dim^-0.5 */
+  const void* embed;       /* [vocab, H] bf16 */
+  const void* pos_table;   /* [max_pos + pos_bias, H] bf16 or NULL */
+  const float* rope_cs;    /* [max_pos, D] f32 or NULL */
+  const void* final_norm_w;
+  const void* final_norm_b; /* or NULL */
+  const void* lm_head;     /* [vocab, H] bf16 (== embed when tied) */
+  const sd_layer_weights* layers; /* n_layers entries (copied) */
+} sd_model_desc;
+
+typedef struct sd_model sd_model;
+
+sd_model* sd_model_create(const sd_model_desc* desc);
+void sd_model_destroy(sd_model* m);
+
+typedef struct {
+  void* k_cache; /* [n_layers][num_pages][Hkv][page] */
+  void* v_cache;
+  int64_t layer_stride_bytes; /* bytes between consecutive layers' caches */
+  const int32_t* block_tables; /* [B, max_blocks_per_seq] i32 (device) */
+  int max_blocks_per_seq;
+} sd_kv_cache;
+
+typedef struct {
+  int B, q_len;              /* q_len tokens per sequence, B*q_len <= 8 */
+  const int32_t* token_ids;  /* token t of seq b at [b*tok_stride + tok_offset + t] */
+  int64_t tok_stride, tok_offset;
+  const int32_t* seq_lens;   /* [B] device; first new position = seq_lens[b] + pos_offset */
+  int pos_offset;
+  int max_ctx;               /* host bound on seq_lens[b] + pos_offset + q_len */
+  int split_tokens;          /* attention keys per workgroup */
+  float* logits;             /* [B*q_len, vocab] f32 out, or NULL to skip the head */
+} sd_forward_args;
+
+size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,
+                                int split_tokens);
+/* One forward pass of B*q_len token rows: embeds, runs every layer (appending
+ * K/V to the cache), final norm and LM head.  Enqueues kernels only.        */
+int sd_model_forward(sd_model* m, const sd_kv_cache* kv,
+                     const sd_forward_args* a, void* workspace,
+                     size_t workspace_bytes, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Speculative step glue that must stay on the device (replaces the tensor
+ * bookkeeping of spec_decode.spec_decode_worker._verify_tokens /
+ * _create_output_sampler_list and top1_proposer's proposal assembly).
+ * Per-sequence device state:
+ *   seq_lens [B] i32   tokens in the sequence so far (n)
+ *   tok_buf  [B, k+2] i32 = {t[n-2], t[n-1], d_1 .. d_k}
+ * ---------------------------------------------------------------------- */
+
+/* Writes proposal ids (i64 -> i32) into tok_buf[:, 2 + step]; optionally
+ * overrides each with `truth[b, n + step]` with probability accept_prob
+ * (counter-based hash of seed, b, position) — a synthetic-acceptance control
+ * for benchmarking with random weights; truth == NULL disables it.         */
+int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, int step,
+                      const int32_t* seq_lens, const int32_t* truth,
+                      int64_t truth_stride, float accept_prob, uint32_t seed,
+                      int B, sd_stream_t stream);
+
+/* Gathers tok_buf[:, 2:2+k] as i64 draft_ids [B, k].                        */
+int sd_gather_proposals(const int32_t* tok_buf, int64_t* draft_ids, int B,
+                        int k, sd_stream_t stream);
+
+/* Applies out_ids [B, k+1] (i64, -1 padded) to the state: appends the emitted
+ * tokens to gen_tokens[b, gen_counts[b]..] (bounded by gen_capacity),
+ * advances seq_lens and gen_counts, and rebuilds tok_buf[:, 0:2].           */
+int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32_t* tok_buf,
+                     int32_t* gen_tokens, int64_t gen_stride, int gen_capacity,
+                     int32_t* gen_counts, int B, int k, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Stream capture helpers (one spec step = one hipGraph launch).
+ * ---------------------------------------------------------------------- */
+typedef struct sd_graph sd_graph;
+int sd_graph_begin(sd_stream_t stream);
+int sd_graph_end(sd_stream_t stream, sd_graph** out);
+int sd_graph_launch(sd_graph* g, sd_stream_t stream);
+void sd_graph_destroy(sd_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SD_AMD_H */

@@ -1,0 +1,108 @@
+"""Acceptance rules of speculative decoding, restated on the CPU (numpy).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows Algorithm 1 of Leviathan et al. 2023 (arXiv 2211.17192); the same rule
+is implemented for batch 1 in
+/usr/local/lib/python3.10/dist-packages/transformers/generation/utils.py:3992-4059
+(accept `r <= p/q` at :4027-4029, residual `clamp(p-q, 0)/sum` at :4045-4052,
+bonus token when all are accepted at :4053-4054).  The reference repository
+holds no implementation (/root/reference/pyproject.toml:31 names the external
+dependency that does).
+
+Conventions fixed here so that results are deterministic and portable:
+  * uniforms are explicit inputs in [0, 1);
+  * accept x iff  u * q(x) < p(x)  (one f32 multiply, one compare);
+  * a token is drawn from non-negative weights w by inverse CDF: the first
+    index t whose float64 running sum exceeds u * sum(w); if rounding leaves
+    none, the last index with w > 0; if sum(w) == 0, the first argmax of p.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def inverse_cdf(weights: np.ndarray, u: float, fallback: np.ndarray | None = None) -> int:
+    w = np.asarray(weights, dtype=np.float32)
+    c = np.cumsum(w.astype(np.float64))
+    total = c[-1]
+    if not total > 0.0:
+        src = w if fallback is None else np.asarray(fallback, dtype=np.float32)
+        return int(np.argmax(src))
+    thr = np.float64(np.float32(u)) * total
+    idx = int(np.searchsorted(c, thr, side="right"))
+    if idx >= w.shape[0]:
+        idx = int(np.nonzero(w > 0)[0][-1])
+    return idx
+
+
+def rejection_sample(target_probs, bonus_ids, draft_probs, draft_ids, u_accept, u_recover,
+                     proposal_lens=None):
+    """Returns (out_ids [B, k+1] int64 with -1 padding, counters [accepted, emitted, draft])."""
+    p = np.asarray(target_probs, dtype=np.float32)
+    q = np.asarray(draft_probs, dtype=np.float32)
+    x = np.asarray(draft_ids, dtype=np.int64)
+    ua = np.asarray(u_accept, dtype=np.float32)
+    ur = np.asarray(u_recover, dtype=np.float32)
+    bonus = np.asarray(bonus_ids, dtype=np.int64).reshape(-1)
+    B, k1, V = p.shape
+    k = k1 - 1
+    out = np.full((B, k + 1), -1, dtype=np.int64)
+    counters = np.zeros(3, dtype=np.int64)
+    for b in range(B):
+        L = k if proposal_lens is None else int(min(max(int(proposal_lens[b]), 0), k))
+        j = 0
+        while j < L:
+            tok = int(x[b, j])
+            ok = False
+            if 0 <= tok < V:
+                uq = np.float32(ua[b, j]) * np.float32(q[b, j, tok])  # f32 product
+                ok = bool(uq < p[b, j, tok])
+            if not ok:
+                break
+            out[b, j] = tok
+            j += 1
+        if j == L and L == k:
+            out[b, j] = bonus[b]
+        elif j < L:
+            resid = np.maximum(p[b, j] - q[b, j], np.float32(0))
+            out[b, j] = inverse_cdf(resid, ur[b, j], fallback=p[b, j])
+        else:  # every proposal of a short sequence accepted: draw from p_L
+            out[b, j] = inverse_cdf(p[b, j], ur[b, j])
+        counters += (j, j + 1, L)
+    return out, counters
+
+
+def greedy_verify(target_ids, draft_ids, proposal_lens=None):
+    t = np.asarray(target_ids, dtype=np.int64)
+    x = np.asarray(draft_ids, dtype=np.int64)
+    B, k1 = t.shape
+    k = k1 - 1
+    out = np.full((B, k + 1), -1, dtype=np.int64)
+    counters = np.zeros(3, dtype=np.int64)
+    for b in range(B):
+        L = k if proposal_lens is None else int(min(max(int(proposal_lens[b]), 0), k))
+        j = 0
+        while j < L and x[b, j] == t[b, j]:
+            out[b, j] = x[b, j]
+            j += 1
+        out[b, j] = t[b, j]
+        counters += (j, j + 1, L)
+    return out, counters
+
+
+def argmax_rows(logits) -> np.ndarray:
+    return np.argmax(np.asarray(logits, dtype=np.float32), axis=-1).astype(np.int64)
+
+
+def softmax_rows(logits, temperature: float = 1.0) -> np.ndarray:
+    z = np.asarray(logits, dtype=np.float32) * np.float32(1.0 / temperature)
+    z = z - z.max(axis=-1, keepdims=True)
+    e = np.exp(z.astype(np.float32))
+    s = e.astype(np.float64).sum(axis=-1, keepdims=True)
+    return (e * (1.0 / s).astype(np.float32)).astype(np.float32)
+
+
+def sample_rows(probs, uniforms) -> np.ndarray:
+    p = np.asarray(probs, dtype=np.float32)
+    return np.array([inverse_cdf(p[r], uniforms[r]) for r in range(p.shape[0])], dtype=np.int64)

@@ -1,0 +1,115 @@
+"""ctypes binding of libsd_amd.so (the C ABI declared in include/sd_amd.h).
+
+There is no fallback: if the library is missing or a call fails, an exception
+is raised.  Tensors cross the boundary as raw device pointers only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_LIB_NAME = "libsd_amd.so"
+_lib: Optional[C.CDLL] = None
+
+c_i32p = C.POINTER(C.c_int32)
+vp = C.c_void_p
+i64 = C.c_int64
+i32 = C.c_int
+
+
+class SdError(RuntimeError):
+    pass
+
+
+class LayerWeights(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "attn_norm_w", "attn_norm_b", "qkv_w", "qkv_b", "o_w", "o_b", "mlp_norm_w", "mlp_norm_b",
+        "up_w", "up_b", "down_w", "down_b")]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("arch", i32), ("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32),
+        ("head_dim", i32), ("ffn", i32), ("vocab", i32), ("max_pos", i32), ("pos_bias", i32),
+        ("norm_eps", C.c_float), ("attn_scale", C.c_float),
+        ("embed", vp), ("pos_table", vp), ("rope_cs", vp), ("final_norm_w", vp),
+        ("final_norm_b", vp), ("lm_head", vp), ("layers", C.POINTER(LayerWeights)),
+    ]
+
+
+class KvCacheDesc(C.Structure):
+    _fields_ = [("k_cache", vp), ("v_cache", vp), ("layer_stride_bytes", i64),
+                ("block_tables", vp), ("max_blocks_per_seq", i32)]
+
+
+class ForwardArgs(C.Structure):
+    _fields_ = [("B", i32), ("q_len", i32), ("token_ids", vp), ("tok_stride", i64),
+                ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
+                ("split_tokens", i32), ("logits", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/sd_amd.h declares.
+SIGNATURES = {
+    "sd_version": (i32, []),
+    "sd_last_error": (i32, [C.c_char_p, C.c_size_t]),
+    "sd_device_info": (i32, [C.POINTER(i32), C.c_char_p, C.c_size_t]),
+    "sd_rejection_sample": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sd_greedy_verify": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
+    "sd_argmax_rows": (i32, [vp, i64, vp, i32, i32, vp]),
+    "sd_softmax_rows": (i32, [vp, i64, C.c_float, vp, i64, i32, i32, vp]),
+    "sd_sample_rows": (i32, [vp, i64, vp, vp, i32, i32, vp]),
+    "sd_rope_append": (i32, [vp, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "sd_paged_attention_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
+    "sd_paged_attention": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, i32,
+                                 i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
+    "sd_linear": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "sd_rmsnorm": (i32, [vp, i64, vp, vp, i64, i32, i32, C.c_float, vp]),
+    "sd_layernorm": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, C.c_float, vp]),
+    "sd_embed": (i32, [vp, i64, i64, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "sd_model_create": (vp, [C.POINTER(ModelDesc)]),
+    "sd_model_destroy": (None, [vp]),
+    "sd_model_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
+    "sd_model_forward": (i32, [vp, C.POINTER(KvCacheDesc), C.POINTER(ForwardArgs), vp,
+                               C.c_size_t, vp]),
+    "sd_store_proposal": (i32, [vp, vp, i32, i32, vp, vp, i64, C.c_float, C.c_uint32, i32, vp]),
+    "sd_gather_proposals": (i32, [vp, vp, i32, i32, vp]),
+    "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, i32, vp]),
+    "sd_graph_begin": (i32, [vp]),
+    "sd_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "sd_graph_launch": (i32, [vp, vp]),
+    "sd_graph_destroy": (None, [vp]),
+}
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load() -> C.CDLL:
+    """Loads the in-tree library and declares every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SdError(f"{path} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
+                      "this package has no CPU or PyTorch fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().sd_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise SdError(f"{what} failed ({rc}): {last_error()}")

@@ -1,0 +1,412 @@
+// Paged-KV attention for the verify pass (k+1 query tokens per sequence) and
+// for decode (1 or 2 query tokens), plus rotary embedding + cache append.
+//
+// One workgroup = 4 waves = one (sequence, KV head, key split).  All query
+// rows that share the KV head (q_len * Hq/Hkv <= 64) ride in the N dimension
+// of 32x32x16 bf16 MFMAs, so the context K/V is streamed from HBM exactly once
+// per (sequence, layer, KV head).  The page layouts make every MFMA operand
+// fragment a contiguous 16-byte piece of a page: K and V go HBM -> VGPR ->
+// MFMA with 512 B / 1 KiB contiguous segments per wave instruction.
+//
+//   S^T[key][m] = K[key][:] . Q[m][:]          A = K page rows, B = Q^T
+//   O^T[d][m]  += V^T[d][key] * P^T[key][m]    A = V^T page rows, B = P^T
+//
+// With keys on the MFMA row index, the S^T accumulator of a lane holds 16 keys
+// of ONE query row, so the online softmax is lane-local plus one exchange
+// between the two half-waves, and the exponentiated accumulator registers are
+// directly the B operand of the P.V MFMA (the V page stores its 16 tokens in
+// the key order those registers have: see sd_v_slot).
+//
+// Every query row's arithmetic depends only on that row's q, its position and
+// the cache contents: tiles are 32 keys at absolute positions, tile j of a
+// split always goes to wave j%4, waves and splits are merged in index order.
+// So a token scored as one of k+1 verify rows gets bit-identical output to the
+// same token scored alone.
+#include "sd_common.h"
+
+namespace {
+
+struct AttnArgs {
+  const bf16_t* q;
+  int64_t ldq;
+  const bf16_t* kc;
+  const bf16_t* vc;
+  const int32_t* block_tables;
+  int max_blocks;
+  const int32_t* seq_lens;
+  int pos_offset;
+  bf16_t* out;
+  int64_t ldo;
+  int q_len, Hq, Hkv;
+  float scale_log2;
+  int split_tokens, n_splits;
+  float* part_o;   // [B, Hkv, n_splits, MT*32, D]
+  float* part_ml;  // [B, Hkv, n_splits, MT*32, 2]
+};
+
+template <int D, int MT>
+__global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
+  constexpr int KS = D / 16;  // k-steps of the K.Q^T product
+  constexpr int DT = D / 32;  // 32-row tiles of O^T
+  constexpr int LDM = 33;     // padded m-stride of the LDS merge image
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sm_o = reinterpret_cast<float*>(smem_raw);          // [4][MT][D][LDM]
+  float* sm_m = sm_o + 4 * MT * D * LDM;                      // [4][MT][32]
+  float* sm_l = sm_m + 4 * MT * 32;                           // [4][MT][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  const int G = a.Hq / a.Hkv;
+  const int m_rows = a.q_len * G;
+  const int pos0 = a.seq_lens[b] + a.pos_offset;
+  const int kv_len = pos0 + a.q_len;
+  const int split_start = split * a.split_tokens;
+  if (split_start >= kv_len) return;
+  const int split_end = min(split_start + a.split_tokens, kv_len);
+  const int last_page = (kv_len - 1) >> 4;
+  const int32_t* bt = a.block_tables + (size_t)b * a.max_blocks;
+
+  // Q^T fragments (B operand): lane (r, h) holds Q[m = r][16s + 8h .. +8].
+  bf16x8 qf[MT][KS];
+  int kvlen_m[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 32 + r;
+    const bool valid = m < m_rows;
+    const int t = valid ? m / G : 0, g = valid ? m % G : 0;
+    kvlen_m[mt] = valid ? pos0 + t + 1 : 0;
+    const bf16_t* qrow = a.q + (size_t)(b * a.q_len + t) * a.ldq + (size_t)(kvh * G + g) * D;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (valid) v = *reinterpret_cast<const bf16x8*>(qrow + 16 * s + 8 * h);
+      qf[mt][s] = v;
+    }
+  }
+
+  f32x16 o_acc[MT][DT];
+  float m_run[MT], l_run[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    m_run[mt] = -INFINITY;
+    l_run[mt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o_acc[mt][dt][i] = 0.f;
+  }
+
+  const size_t page_elems = (size_t)D * 16;
+  for (int tile = (split_start >> 5) + w; tile * 32 < split_end; tile += 4) {
+    const int key0 = tile * 32;
+    const int pgA = min(tile * 2, last_page), pgB = min(tile * 2 + 1, last_page);
+    const int blkA = bt[pgA], blkB = bt[pgB];
+    // K fragments (A operand): lane (r, h) holds K[key0 + r][16s + 8h .. +8],
+    // which is chunk 2s+h, token r&15 of page r>>4.
+    const bf16_t* kpage = a.kc + ((size_t)((r >> 4) ? blkB : blkA) * a.Hkv + kvh) * page_elems;
+    bf16x8 kf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      kf[s] = *reinterpret_cast<const bf16x8*>(kpage + ((2 * s + h) * 16 + (r & 15)) * 8);
+    // V^T fragments (A operand): lane (r, h) holds row d = 32dt + r, slots 8h..8h+7
+    // of page s.
+    const bf16_t* vpage[2] = {a.vc + ((size_t)blkA * a.Hkv + kvh) * page_elems,
+                              a.vc + ((size_t)blkB * a.Hkv + kvh) * page_elems};
+    bf16x8 vf[2][DT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        vf[s][dt] = *reinterpret_cast<const bf16x8*>(vpage[s] + (dt * 32 + r) * 16 + 8 * h);
+
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      f32x16 s_acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[mt][s], s_acc, 0, 0, 0);
+
+      // Online softmax of row m = 32mt + r over this lane's 16 keys.
+      float sv[16];
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        sv[i] = key < kvlen_m[mt] ? s_acc[i] * a.scale_log2 : -INFINITY;
+        tmax = fmaxf(tmax, sv[i]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run[mt], tmax);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_use);
+      float psum = 0.f;
+      bf16x8 pf[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(sv[i] - m_use);
+        psum += p;
+        pf[i >> 3][i & 7] = (bf16_t)p;
+      }
+      l_run[mt] = l_run[mt] * alpha + psum;
+      m_run[mt] = m_new;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o_acc[mt][dt][i] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          o_acc[mt][dt] =
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s][dt], pf[s], o_acc[mt][dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // Publish this wave's (m, l, O^T) to LDS; merge the 4 waves in index order.
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const float l_tot = l_run[mt] + __shfl_xor(l_run[mt], 32, 64);
+    if (h == 0) {
+      sm_m[(w * MT + mt) * 32 + r] = m_run[mt];
+      sm_l[(w * MT + mt) * 32 + r] = l_tot;
+    }
+    float* so = sm_o + (size_t)(w * MT + mt) * D * LDM;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int d = dt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        so[d * LDM + r] = o_acc[mt][dt][i];
+      }
+  }
+  __syncthreads();
+
+  const bool direct = a.n_splits == 1;
+  const size_t part_base = ((size_t)(b * a.Hkv + kvh) * a.n_splits + split) * (MT * 32);
+  for (int e = tid; e < MT * 32 * D; e += 256) {
+    const int d = e % D;
+    const int m = e / D;  // 0 .. MT*32-1
+    const int mt = m >> 5, mr = m & 31;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) mx = fmaxf(mx, sm_m[(ww * MT + mt) * 32 + mr]);
+    float o = 0.f, l = 0.f;
+    if (mx != -INFINITY) {
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const float f = __builtin_amdgcn_exp2f(sm_m[(ww * MT + mt) * 32 + mr] - mx);
+        o += f * sm_o[((size_t)(ww * MT + mt) * D + d) * LDM + mr];
+        l += f * sm_l[(ww * MT + mt) * 32 + mr];
+      }
+    }
+    if (direct) {
+      if (m < m_rows) {
+        const int t = m / G, g = m % G;
+        a.out[(size_t)(b * a.q_len + t) * a.ldo + (size_t)(kvh * G + g) * D + d] =
+            (bf16_t)(l > 0.f ? o / l : 0.f);
+      }
+    } else {
+      a.part_o[(part_base + m) * D + d] = o;
+      if (d == 0) {
+        a.part_ml[(part_base + m) * 2 + 0] = mx;
+        a.part_ml[(part_base + m) * 2 + 1] = l;
+      }
+    }
+  }
+}
+
+// Merges the per-split partials of one (sequence, token, head) in split order.
+template <int D>
+__global__ __launch_bounds__(D) void attn_merge_kernel(AttnArgs a, int m_pad) {
+  const int d = threadIdx.x;
+  const int head = blockIdx.x, t = blockIdx.y, b = blockIdx.z;
+  const int G = a.Hq / a.Hkv;
+  const int kvh = head / G, g = head % G;
+  const int m = t * G + g;
+  const int kv_len = a.seq_lens[b] + a.pos_offset + a.q_len;
+  const int n_valid = min((kv_len + a.split_tokens - 1) / a.split_tokens, a.n_splits);
+  const size_t base = (size_t)(b * a.Hkv + kvh) * a.n_splits;
+  float mx = -INFINITY;
+  for (int s = 0; s < n_valid; ++s)
+    mx = fmaxf(mx, a.part_ml[((base + s) * m_pad + m) * 2]);
+  float o = 0.f, l = 0.f;
+  if (mx != -INFINITY) {
+    for (int s = 0; s < n_valid; ++s) {
+      const size_t row = (base + s) * m_pad + m;
+      const float f = __builtin_amdgcn_exp2f(a.part_ml[row * 2] - mx);
+      o += f * a.part_o[row * D + d];
+      l += f * a.part_ml[row * 2 + 1];
+    }
+  }
+  a.out[(size_t)(b * a.q_len + t) * a.ldo + (size_t)head * D + d] =
+      (bf16_t)(l > 0.f ? o / l : 0.f);
+}
+
+__global__ __launch_bounds__(256) void rope_append_kernel(
+    bf16_t* __restrict__ qkv, const float* __restrict__ rope_cs, int max_pos,
+    bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int32_t* __restrict__ block_tables,
+    int max_blocks, const int32_t* __restrict__ seq_lens, int pos_offset, int q_len, int Hq,
+    int Hkv, int D) {
+  const int row = blockIdx.x;  // token row
+  const int b = row / q_len, t = row % q_len;
+  const int pos = seq_lens[b] + pos_offset + t;
+  if (pos < 0) return;
+  const int half = D / 2;
+  const int page = block_tables[(size_t)b * max_blocks + (pos >> 4)];
+  const int slot = pos & 15;
+  bf16_t* x = qkv + (size_t)row * (Hq + 2 * Hkv) * D;
+  const float* cs = rope_cs ? rope_cs + (size_t)min(pos, max_pos - 1) * D : nullptr;
+  const int n_items = (Hq + 2 * Hkv) * half;
+  for (int it = threadIdx.x; it < n_items; it += blockDim.x) {
+    const int head = it / half, i = it % half;
+    bf16_t* hp = x + (size_t)head * D;
+    float lo = (float)hp[i], hi = (float)hp[i + half];
+    if (head < Hq + Hkv && cs) {
+      const float c = cs[i], s = cs[half + i];
+      const float nlo = lo * c - hi * s;
+      const float nhi = hi * c + lo * s;
+      lo = nlo;
+      hi = nhi;
+    }
+    if (head < Hq) {
+      hp[i] = (bf16_t)lo;
+      hp[i + half] = (bf16_t)hi;
+    } else if (head < Hq + Hkv) {
+      const int kh = head - Hq;
+      bf16_t* kp = kc + ((size_t)page * Hkv + kh) * D * 16;
+      kp[((i >> 3) * 16 + slot) * 8 + (i & 7)] = (bf16_t)lo;
+      const int i2 = i + half;
+      kp[((i2 >> 3) * 16 + slot) * 8 + (i2 & 7)] = (bf16_t)hi;
+    } else {
+      const int vh = head - Hq - Hkv;
+      bf16_t* vp = vc + ((size_t)page * Hkv + vh) * D * 16;
+      const int sl = sd_v_slot(slot);
+      vp[i * 16 + sl] = (bf16_t)lo;
+      vp[(i + half) * 16 + sl] = (bf16_t)hi;
+    }
+  }
+}
+
+template <int D, int MT>
+size_t attn_lds_bytes() {
+  return (size_t)(4 * MT * D * 33 + 2 * 4 * MT * 32) * sizeof(float);
+}
+
+template <int D, int MT>
+int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
+  const size_t lds = attn_lds_bytes<D, MT>();
+  static bool attr_set = false;  // raise the dynamic-LDS limit once per process
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attn_kernel<D, MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      sd_set_error("sd_paged_attention: hipFuncSetAttribute(%zu) failed: %s", lds,
+                   hipGetErrorString(e));
+      return SD_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((paged_attn_kernel<D, MT>), dim3(a.Hkv, a.n_splits, B), dim3(256), lds,
+                     stream, a);
+  SD_CHECK_LAUNCH("sd_paged_attention");
+  if (a.n_splits > 1) {
+    hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(a.Hq, a.q_len, B), dim3(D), 0, stream, a,
+                       MT * 32);
+    SD_CHECK_LAUNCH("sd_paged_attention(merge)");
+  }
+  return SD_OK;
+}
+
+int n_splits_for(int max_ctx, int split_tokens) {
+  return max(1, (max_ctx + split_tokens - 1) / split_tokens);
+}
+
+}  // namespace
+
+extern "C" size_t sd_paged_attention_workspace_bytes(int B, int q_len, int Hq, int D,
+                                                     int max_ctx, int split_tokens) {
+  (void)q_len;
+  if (B <= 0 || split_tokens <= 0) return 0;
+  const int n_splits = n_splits_for(max_ctx, split_tokens);
+  if (n_splits == 1) return 16;
+  // Rows are padded to 64 per KV head; Hq bounds Hkv.
+  const size_t rows = (size_t)B * Hq * n_splits * 64;
+  return rows * D * sizeof(float) + rows * 2 * sizeof(float) + 256;
+}
+
+extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cache,
+                                  const void* v_cache, const int32_t* block_tables,
+                                  int max_blocks_per_seq, const int32_t* seq_lens,
+                                  int pos_offset, void* out, int64_t ldo, int B, int q_len,
+                                  int Hq, int Hkv, int D, float scale, int max_ctx,
+                                  int split_tokens, void* workspace, size_t workspace_bytes,
+                                  sd_stream_t stream) {
+  SD_REQUIRE(q && k_cache && v_cache && block_tables && seq_lens && out, SD_ERR_INVALID,
+             "sd_paged_attention: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, SD_ERR_INVALID,
+             "sd_paged_attention: bad head counts (Hq=%d Hkv=%d)", Hq, Hkv);
+  SD_REQUIRE(D == 64 || D == 128, SD_ERR_UNSUPPORTED,
+             "sd_paged_attention: head_dim %d not in {64,128}", D);
+  const int G = Hq / Hkv;
+  SD_REQUIRE(q_len * G <= 64, SD_ERR_UNSUPPORTED,
+             "sd_paged_attention: q_len*(Hq/Hkv) = %d > 64", q_len * G);
+  SD_REQUIRE(split_tokens >= 128 && split_tokens % 128 == 0, SD_ERR_INVALID,
+             "sd_paged_attention: split_tokens %d must be a positive multiple of 128",
+             split_tokens);
+  SD_REQUIRE(max_ctx >= 1 && max_blocks_per_seq * 16 >= max_ctx, SD_ERR_INVALID,
+             "sd_paged_attention: max_ctx %d exceeds block table (%d pages)", max_ctx,
+             max_blocks_per_seq);
+  SD_REQUIRE(ldq % 8 == 0 && sd_aligned16(q) && ldo >= (int64_t)Hq * D, SD_ERR_INVALID,
+             "sd_paged_attention: q rows must be 16-byte aligned");
+  if (B == 0) return SD_OK;
+  AttnArgs a;
+  a.q = (const bf16_t*)q;
+  a.ldq = ldq;
+  a.kc = (const bf16_t*)k_cache;
+  a.vc = (const bf16_t*)v_cache;
+  a.block_tables = block_tables;
+  a.max_blocks = max_blocks_per_seq;
+  a.seq_lens = seq_lens;
+  a.pos_offset = pos_offset;
+  a.out = (bf16_t*)out;
+  a.ldo = ldo;
+  a.q_len = q_len;
+  a.Hq = Hq;
+  a.Hkv = Hkv;
+  a.scale_log2 = scale * 1.4426950408889634f;
+  a.split_tokens = split_tokens;
+  a.n_splits = n_splits_for(max_ctx, split_tokens);
+  a.part_o = nullptr;
+  a.part_ml = nullptr;
+  const int MT = q_len * G <= 32 ? 1 : 2;
+  if (a.n_splits > 1) {
+    const size_t rows = (size_t)B * Hkv * a.n_splits * (MT * 32);
+    const size_t need = rows * D * sizeof(float) + rows * 2 * sizeof(float);
+    SD_REQUIRE(workspace && workspace_bytes >= need, SD_ERR_WORKSPACE,
+               "sd_paged_attention: workspace %zu < %zu bytes", workspace_bytes, need);
+    a.part_o = (float*)workspace;
+    a.part_ml = a.part_o + rows * D;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) return MT == 1 ? launch_attn<128, 1>(a, B, st) : launch_attn<128, 2>(a, B, st);
+  return MT == 1 ? launch_attn<64, 1>(a, B, st) : launch_attn<64, 2>(a, B, st);
+}
+
+extern "C" int sd_rope_append(void* qkv, const float* rope_cs, int max_pos, void* k_cache,
+                              void* v_cache, const int32_t* block_tables,
+                              int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
+                              int B, int q_len, int Hq, int Hkv, int D, sd_stream_t stream) {
+  SD_REQUIRE(qkv && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
+             "sd_rope_append: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && D % 16 == 0 && D >= 16,
+             SD_ERR_INVALID, "sd_rope_append: bad shape (D=%d)", D);
+  SD_REQUIRE(!rope_cs || max_pos >= 1, SD_ERR_INVALID, "sd_rope_append: max_pos < 1");
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(rope_append_kernel, dim3(B * q_len), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)qkv, rope_cs, max_pos, (bf16_t*)k_cache, (bf16_t*)v_cache,
+                     block_tables, max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D);
+  SD_CHECK_LAUNCH("sd_rope_append");
+  return SD_OK;
+}

@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 speculative-decoding kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sd_amd.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define SD_WAVE 64
+
+// Error text is per host thread; set by the launch wrappers.
+void sd_set_error(const char* fmt, ...);
+
+#define SD_REQUIRE(cond, code, ...)            \
+  do {                                         \
+    if (!(cond)) {                             \
+      sd_set_error(__VA_ARGS__);               \
+      return (code);                           \
+    }                                          \
+  } while (0)
+
+#define SD_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      sd_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return SD_ERR_HIP;                                                   \
+    }                                                                      \
+  } while (0)
+
+static inline bool sd_aligned16(const void* p) {
+  return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }
+// Round-trip through bf16: what a bf16 tensor op would have stored.
+__device__ __forceinline__ float round_bf16(float v) { return (float)(bf16_t)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Slot of token t (0..15) inside a V page row: bits 2 and 3 swapped, so that
+// the 8 consecutive slots a lane reads are the keys its accumulator registers
+// hold after the K*Q^T MFMA.
+__host__ __device__ __forceinline__ int sd_v_slot(int t) {
+  return (t & 3) | (((t >> 3) & 1) << 2) | (((t >> 2) & 1) << 3);
+}

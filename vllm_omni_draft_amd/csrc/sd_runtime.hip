@@ -1,0 +1,247 @@
+// Host runtime of the library: error text, device info, the decoder-model
+// forward pass (a fixed sequence of kernel launches on the caller's stream,
+// no synchronisation, no allocation) and hipGraph capture helpers so that a
+// whole speculative step replays as one launch.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "sd_common.h"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+void sd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int sd_version(void) { return 100; }
+
+extern "C" int sd_last_error(char* buf, size_t n) {
+  if (!buf || n == 0) return SD_ERR_INVALID;
+  strncpy(buf, g_err, n - 1);
+  buf[n - 1] = '\0';
+  return SD_OK;
+}
+
+extern "C" int sd_device_info(int* cu_count, char* name, size_t n) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) {
+    sd_set_error("sd_device_info: hipGetDevice: %s", hipGetErrorString(e));
+    return SD_ERR_HIP;
+  }
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) {
+    sd_set_error("sd_device_info: hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return SD_ERR_HIP;
+  }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (name && n) {
+    strncpy(name, prop.gcnArchName, n - 1);
+    name[n - 1] = '\0';
+  }
+  return SD_OK;
+}
+
+struct sd_model {
+  sd_model_desc d;
+  std::vector<sd_layer_weights> layers;
+};
+
+extern "C" sd_model* sd_model_create(const sd_model_desc* desc) {
+  if (!desc || !desc->layers || desc->n_layers < 1) {
+    sd_set_error("sd_model_create: null descriptor or no layers");
+    return nullptr;
+  }
+  const sd_model_desc& d = *desc;
+  if (d.arch != SD_ARCH_LLAMA && d.arch != SD_ARCH_OPT) {
+    sd_set_error("sd_model_create: unknown arch %d", d.arch);
+    return nullptr;
+  }
+  if (d.hidden % 8 || d.ffn % 8 || (d.head_dim != 64 && d.head_dim != 128) ||
+      d.n_heads % d.n_kv_heads || d.vocab < 1 || !d.embed || !d.lm_head || !d.final_norm_w) {
+    sd_set_error("sd_model_create: unsupported shape (H=%d F=%d D=%d Hq=%d Hkv=%d)", d.hidden,
+                 d.ffn, d.head_dim, d.n_heads, d.n_kv_heads);
+    return nullptr;
+  }
+  if (d.arch == SD_ARCH_LLAMA && !d.rope_cs) {
+    sd_set_error("sd_model_create: llama arch needs a rope table");
+    return nullptr;
+  }
+  if (d.arch == SD_ARCH_OPT && !d.pos_table) {
+    sd_set_error("sd_model_create: opt arch needs a position table");
+    return nullptr;
+  }
+  sd_model* m = new sd_model;
+  m->d = d;
+  m->layers.assign(d.layers, d.layers + d.n_layers);
+  m->d.layers = m->layers.data();
+  for (int i = 0; i < d.n_layers; ++i) {
+    const sd_layer_weights& l = m->layers[i];
+    if (!l.attn_norm_w || !l.qkv_w || !l.o_w || !l.mlp_norm_w || !l.up_w || !l.down_w) {
+      sd_set_error("sd_model_create: layer %d has a null weight", i);
+      delete m;
+      return nullptr;
+    }
+  }
+  return m;
+}
+
+extern "C" void sd_model_destroy(sd_model* m) { delete m; }
+
+namespace {
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Workspace {
+  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, total;
+};
+
+Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int split_tokens) {
+  Workspace w;
+  const size_t qkv_cols = (size_t)(d.n_heads + 2 * d.n_kv_heads) * d.head_dim;
+  size_t off = 0;
+  w.h = off;    off += align256((size_t)rows * d.hidden * 2);
+  w.xn = off;   off += align256((size_t)rows * d.hidden * 2);
+  w.qkv = off;  off += align256((size_t)rows * qkv_cols * 2);
+  w.attn = off; off += align256((size_t)rows * d.n_heads * d.head_dim * 2);
+  w.act = off;  off += align256((size_t)rows * d.ffn * 2);
+  // rows bounds B and q_len separately; B*q_len rows in total
+  w.attn_ws_bytes = sd_paged_attention_workspace_bytes(rows, rows, d.n_heads, d.head_dim,
+                                                       max_ctx, split_tokens);
+  w.attn_ws = off; off += align256(w.attn_ws_bytes);
+  w.total = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,
+                                           int split_tokens) {
+  if (!m || max_rows < 1) return 0;
+  return plan_workspace(m->d, max_rows, max_ctx, split_tokens).total;
+}
+
+#define SD_TRY(expr)            \
+  do {                          \
+    int rc__ = (expr);          \
+    if (rc__ != SD_OK) return rc__; \
+  } while (0)
+
+extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_forward_args* a,
+                                void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+  SD_REQUIRE(m && kv && a && workspace, SD_ERR_INVALID, "sd_model_forward: null argument");
+  const sd_model_desc& d = m->d;
+  const int rows = a->B * a->q_len;
+  SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= 8, SD_ERR_UNSUPPORTED,
+             "sd_model_forward: B*q_len = %d outside 1..8", rows);
+  SD_REQUIRE(a->token_ids && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
+             SD_ERR_INVALID, "sd_model_forward: null buffer");
+  SD_REQUIRE(a->max_ctx >= 1 && a->max_ctx <= d.max_pos, SD_ERR_INVALID,
+             "sd_model_forward: max_ctx %d outside 1..max_pos %d", a->max_ctx, d.max_pos);
+  const Workspace w = plan_workspace(d, rows, a->max_ctx, a->split_tokens);
+  SD_REQUIRE(workspace_bytes >= w.total, SD_ERR_WORKSPACE,
+             "sd_model_forward: workspace %zu < %zu bytes", workspace_bytes, w.total);
+  SD_REQUIRE(sd_aligned16(workspace), SD_ERR_INVALID, "sd_model_forward: workspace unaligned");
+
+  char* base = (char*)workspace;
+  void* h = base + w.h;
+  void* xn = base + w.xn;
+  void* qkv = base + w.qkv;
+  void* attn = base + w.attn;
+  void* act = base + w.act;
+  void* attn_ws = base + w.attn_ws;
+  const int H = d.hidden, D = d.head_dim, Hq = d.n_heads, Hkv = d.n_kv_heads, F = d.ffn;
+  const int64_t qkv_cols = (int64_t)(Hq + 2 * Hkv) * D;
+  const bool llama = d.arch == SD_ARCH_LLAMA;
+
+  SD_TRY(sd_embed(a->token_ids, a->tok_stride, a->tok_offset, d.embed, d.pos_table, d.pos_bias,
+                  a->seq_lens, a->pos_offset, h, a->B, a->q_len, H, d.vocab, stream));
+  for (int li = 0; li < d.n_layers; ++li) {
+    const sd_layer_weights& l = m->layers[li];
+    void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
+    void* vc = (char*)kv->v_cache + (size_t)li * kv->layer_stride_bytes;
+    if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
+    else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
+    SD_TRY(sd_linear(l.qkv_w, xn, H, l.qkv_b, nullptr, qkv, qkv_cols, rows, (int)qkv_cols, H,
+                     SD_EPI_STORE, stream));
+    SD_TRY(sd_rope_append(qkv, llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
+                          kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len, Hq,
+                          Hkv, D, stream));
+    SD_TRY(sd_paged_attention(qkv, qkv_cols, kc, vc, kv->block_tables, kv->max_blocks_per_seq,
+                              a->seq_lens, a->pos_offset, attn, (int64_t)Hq * D, a->B, a->q_len,
+                              Hq, Hkv, D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
+                              w.attn_ws_bytes, stream));
+    SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, l.o_b, h, h, H, rows, H, Hq * D,
+                     SD_EPI_RESIDUAL, stream));
+    if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
+    else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
+    SD_TRY(sd_linear(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H,
+                     llama ? SD_EPI_SILU_MUL : SD_EPI_RELU, stream));
+    SD_TRY(sd_linear(l.down_w, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL, stream));
+  }
+  if (a->logits) {
+    if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
+    else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
+    SD_TRY(sd_linear(d.lm_head, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
+                     SD_EPI_F32, stream));
+  }
+  return SD_OK;
+}
+
+struct sd_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+extern "C" int sd_graph_begin(sd_stream_t stream) {
+  hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    sd_set_error("sd_graph_begin: %s", hipGetErrorString(e));
+    return SD_ERR_HIP;
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_graph_end(sd_stream_t stream, sd_graph** out) {
+  SD_REQUIRE(out, SD_ERR_INVALID, "sd_graph_end: null out");
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+  if (e != hipSuccess || !g) {
+    sd_set_error("sd_graph_end: capture failed: %s", hipGetErrorString(e));
+    return SD_ERR_HIP;
+  }
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    hipGraphDestroy(g);
+    sd_set_error("sd_graph_end: instantiate failed: %s", hipGetErrorString(e));
+    return SD_ERR_HIP;
+  }
+  *out = new sd_graph{g, ex};
+  return SD_OK;
+}
+
+extern "C" int sd_graph_launch(sd_graph* g, sd_stream_t stream) {
+  SD_REQUIRE(g, SD_ERR_INVALID, "sd_graph_launch: null graph");
+  hipError_t e = hipGraphLaunch(g->exec, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    sd_set_error("sd_graph_launch: %s", hipGetErrorString(e));
+    return SD_ERR_HIP;
+  }
+  return SD_OK;
+}
+
+extern "C" void sd_graph_destroy(sd_graph* g) {
+  if (!g) return;
+  hipGraphExecDestroy(g->exec);
+  hipGraphDestroy(g->graph);
+  delete g;
+}

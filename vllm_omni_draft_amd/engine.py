@@ -1,0 +1,335 @@
+"""SpecEngine: the device-resident speculative-decoding loop of one GPU.
+
+Holds the target and draft DecoderModels, their paged KV caches and the
+per-sequence state (sequence lengths, the token window {t[n-2], t[n-1],
+d_1..d_k}, generated tokens, acceptance counters) as device tensors, and
+enqueues one whole speculative step — k draft passes, one (k+1)-token target
+verify pass, acceptance, state update — without any host synchronisation.  A
+step of fixed shape is captured into a hipGraph and replayed.
+
+State invariant between steps, for a sequence of n tokens: both caches hold
+K/V of tokens 0..n-2 (the draft's may lack token n-2 after a step in which
+every proposal was accepted; its first pass therefore always feeds the last
+TWO tokens, which is idempotent when it did not).
+
+This is the machinery behind the SpecDecodeWorker / Proposer / Scorer surface
+in spec_decode_worker.py (vLLM-V0 names; the reference only documents the
+V1 step contract they plug into, /root/reference/src/doc/engine_core.md:117-122).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from .kv_cache import PagedKVCache
+from .model_runner import MAX_ROWS, DecoderModel
+from .weights import ModelWeights
+
+
+@dataclass
+class EngineConfig:
+    k: int = 5                     # proposals per step; 0 = plain autoregressive decoding
+    max_batch: int = 1
+    max_seq_len: int = 2048        # prompt + generated tokens (+ k+1 slack is added)
+    split_tokens: int = 256        # attention keys per workgroup
+    temperature: float = 0.0       # 0 = greedy
+    seed: int = 0
+    use_graph: bool = True
+    gen_capacity: int = 4096       # generated tokens kept on the device per sequence
+
+
+class SpecEngine:
+    def __init__(self, target: ModelWeights, draft: Optional[ModelWeights], cfg: EngineConfig):
+        if cfg.k < 0 or cfg.k > 7:
+            raise ValueError("k must be in 0..7")
+        if cfg.k > 0 and draft is None:
+            raise ValueError("k > 0 needs a draft model")
+        if draft is not None and draft.cfg.vocab != target.cfg.vocab:
+            raise ValueError("draft and target must share a vocabulary "
+                             f"({draft.cfg.vocab} vs {target.cfg.vocab})")
+        self.cfg = cfg
+        self.k = cfg.k
+        dev = target.embed.device
+        self.device = dev
+        B, k = cfg.max_batch, cfg.k
+        self.max_ctx = cfg.max_seq_len + k + 2
+        self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens)
+        self.draft = DecoderModel(draft, self.max_ctx, cfg.split_tokens) if k > 0 else None
+        self.V = target.cfg.vocab
+        pages = PagedKVCache.pages_for(target.cfg, B, self.max_ctx)
+        self.t_kv = PagedKVCache(target.cfg, pages, B, self.max_ctx, dev)
+        self.d_kv = PagedKVCache(draft.cfg, pages, B, self.max_ctx, dev) if k > 0 else None
+
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.seq_lens = torch.zeros(B, **i32)
+        self.tok_buf = torch.zeros(B, k + 2, **i32)
+        self.gen_tokens = torch.zeros(B, cfg.gen_capacity, **i32)
+        self.gen_counts = torch.zeros(B, **i32)
+        self.counters = torch.zeros(3, dtype=torch.int64, device=dev)
+        self.zero_lens = torch.zeros(B, **i32)
+        self.prompt_buf = torch.zeros(max(cfg.max_seq_len, 8), **i32)
+        self.t_logits = torch.empty(MAX_ROWS if k == 0 else max(MAX_ROWS, B * (k + 1)), self.V,
+                                    dtype=torch.float32, device=dev)
+        self.d_logits = torch.empty(max(MAX_ROWS, 2 * B), self.V, dtype=torch.float32, device=dev)
+        self.ids_tmp = torch.zeros(max(B, 1), dtype=torch.int64, device=dev)
+        self.target_ids = torch.zeros(B, k + 1, dtype=torch.int64, device=dev)
+        self.draft_ids = torch.zeros(B, max(k, 1), dtype=torch.int64, device=dev)
+        self.out_ids = torch.full((B, k + 1), -1, dtype=torch.int64, device=dev)
+        self.sampling = cfg.temperature > 0.0
+        if self.sampling:
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.t_probs = torch.empty(B, k + 1, self.V, **f32)
+            self.d_probs = torch.empty(B, max(k, 1), self.V, **f32)
+            self.u_draft = torch.zeros(max(k, 1), B, **f32)
+            self.u_accept = torch.zeros(B, max(k, 1), **f32)
+            self.u_recover = torch.zeros(B, k + 1, **f32)
+            self.u_bonus = torch.zeros(B, **f32)
+            self.bonus_ids = torch.zeros(B, dtype=torch.int64, device=dev)
+            self.rng = torch.Generator(device=dev).manual_seed(cfg.seed)
+        # synthetic acceptance control (benchmarks with random weights)
+        self.truth: Optional[torch.Tensor] = None
+        self.accept_prob = 0.0
+        self.accept_seed = 0
+        self.active = 0                       # sequences currently in the batch
+        self.host_lens: List[int] = [0] * B   # upper bound of seq_lens known to the host
+        self.host_gen: List[int] = [0] * B
+        self._graph = None
+        self._graph_key = None
+        # stream capture is not allowed on the legacy default stream
+        self.stream = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)  # buffers above were filled on the default stream
+
+    # ------------------------------------------------------------------ requests
+    def reset(self) -> None:
+        with torch.cuda.stream(self.stream):
+            self._reset()
+
+    def _reset(self) -> None:
+        for b in range(self.cfg.max_batch):
+            self.t_kv.release(b)
+            if self.d_kv is not None:
+                self.d_kv.release(b)
+            self.host_lens[b] = 0
+            self.host_gen[b] = 0
+        self.seq_lens.zero_()
+        self.gen_counts.zero_()
+        self.counters.zero_()
+        self.active = 0
+
+    def set_synthetic_acceptance(self, truth: Optional[torch.Tensor], accept_prob: float,
+                                 seed: int = 0) -> None:
+        """truth [B, L] int32: token at every absolute position of the stream the
+        target would emit; each proposal is replaced by the true token with
+        probability accept_prob.  None switches the control off."""
+        if truth is not None and (truth.dtype != torch.int32 or truth.dim() != 2):
+            raise ValueError("truth must be an int32 [B, L] tensor")
+        self.truth = truth
+        self.accept_prob = float(accept_prob)
+        self.accept_seed = int(seed)
+        self._graph = None
+
+    def add_request(self, slot: int, prompt: Sequence[int]) -> int:
+        """Prefills both models with `prompt` into batch slot `slot`, emits the
+        first token from the target and returns it (this synchronises)."""
+        with torch.cuda.stream(self.stream):
+            return self._add_request(slot, prompt)
+
+    def _add_request(self, slot: int, prompt: Sequence[int]) -> int:
+        n = len(prompt)
+        if n < 1 or n + 1 > self.cfg.max_seq_len:
+            raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
+        if slot != self.active:
+            raise ValueError("slots must be filled in order (slot == number of active sequences)")
+        self.t_kv.ensure_capacity(slot, n + self.k + 2)
+        if self.d_kv is not None:
+            self.d_kv.ensure_capacity(slot, n + self.k + 2)
+        self.prompt_buf[:n].copy_(torch.tensor(list(prompt), dtype=torch.int32))
+        zl = self.zero_lens[slot:slot + 1]
+        for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
+            if model is None:
+                continue
+            for c0 in range(0, n, MAX_ROWS):
+                q = min(MAX_ROWS, n - c0)
+                last = c0 + q >= n
+                want = last and model is self.target
+                self._forward(model, kv, self.prompt_buf, 0, c0, zl, c0, 1, q,
+                              self.t_logits if want else None, slot0=slot)
+        # first generated token from the last prompt row
+        q_last = n - ((n - 1) // MAX_ROWS) * MAX_ROWS
+        row = self.t_logits[q_last - 1:q_last]
+        if self.sampling:
+            u = torch.rand(1, generator=self.rng, device=self.device)
+            probs = ops.softmax_rows(row, self.cfg.temperature)
+            first = ops.sample_rows(probs, u)
+        else:
+            first = ops.argmax_rows(row)
+        first_tok = int(first.item())
+        self.tok_buf[slot, 0] = int(prompt[-1])
+        self.tok_buf[slot, 1] = first_tok
+        self.seq_lens[slot] = n + 1
+        self.gen_tokens[slot, 0] = first_tok
+        self.gen_counts[slot] = 1
+        self.host_lens[slot] = n + 1
+        self.host_gen[slot] = 1
+        self.active += 1
+        return first_tok
+
+    # ------------------------------------------------------------------ passes
+    def _forward(self, model: DecoderModel, kv: PagedKVCache, tokens, tok_stride, tok_offset,
+                 seq_lens, pos_offset, B, q_len, logits, slot0: int = 0) -> None:
+        """One model pass over B sequences x q_len tokens, in sub-batches of at
+        most MAX_ROWS token rows."""
+        per = max(1, MAX_ROWS // q_len)
+        for b0 in range(0, B, per):
+            nb = min(per, B - b0)
+            sub_logits = None
+            if logits is not None:
+                sub_logits = logits[b0 * q_len:(b0 + nb) * q_len]
+            view = _KvView(kv, slot0 + b0)
+            model.forward(view, tokens[b0 * tok_stride:] if tok_stride else tokens, tok_stride,
+                          tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self.max_ctx)
+
+    def _enqueue_step(self) -> None:
+        B, k = self.active, self.k
+        stride = k + 2
+        if k == 0:
+            self._forward(self.target, self.t_kv, self.tok_buf, stride, 1, self.seq_lens, -1, B, 1,
+                          self.t_logits)
+            if self.sampling:
+                ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V))
+                ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp)
+            else:
+                ops.argmax_rows(self.t_logits[:B], out=self.ids_tmp)
+            ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf, self.gen_tokens,
+                              self.gen_counts, 0)
+            return
+        for i in range(k):
+            if i == 0:
+                self._forward(self.draft, self.d_kv, self.tok_buf, stride, 0, self.seq_lens, -2, B, 2,
+                              self.d_logits)
+                off, step = 1, 2
+            else:
+                self._forward(self.draft, self.d_kv, self.tok_buf, stride, 1 + i, self.seq_lens,
+                              -1 + i, B, 1, self.d_logits)
+                off, step = 0, 1
+            rows = self.d_logits[:B * step]
+            if self.sampling:
+                ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
+                                 out_ptr=self.d_probs.data_ptr() + i * self.V * 4, out_ld=k * self.V)
+                ops.sample_rows(self.d_probs.view(-1, self.V)[:B * k], self.u_draft[i],
+                                out=self.ids_tmp, row_offset=i, row_step=k)
+            else:
+                ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
+            ops.store_proposal(self.ids_tmp, self.tok_buf, k, i, self.seq_lens, self.truth,
+                               self.accept_prob, self.accept_seed)
+        self._forward(self.target, self.t_kv, self.tok_buf, stride, 1, self.seq_lens, -1, B, k + 1,
+                      self.t_logits)
+        ops.gather_proposals(self.tok_buf, self.draft_ids, k)
+        rows = self.t_logits[:B * (k + 1)]
+        if self.sampling:
+            ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V))
+            ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
+                            out=self.bonus_ids, row_offset=k, row_step=k + 1)
+            _lib.check(_lib.load().sd_rejection_sample(
+                self.t_probs.data_ptr(), self.bonus_ids.data_ptr(), self.d_probs.data_ptr(),
+                self.draft_ids.data_ptr(), self.u_accept.data_ptr(), self.u_recover.data_ptr(),
+                None, self.out_ids.data_ptr(), self.counters.data_ptr(), B, k, self.V,
+                torch.cuda.current_stream().cuda_stream), "sd_rejection_sample")
+        else:
+            ops.argmax_rows(rows, out=self.target_ids.view(-1))
+            ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], None, self.counters,
+                              out=self.out_ids)
+        ops.advance_state(self.out_ids, self.seq_lens, self.tok_buf, self.gen_tokens,
+                          self.gen_counts, k)
+
+    # ------------------------------------------------------------------ stepping
+    def _refresh_uniforms(self) -> None:
+        for t in (self.u_draft, self.u_accept, self.u_recover, self.u_bonus):
+            t.copy_(torch.rand(t.shape, generator=self.rng, device=self.device))
+
+    def step(self, sync: bool = True) -> Optional[List[List[int]]]:
+        """Runs one step for every active sequence.  With sync=True returns the
+        tokens each sequence emitted in this step (the V1 worker contract:
+        sampled_token_ids, one variable-length list per request)."""
+        with torch.cuda.stream(self.stream):
+            return self._step(sync)
+
+    def _step(self, sync: bool) -> Optional[List[List[int]]]:
+        B, k = self.active, self.k
+        if B == 0:
+            return [] if sync else None
+        for b in range(B):
+            need = self.host_lens[b] + k + 2
+            if need > self.max_ctx:
+                raise RuntimeError(f"sequence {b} would exceed max_seq_len")
+            self.t_kv.ensure_capacity(b, need)
+            if self.d_kv is not None:
+                self.d_kv.ensure_capacity(b, need)
+        if self.sampling:
+            self._refresh_uniforms()
+        stream = torch.cuda.current_stream().cuda_stream
+        lib = _lib.load()
+        if self.cfg.use_graph:
+            key = (B, k, self.truth is not None)
+            if self._graph is None or self._graph_key != key:
+                if self._graph is not None:
+                    lib.sd_graph_destroy(self._graph)
+                    self._graph = None
+                self._enqueue_step()          # eager warm-up step (also a real step)
+                torch.cuda.synchronize()
+                self._graph_key = key
+                g = C.c_void_p()
+                _lib.check(lib.sd_graph_begin(stream), "sd_graph_begin")
+                try:
+                    self._enqueue_step()
+                finally:
+                    rc = lib.sd_graph_end(stream, C.byref(g))
+                _lib.check(rc, "sd_graph_end")
+                self._graph = g
+                # the captured step has not run: the warm-up step is this call's step
+            else:
+                _lib.check(lib.sd_graph_launch(self._graph, stream), "sd_graph_launch")
+        else:
+            self._enqueue_step()
+        for b in range(B):
+            self.host_lens[b] += k + 1        # upper bound until the next read-back
+        if not sync:
+            return None
+        return self._read_back()
+
+    def read_back(self) -> List[List[int]]:
+        """Synchronises and returns the tokens emitted since the last read-back."""
+        with torch.cuda.stream(self.stream):
+            return self._read_back()
+
+    def _read_back(self) -> List[List[int]]:
+        B = self.active
+        counts = self.gen_counts[:B].tolist()
+        lens = self.seq_lens[:B].tolist()
+        out: List[List[int]] = []
+        for b in range(B):
+            lo, hi = self.host_gen[b], counts[b]
+            toks = self.gen_tokens[b, lo:min(hi, self.cfg.gen_capacity)].tolist() if hi > lo else []
+            out.append(toks)
+            self.host_gen[b] = hi
+            self.host_lens[b] = lens[b]
+        return out
+
+    def metrics(self) -> dict:
+        with torch.cuda.stream(self.stream):
+            acc, emit, draft = self.counters.tolist()
+        return {"accepted": acc, "emitted": emit, "draft": draft}
+
+
+class _KvView:
+    """PagedKVCache seen from batch slot `slot0` on (block-table rows shifted)."""
+
+    def __init__(self, kv: PagedKVCache, slot0: int):
+        self.k, self.v = kv.k, kv.v
+        self.layer_stride_bytes = kv.layer_stride_bytes
+        self.block_tables = kv.block_tables[slot0:]
+        self.max_blocks_per_seq = kv.max_blocks_per_seq

@@ -1,0 +1,87 @@
+"""Paged KV cache storage and page allocation.
+
+Page = 16 tokens of one KV head; layouts are documented in include/sd_amd.h.
+The cache is zero-filled at allocation (the attention kernel reads unwritten
+slots of a partly filled page and masks them, so they must be finite).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from .config import ModelConfig
+
+PAGE = 16
+
+
+class OutOfPages(RuntimeError):
+    pass
+
+
+class PageAllocator:
+    """Free-list allocator of cache pages shared by the sequences of one model."""
+
+    def __init__(self, num_pages: int):
+        self.num_pages = num_pages
+        self._free = list(range(num_pages - 1, -1, -1))
+
+    @property
+    def num_free(self) -> int:
+        return len(self._free)
+
+    def alloc(self) -> int:
+        if not self._free:
+            raise OutOfPages("KV cache is out of pages")
+        return self._free.pop()
+
+    def free(self, pages: List[int]) -> None:
+        self._free.extend(pages)
+
+
+class PagedKVCache:
+    """K and V pages of every layer of one model, plus the block tables of the
+    running batch as a device tensor."""
+
+    def __init__(self, cfg: ModelConfig, num_pages: int, max_batch: int, max_seq_len: int,
+                 device="cuda"):
+        self.cfg = cfg
+        self.num_pages = num_pages
+        self.max_blocks_per_seq = (max_seq_len + PAGE - 1) // PAGE
+        page_elems = cfg.head_dim * PAGE
+        shape = (cfg.n_layers, num_pages, cfg.n_kv_heads, page_elems)
+        self.k = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+        self.v = torch.zeros(shape, dtype=torch.bfloat16, device=device)
+        self.layer_stride_bytes = num_pages * cfg.n_kv_heads * page_elems * 2
+        self.allocator = PageAllocator(num_pages)
+        self.block_tables = torch.zeros(max_batch, self.max_blocks_per_seq, dtype=torch.int32,
+                                        device=device)
+        self._host_tables: List[List[int]] = [[] for _ in range(max_batch)]
+
+    def pages_of(self, slot: int) -> List[int]:
+        return self._host_tables[slot]
+
+    def ensure_capacity(self, slot: int, n_tokens: int) -> None:
+        """Makes sure batch slot `slot` owns pages for positions 0..n_tokens-1."""
+        need = (n_tokens + PAGE - 1) // PAGE
+        if need > self.max_blocks_per_seq:
+            raise OutOfPages(f"sequence of {n_tokens} tokens exceeds max_seq_len")
+        tbl = self._host_tables[slot]
+        if len(tbl) >= need:
+            return
+        first_new = len(tbl)
+        while len(tbl) < need:
+            tbl.append(self.allocator.alloc())
+        new = torch.tensor(tbl[first_new:], dtype=torch.int32)
+        self.block_tables[slot, first_new:need].copy_(new, non_blocking=True)
+
+    def release(self, slot: int) -> None:
+        self.allocator.free(self._host_tables[slot])
+        self._host_tables[slot] = []
+
+    @staticmethod
+    def pages_for(cfg: ModelConfig, max_batch: int, max_seq_len: int) -> int:
+        return max_batch * ((max_seq_len + PAGE - 1) // PAGE)
+
+    def nbytes(self) -> int:
+        return 2 * self.k.numel() * 2

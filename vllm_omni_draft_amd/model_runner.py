@@ -1,0 +1,86 @@
+"""DecoderModel: the host handle of one model (target or draft) on one GPU.
+
+It owns the native model descriptor (sd_model_create) and a workspace, and
+enqueues whole forward passes with one C call; nothing here computes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .config import ModelConfig
+from .kv_cache import PagedKVCache
+from .weights import ModelWeights
+
+MAX_ROWS = 8  # token rows one forward pass may carry (B * q_len)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class DecoderModel:
+    def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256):
+        self.weights = weights  # keeps the device tensors alive
+        self.cfg: ModelConfig = weights.cfg
+        cfg = self.cfg
+        if max_ctx > cfg.max_pos:
+            raise ValueError(f"max_ctx {max_ctx} exceeds the model's max_pos {cfg.max_pos}")
+        self.max_ctx = max_ctx
+        self.split_tokens = split_tokens
+        lib = _lib.load()
+        layers = (_lib.LayerWeights * cfg.n_layers)()
+        for i, l in enumerate(weights.layers):
+            for name, _ in _lib.LayerWeights._fields_:
+                setattr(layers[i], name, _ptr(getattr(l, name)))
+        desc = _lib.ModelDesc(
+            arch=0 if cfg.arch == "llama" else 1, n_layers=cfg.n_layers, hidden=cfg.hidden,
+            n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads, head_dim=cfg.head_dim, ffn=cfg.ffn,
+            vocab=cfg.vocab, max_pos=cfg.max_pos, pos_bias=cfg.pos_bias if cfg.arch == "opt" else 0,
+            norm_eps=cfg.norm_eps, attn_scale=cfg.head_dim ** -0.5,
+            embed=_ptr(weights.embed), pos_table=_ptr(weights.pos_table),
+            rope_cs=_ptr(weights.rope_cs), final_norm_w=_ptr(weights.final_norm_w),
+            final_norm_b=_ptr(weights.final_norm_b), lm_head=_ptr(weights.lm_head), layers=layers)
+        self._handle = lib.sd_model_create(C.byref(desc))
+        if not self._handle:
+            raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")
+        nbytes = lib.sd_model_workspace_bytes(self._handle, MAX_ROWS, max_ctx, split_tokens)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=weights.embed.device)
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h:
+            try:
+                _lib.load().sd_model_destroy(h)
+            except Exception:
+                pass
+            self._handle = None
+
+    def forward(self, kv: PagedKVCache, token_ids: torch.Tensor, tok_stride: int, tok_offset: int,
+                seq_lens: torch.Tensor, pos_offset: int, B: int, q_len: int,
+                logits: Optional[torch.Tensor], max_ctx: Optional[int] = None) -> None:
+        """Enqueues one pass over B*q_len token rows on the current stream.
+        Token t of sequence b is token_ids[b*tok_stride + tok_offset + t] at
+        position seq_lens[b] + pos_offset + t.  `logits` ([B*q_len, vocab] f32)
+        may be None to skip the LM head."""
+        if token_ids.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+            raise _lib.SdError("token_ids and seq_lens must be int32 device tensors")
+        if logits is not None and (logits.dtype != torch.float32 or not logits.is_contiguous()
+                                   or logits.numel() < B * q_len * self.cfg.vocab):
+            raise _lib.SdError("logits must be a contiguous float32 [B*q_len, vocab] tensor")
+        kvd = _lib.KvCacheDesc(k_cache=kv.k.data_ptr(), v_cache=kv.v.data_ptr(),
+                               layer_stride_bytes=kv.layer_stride_bytes,
+                               block_tables=kv.block_tables.data_ptr(),
+                               max_blocks_per_seq=kv.max_blocks_per_seq)
+        args = _lib.ForwardArgs(B=B, q_len=q_len, token_ids=token_ids.data_ptr(),
+                                tok_stride=tok_stride, tok_offset=tok_offset,
+                                seq_lens=seq_lens.data_ptr(), pos_offset=pos_offset,
+                                max_ctx=max_ctx or self.max_ctx, split_tokens=self.split_tokens,
+                                logits=_ptr(logits))
+        rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
+                                          self.workspace.data_ptr(), self.workspace.numel(),
+                                          torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "sd_model_forward")

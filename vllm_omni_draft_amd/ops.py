@@ -1,0 +1,230 @@
+"""Tensor-level wrappers over the C ABI: unwrap `data_ptr()`, pass the current
+HIP stream, raise on any non-zero status.  No computation happens in Python
+and nothing here falls back to PyTorch ops."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_STORE, EPI_RESIDUAL, EPI_SILU_MUL, EPI_RELU, EPI_F32, EPI_GELU_TANH = range(6)
+PAGE = 16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise _lib.SdError(f"{name}: tensor must live on the GPU (got {t.device}); "
+                           "there is no CPU path")
+    if t.dtype != dtype:
+        raise _lib.SdError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.SdError(f"{name}: tensor must be contiguous")
+
+
+def device_info():
+    import ctypes as C
+    cu = C.c_int(0)
+    buf = C.create_string_buffer(128)
+    _lib.check(_lib.load().sd_device_info(C.byref(cu), buf, 128), "sd_device_info")
+    return cu.value, buf.value.decode()
+
+
+# ---------------------------------------------------------------- acceptance
+def rejection_sample(target_probs, bonus_ids, draft_probs, draft_ids, u_accept, u_recover,
+                     proposal_lens=None, counters=None) -> torch.Tensor:
+    B, k1, V = target_probs.shape
+    k = k1 - 1
+    _need(target_probs, torch.float32, "target_probs")
+    _need(draft_probs, torch.float32, "draft_probs")
+    _need(draft_ids, torch.int64, "draft_ids")
+    _need(u_accept, torch.float32, "u_accept")
+    _need(u_recover, torch.float32, "u_recover")
+    bonus = bonus_ids.reshape(-1)
+    _need(bonus, torch.int64, "bonus_ids")
+    if tuple(draft_probs.shape) != (B, k, V) or tuple(draft_ids.shape) != (B, k) or \
+            tuple(u_accept.shape) != (B, k) or tuple(u_recover.shape) != (B, k + 1) or \
+            bonus.numel() != B:
+        raise _lib.SdError("rejection_sample: inconsistent shapes")
+    if proposal_lens is not None:
+        _need(proposal_lens, torch.int32, "proposal_lens")
+    if counters is not None:
+        _need(counters, torch.int64, "counters")
+    out = torch.empty(B, k + 1, dtype=torch.int64, device=target_probs.device)
+    _lib.check(_lib.load().sd_rejection_sample(
+        _p(target_probs), _p(bonus), _p(draft_probs), _p(draft_ids), _p(u_accept), _p(u_recover),
+        _p(proposal_lens), _p(out), _p(counters), B, k, V, _stream()), "sd_rejection_sample")
+    return out
+
+
+def greedy_verify(target_ids, draft_ids, proposal_lens=None, counters=None, out=None):
+    B, k1 = target_ids.shape
+    k = k1 - 1
+    _need(target_ids, torch.int64, "target_ids")
+    _need(draft_ids, torch.int64, "draft_ids")
+    if tuple(draft_ids.shape) != (B, k):
+        raise _lib.SdError("greedy_verify: inconsistent shapes")
+    if proposal_lens is not None:
+        _need(proposal_lens, torch.int32, "proposal_lens")
+    if out is None:
+        out = torch.empty(B, k + 1, dtype=torch.int64, device=target_ids.device)
+    _lib.check(_lib.load().sd_greedy_verify(_p(target_ids), _p(draft_ids), _p(proposal_lens),
+                                            _p(out), _p(counters), B, k, _stream()),
+               "sd_greedy_verify")
+    return out
+
+
+def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None, *, row_offset: int = 0,
+                row_step: int = 1) -> torch.Tensor:
+    """argmax over the last dim of rows row_offset, row_offset+row_step, ..."""
+    _need(logits, torch.float32, "logits")
+    R_all, V = logits.shape
+    R = (R_all - row_offset + row_step - 1) // row_step
+    if out is None:
+        out = torch.empty(R, dtype=torch.int64, device=logits.device)
+    _lib.check(_lib.load().sd_argmax_rows(logits.data_ptr() + row_offset * V * 4, V * row_step,
+                                          _p(out), R, V, _stream()), "sd_argmax_rows")
+    return out
+
+
+def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out=None, *, row_offset=0,
+                 row_step=1, out_ptr=None, out_ld=None) -> torch.Tensor:
+    """softmax(logits / T) of rows row_offset, row_offset+row_step, ...; the
+    result goes to `out` ([R, V]) or to raw address out_ptr with row stride out_ld."""
+    _need(logits, torch.float32, "logits")
+    R_all, V = logits.shape
+    R = (R_all - row_offset + row_step - 1) // row_step
+    if out is None and out_ptr is None:
+        out = torch.empty(R, V, dtype=torch.float32, device=logits.device)
+    dst = out_ptr if out_ptr is not None else out.data_ptr()
+    _lib.check(_lib.load().sd_softmax_rows(logits.data_ptr() + row_offset * V * 4, V * row_step,
+                                           float(temperature), dst, out_ld or V, R, V, _stream()),
+               "sd_softmax_rows")
+    return out
+
+
+def sample_rows(probs: torch.Tensor, uniforms: torch.Tensor, out=None, *, row_offset=0,
+                row_step=1) -> torch.Tensor:
+    """Inverse-CDF draw from rows row_offset, row_offset+row_step, ... of probs [*, V]."""
+    _need(probs, torch.float32, "probs")
+    _need(uniforms, torch.float32, "uniforms")
+    R_all, V = probs.shape
+    R = (R_all - row_offset + row_step - 1) // row_step
+    if uniforms.numel() < R:
+        raise _lib.SdError("sample_rows: need one uniform per row")
+    if out is None:
+        out = torch.empty(R, dtype=torch.int64, device=probs.device)
+    _lib.check(_lib.load().sd_sample_rows(probs.data_ptr() + row_offset * V * 4, V * row_step,
+                                          _p(uniforms), _p(out), R, V, _stream()),
+               "sd_sample_rows")
+    return out
+
+
+# ---------------------------------------------------------------- attention
+def rope_append(qkv, rope_cs, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_len,
+                Hq, Hkv, D) -> None:
+    _need(qkv, torch.bfloat16, "qkv")
+    _need(k_cache, torch.bfloat16, "k_cache")
+    _need(v_cache, torch.bfloat16, "v_cache")
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    max_pos = 0
+    if rope_cs is not None:
+        _need(rope_cs, torch.float32, "rope_cs")
+        max_pos = rope_cs.shape[0]
+    _lib.check(_lib.load().sd_rope_append(
+        _p(qkv), _p(rope_cs), max_pos, _p(k_cache), _p(v_cache), _p(block_tables),
+        block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, _stream()),
+        "sd_rope_append")
+
+
+def paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx, split_tokens) -> int:
+    return int(_lib.load().sd_paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx,
+                                                              split_tokens))
+
+
+def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D,
+                    scale, max_ctx, split_tokens=256, ldq=None, workspace=None) -> torch.Tensor:
+    """q: [B*q_len, >= Hq*D] bf16 rows (row stride ldq elements)."""
+    _need(q, torch.bfloat16, "q")
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    if ldq is None:
+        ldq = q.shape[-1] if q.dim() == 2 else Hq * D
+    out = torch.empty(B * q_len, Hq * D, dtype=torch.bfloat16, device=q.device)
+    need = paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx, split_tokens)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    _lib.check(_lib.load().sd_paged_attention(
+        _p(q), ldq, _p(k_cache), _p(v_cache), _p(block_tables), block_tables.shape[1],
+        _p(seq_lens), pos_offset, _p(out), Hq * D, B, q_len, Hq, Hkv, D, float(scale), max_ctx,
+        split_tokens, _p(workspace), workspace.numel(), _stream()), "sd_paged_attention")
+    return out
+
+
+# ---------------------------------------------------------------- dense ops
+def linear(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None) -> torch.Tensor:
+    _need(W, torch.bfloat16, "W")
+    _need(x, torch.bfloat16, "x")
+    M, K = x.shape
+    n_rows = W.shape[0]
+    N = n_rows // 2 if epilogue == EPI_SILU_MUL else n_rows
+    if W.shape[1] != K:
+        raise _lib.SdError(f"linear: W is {tuple(W.shape)}, x is {tuple(x.shape)}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16,
+                          device=x.device)
+    _lib.check(_lib.load().sd_linear(_p(W), _p(x), K, _p(bias), _p(residual), _p(out), N, M, N, K,
+                                     epilogue, _stream()), "sd_linear")
+    return out
+
+
+def rmsnorm(x, w, eps) -> torch.Tensor:
+    _need(x, torch.bfloat16, "x")
+    _need(w, torch.bfloat16, "w")
+    rows, H = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().sd_rmsnorm(_p(x), H, _p(w), _p(out), H, rows, H, float(eps), _stream()),
+               "sd_rmsnorm")
+    return out
+
+
+def layernorm(x, w, b, eps) -> torch.Tensor:
+    _need(x, torch.bfloat16, "x")
+    rows, H = x.shape
+    out = torch.empty_like(x)
+    _lib.check(_lib.load().sd_layernorm(_p(x), H, _p(w), _p(b), _p(out), H, rows, H, float(eps),
+                                        _stream()), "sd_layernorm")
+    return out
+
+
+# ---------------------------------------------------------------- step glue
+def store_proposal(ids, tok_buf, k, step, seq_lens, truth=None, accept_prob=0.0, seed=0) -> None:
+    B = tok_buf.shape[0]
+    _lib.check(_lib.load().sd_store_proposal(
+        _p(ids), _p(tok_buf), k, step, _p(seq_lens), _p(truth),
+        0 if truth is None else truth.shape[1], float(accept_prob), int(seed) & 0xFFFFFFFF, B,
+        _stream()), "sd_store_proposal")
+
+
+def gather_proposals(tok_buf, draft_ids, k) -> None:
+    _lib.check(_lib.load().sd_gather_proposals(_p(tok_buf), _p(draft_ids), tok_buf.shape[0], k,
+                                               _stream()), "sd_gather_proposals")
+
+
+def advance_state(out_ids, seq_lens, tok_buf, gen_tokens, gen_counts, k) -> None:
+    B = seq_lens.shape[0]
+    _lib.check(_lib.load().sd_advance_state(
+        _p(out_ids), _p(seq_lens), _p(tok_buf), _p(gen_tokens),
+        0 if gen_tokens is None else gen_tokens.shape[1],
+        0 if gen_tokens is None else gen_tokens.shape[1], _p(gen_counts), B, k, _stream()),
+        "sd_advance_state")

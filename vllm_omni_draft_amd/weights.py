@@ -1,0 +1,172 @@
+"""Device-resident model weights in the layout the kernels stream: bf16,
+row-major [out, in], q/k/v fused into one matrix and gate/up fused into one.
+
+Sources: a Hugging Face style state dict (names as in transformers), a local
+directory of *.safetensors shards, or seeded random initialisation.  The
+reference only ever loads by hub name
+(/root/reference/src/qwen_image_gen/model.py:46-65), which needs a network.
+"""
+from __future__ import annotations
+
+import glob
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from .config import ModelConfig, rope_table
+
+
+@dataclass
+class LayerTensors:
+    attn_norm_w: torch.Tensor
+    qkv_w: torch.Tensor
+    o_w: torch.Tensor
+    mlp_norm_w: torch.Tensor
+    up_w: torch.Tensor
+    down_w: torch.Tensor
+    attn_norm_b: Optional[torch.Tensor] = None
+    qkv_b: Optional[torch.Tensor] = None
+    o_b: Optional[torch.Tensor] = None
+    mlp_norm_b: Optional[torch.Tensor] = None
+    up_b: Optional[torch.Tensor] = None
+    down_b: Optional[torch.Tensor] = None
+
+
+@dataclass
+class ModelWeights:
+    cfg: ModelConfig
+    embed: torch.Tensor
+    final_norm_w: torch.Tensor
+    lm_head: torch.Tensor
+    layers: List[LayerTensors]
+    pos_table: Optional[torch.Tensor] = None
+    final_norm_b: Optional[torch.Tensor] = None
+    rope_cs: Optional[torch.Tensor] = None
+
+    def nbytes(self) -> int:
+        seen, total = set(), 0
+        for t in self.tensors():
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                total += t.numel() * t.element_size()
+        return total
+
+    def tensors(self):
+        for t in (self.embed, self.final_norm_w, self.lm_head, self.pos_table, self.final_norm_b):
+            if t is not None:
+                yield t
+        for l in self.layers:
+            for t in vars(l).values():
+                if t is not None:
+                    yield t
+
+
+def _dev(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cuda") -> ModelWeights:
+    cfg.validate()
+    g = lambda n: state[n]
+    opt = lambda n: state.get(n)
+    layers = []
+    if cfg.arch == "llama":
+        pre = "model."
+        for i in range(cfg.n_layers):
+            lp = f"{pre}layers.{i}."
+            qkv_w = torch.cat([g(lp + "self_attn.q_proj.weight"), g(lp + "self_attn.k_proj.weight"),
+                               g(lp + "self_attn.v_proj.weight")], dim=0)
+            qb = opt(lp + "self_attn.q_proj.bias")
+            qkv_b = None if qb is None else torch.cat(
+                [qb, g(lp + "self_attn.k_proj.bias"), g(lp + "self_attn.v_proj.bias")], dim=0)
+            up_w = torch.cat([g(lp + "mlp.gate_proj.weight"), g(lp + "mlp.up_proj.weight")], dim=0)
+            layers.append(LayerTensors(
+                attn_norm_w=_dev(g(lp + "input_layernorm.weight"), device),
+                qkv_w=_dev(qkv_w, device), qkv_b=None if qkv_b is None else _dev(qkv_b, device),
+                o_w=_dev(g(lp + "self_attn.o_proj.weight"), device),
+                mlp_norm_w=_dev(g(lp + "post_attention_layernorm.weight"), device),
+                up_w=_dev(up_w, device), down_w=_dev(g(lp + "mlp.down_proj.weight"), device)))
+        embed = _dev(g(pre + "embed_tokens.weight"), device)
+        head = opt("lm_head.weight")
+        return ModelWeights(cfg=cfg, embed=embed, final_norm_w=_dev(g(pre + "norm.weight"), device),
+                            lm_head=embed if head is None else _dev(head, device), layers=layers,
+                            rope_cs=rope_table(cfg, device))
+    pre = "model.decoder."
+    for i in range(cfg.n_layers):
+        lp = f"{pre}layers.{i}."
+        qkv_w = torch.cat([g(lp + f"self_attn.{n}_proj.weight") for n in "qkv"], dim=0)
+        qkv_b = torch.cat([g(lp + f"self_attn.{n}_proj.bias") for n in "qkv"], dim=0)
+        layers.append(LayerTensors(
+            attn_norm_w=_dev(g(lp + "self_attn_layer_norm.weight"), device),
+            attn_norm_b=_dev(g(lp + "self_attn_layer_norm.bias"), device),
+            qkv_w=_dev(qkv_w, device), qkv_b=_dev(qkv_b, device),
+            o_w=_dev(g(lp + "self_attn.out_proj.weight"), device),
+            o_b=_dev(g(lp + "self_attn.out_proj.bias"), device),
+            mlp_norm_w=_dev(g(lp + "final_layer_norm.weight"), device),
+            mlp_norm_b=_dev(g(lp + "final_layer_norm.bias"), device),
+            up_w=_dev(g(lp + "fc1.weight"), device), up_b=_dev(g(lp + "fc1.bias"), device),
+            down_w=_dev(g(lp + "fc2.weight"), device), down_b=_dev(g(lp + "fc2.bias"), device)))
+    embed = _dev(g(pre + "embed_tokens.weight"), device)
+    head = opt("lm_head.weight")
+    return ModelWeights(cfg=cfg, embed=embed, pos_table=_dev(g(pre + "embed_positions.weight"), device),
+                        final_norm_w=_dev(g(pre + "final_layer_norm.weight"), device),
+                        final_norm_b=_dev(g(pre + "final_layer_norm.bias"), device),
+                        lm_head=embed if head is None else _dev(head, device), layers=layers)
+
+
+def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02) -> ModelWeights:
+    """Seeded random weights generated directly on the device in the fused
+    layout (no host copy: an 8B model is 16 GB)."""
+    cfg.validate()
+    gen = torch.Generator(device=device).manual_seed(seed)
+
+    def rn(*shape, s=std):
+        return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s
+                ).to(torch.bfloat16)
+
+    def ones(n):
+        return (1.0 + torch.randn(n, generator=gen, device=device) * 0.05).to(torch.bfloat16)
+
+    H, F = cfg.hidden, cfg.ffn
+    layers = []
+    for _ in range(cfg.n_layers):
+        if cfg.arch == "llama":
+            layers.append(LayerTensors(
+                attn_norm_w=ones(H), qkv_w=rn(cfg.qkv_rows, H),
+                qkv_b=rn(cfg.qkv_rows) if cfg.qkv_bias else None,
+                o_w=rn(H, cfg.n_heads * cfg.head_dim), mlp_norm_w=ones(H), up_w=rn(2 * F, H),
+                down_w=rn(H, F)))
+        else:
+            layers.append(LayerTensors(
+                attn_norm_w=ones(H), attn_norm_b=rn(H), qkv_w=rn(cfg.qkv_rows, H),
+                qkv_b=rn(cfg.qkv_rows), o_w=rn(H, cfg.n_heads * cfg.head_dim), o_b=rn(H),
+                mlp_norm_w=ones(H), mlp_norm_b=rn(H), up_w=rn(F, H), up_b=rn(F),
+                down_w=rn(H, F), down_b=rn(H)))
+    embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5)
+    lm_head = embed if cfg.tie_embeddings else rn(cfg.vocab, H)
+    w = ModelWeights(cfg=cfg, embed=embed, final_norm_w=ones(H), lm_head=lm_head, layers=layers)
+    if cfg.arch == "llama":
+        w.rope_cs = rope_table(cfg, device)
+    else:
+        w.pos_table = rn(cfg.max_pos + cfg.pos_bias, H, s=0.5)
+        w.final_norm_b = rn(H)
+    return w
+
+
+def from_safetensors_dir(cfg: ModelConfig, model_dir: str, device="cuda") -> ModelWeights:
+    """Loads every *.safetensors shard of a local Hugging Face checkpoint."""
+    from safetensors import safe_open
+
+    files = sorted(glob.glob(os.path.join(model_dir, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {model_dir}")
+    state: Dict[str, torch.Tensor] = {}
+    for fn in files:
+        with safe_open(fn, framework="pt", device="cpu") as f:
+            for key in f.keys():
+                state[key] = f.get_tensor(key)
+    if cfg.arch == "opt" and "decoder.embed_tokens.weight" in state:
+        state = {"model." + k if k.startswith("decoder.") else k: v for k, v in state.items()}
+    return from_state_dict(cfg, state, device)
