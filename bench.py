@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Headline benchmark: output tokens/s and accept-len of speculative decoding,
+Llama-3-8B target + Llama-3.2-1B draft, k = 5, one sequence per GPU.
+
+    python bench.py --gpus 1 --steps 64 --warmup 8
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one speculative step of the hot path (k draft passes, one
+(k+1)-token target verify pass over the paged KV cache, acceptance, state
+update), replayed as one hipGraph; the host reads the emitted tokens back after
+every step, as a serving loop must.  Data is synthetic: seeded random-init
+weights of the named architectures and a random-token prompt.  Random weights
+give a random draft no chance of agreeing with the target, so acceptance is a
+controlled parameter: the greedy autoregressive stream of the target is
+recorded first, and each draft proposal (computed in full by the draft model)
+is replaced by the true next token with probability --accept-prob.  The run
+then also proves, at full size, that the speculative stream equals the
+autoregressive stream token for token.
+
+With N > 1 every rank runs an independent replica (its own sequence); no
+collective is on the data path; throughput is summed (weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--prompt-len", type=int, default=1024)
+    ap.add_argument("--accept-prob", type=float, default=0.8)
+    ap.add_argument("--target", default="llama-3-8b")
+    ap.add_argument("--draft", default="llama-3.2-1b")
+    ap.add_argument("--split-tokens", type=int, default=256)
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--layers", type=int, default=0, help="debug only: truncate both models")
+    return ap.parse_args()
+
+
+def load_weights(name, seed, device, layers=0):
+    from vllm_omni_draft_amd import config, weights
+    root = os.environ.get("SD_MODEL_ROOT", "")
+    path = os.path.join(root, name) if root else ""
+    if path and os.path.isdir(path):
+        cfg = config.load_hf_config(path)
+        return weights.from_safetensors_dir(cfg, path, device), "local safetensors"
+    cfg = config.preset(name, **({"n_layers": layers} if layers else {}))
+    return weights.random_init(cfg, seed=seed, device=device), "seeded random init"
+
+
+def run_generation(eng, prompt, n_steps, warmup, dist_barrier):
+    """Prefill, `warmup` untimed steps, then exactly n_steps timed steps with a
+    read-back after each.  Returns (tokens, timed_tokens, seconds, prefill_s)."""
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = [eng.add_request(0, prompt)]
+    torch.cuda.synchronize()
+    prefill_s = time.perf_counter() - t0
+    for _ in range(warmup):
+        out.extend(eng.step()[0])
+    dist_barrier()
+    torch.cuda.synchronize()
+    n0 = len(out)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        out.extend(eng.step()[0])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dist_barrier()
+    return out, len(out) - n0, dt, prefill_s
+
+
+def step_bytes(tcfg, dcfg, k, ctx):
+    """Algorithmic HBM bytes of one speculative step at context length ctx."""
+    V = tcfg.vocab
+    kv_t = tcfg.kv_bytes_per_token() * ctx
+    kv_d = dcfg.kv_bytes_per_token() * ctx * k
+    logits = (k + 1) * V * 4 * 2 + k * V * 4 * 2  # written once, read once by argmax
+    return tcfg.param_bytes() + k * dcfg.param_bytes() + kv_t + kv_d + logits
+
+
+def kernel_roofline(eng, tw, rows, reps=3):
+    """Times the dominant kernel of the step — the gate/up weight-streaming
+    linear of the target verify pass (M = k+1 rows) — with events on the
+    engine's stream, cycling through every layer's matrix so that no launch
+    finds its weights in the 256 MiB Infinity Cache."""
+    from vllm_omni_draft_amd import ops
+    cfg = tw.cfg
+    x = torch.randn(rows, cfg.hidden, device=eng.device).to(torch.bfloat16)
+    out = torch.empty(rows, cfg.ffn, dtype=torch.bfloat16, device=eng.device)
+    epi = ops.EPI_SILU_MUL if cfg.arch == "llama" else ops.EPI_RELU
+    with torch.cuda.stream(eng.stream):
+        for l in tw.layers:  # warm-up pass
+            ops.linear(l.up_w, x, None, None, epi, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for l in tw.layers:
+                ops.linear(l.up_w, x, None, None, epi, out=out)
+        e1.record()
+        e1.synchronize()
+    n = reps * len(tw.layers)
+    us = e0.elapsed_time(e1) * 1e3 / n
+    w = tw.layers[0].up_w
+    bytes_per_launch = w.numel() * 2 + x.numel() * 2 + out.numel() * 2
+    gbs = bytes_per_launch / us * 1e-3
+    return {"kernel": f"linear_kernel<M={rows},gate_up+silu_mul> [{w.shape[0]}x{w.shape[1]}] bf16",
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
+
+
+def attention_roofline(device, k):
+    """The verify attention kernel alone at a KV-bound size: 32 sequences x 4096
+    cached tokens, Llama-3-8B head shape, k+1 query tokens each."""
+    from vllm_omni_draft_amd import ops
+    B, ctx, Hq, Hkv, D, q_len = 32, 4096, 32, 8, 128, k + 1
+    pages_per_seq = (ctx + q_len + 15) // 16
+    n_pages = B * pages_per_seq
+    kc = (torch.randn(n_pages, Hkv, D * 16, device=device) * 0.5).to(torch.bfloat16)
+    vc = (torch.randn(n_pages, Hkv, D * 16, device=device) * 0.5).to(torch.bfloat16)
+    bt = torch.randperm(n_pages, device=device).to(torch.int32).view(B, pages_per_seq).contiguous()
+    q = torch.randn(B * q_len, Hq * D, device=device).to(torch.bfloat16)
+    sl = torch.full((B,), ctx, dtype=torch.int32, device=device)
+    ws = torch.empty(ops.paged_attention_workspace_bytes(B, q_len, Hq, D, ctx + q_len, 512),
+                     dtype=torch.uint8, device=device)
+    run = lambda: ops.paged_attention(q, kc, vc, bt, sl, 0, B, q_len, Hq, Hkv, D, D ** -0.5,
+                                      ctx + q_len, 512, workspace=ws)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()
+    for _ in range(reps):
+        run()
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    kv_bytes = B * (ctx + q_len) * Hkv * D * 2 * 2
+    gbs = kv_bytes / us * 1e-3
+    return {"kernel": "paged_attn_kernel<D=128> + merge, B=32 ctx=4096 q_len=%d" % q_len,
+            "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": kv_bytes,
+            "avg_us": round(us, 2)}
+
+
+def cpu_baseline(args, tokens_per_step, budget_s=30.0):
+    """The CPU oracle (oracle/, torch CPU kernels) on the same model shapes:
+    k draft passes + one (k+1)-row verify pass per step, bf16 weights, random
+    KV of the prompt length.  Bounded: at most 2 steps or ~budget_s."""
+    from oracle.models import KVCache, OracleConfig, OracleLM
+    from vllm_omni_draft_amd import config as pc
+    torch.manual_seed(0)
+    pool = (torch.randn(1 << 24) * 0.02).to(torch.bfloat16)
+
+    def cheap(shape):
+        n = 1
+        for s in shape:
+            n *= s
+        reps = (n + pool.numel() - 1) // pool.numel()
+        return pool.repeat(reps)[:n].view(*shape)
+
+    def build(name):
+        c = pc.preset(name, **({"n_layers": args.layers} if args.layers else {}))
+        oc = OracleConfig(arch=c.arch, n_layers=c.n_layers, hidden=c.hidden, n_heads=c.n_heads,
+                          n_kv_heads=c.n_kv_heads, head_dim=c.head_dim, ffn=c.ffn, vocab=c.vocab,
+                          norm_eps=c.norm_eps, rope_theta=c.rope_theta, rope_scaling=c.rope_scaling,
+                          max_pos=args.prompt_len + 64, tie_embeddings=c.tie_embeddings)
+        H, D, Hq, Hkv, F = oc.hidden, oc.head_dim, oc.n_heads, oc.n_kv_heads, oc.ffn
+        st = {"model.embed_tokens.weight": cheap((oc.vocab, H)), "model.norm.weight": cheap((H,))}
+        if not oc.tie_embeddings:
+            st["lm_head.weight"] = cheap((oc.vocab, H))
+        for i in range(oc.n_layers):
+            lp = f"model.layers.{i}."
+            st[lp + "input_layernorm.weight"] = cheap((H,))
+            st[lp + "post_attention_layernorm.weight"] = cheap((H,))
+            st[lp + "self_attn.q_proj.weight"] = cheap((Hq * D, H))
+            st[lp + "self_attn.k_proj.weight"] = cheap((Hkv * D, H))
+            st[lp + "self_attn.v_proj.weight"] = cheap((Hkv * D, H))
+            st[lp + "self_attn.o_proj.weight"] = cheap((H, Hq * D))
+            st[lp + "mlp.gate_proj.weight"] = cheap((F, H))
+            st[lp + "mlp.up_proj.weight"] = cheap((F, H))
+            st[lp + "mlp.down_proj.weight"] = cheap((H, F))
+        lm = OracleLM(oc, st, bf16_acts=False, compute_dtype=torch.bfloat16)
+        cache = KVCache(oc.n_layers)
+        for i in range(oc.n_layers):
+            cache.k[i] = torch.randn(args.prompt_len, Hkv, D) * 0.5
+            cache.v[i] = torch.randn(args.prompt_len, Hkv, D) * 0.5
+        return lm, cache
+
+    k, n = args.k, args.prompt_len
+    target, t_cache = build(args.target)
+    draft, d_cache = build(args.draft)
+    steps, t_total = 0, 0.0
+    with torch.no_grad():
+        while steps < 2 and t_total < budget_s:
+            t0 = time.perf_counter()
+            toks = [1, 2]
+            pos = n - 1
+            for i in range(k):
+                lg = draft.forward(toks, pos, d_cache)[-1]
+                pos += len(toks)
+                toks = [int(torch.argmax(lg))]
+            lg = target.forward([1] + [2] * k, n, t_cache)
+            _ = torch.argmax(lg, dim=-1)
+            t_cache.truncate(n)
+            d_cache.truncate(n - 1)
+            t_total += time.perf_counter() - t0
+            steps += 1
+    step_s = t_total / steps
+    return {"value": round(tokens_per_step / step_s, 3), "unit": "tokens/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} speculative step(s) of the same shapes ({args.target} + {args.draft}, "
+                      f"k={k}, batch 1, ctx {n}, bf16 weights) on the torch-CPU oracle, "
+                      f"{step_s:.2f} s/step; tokens/step ({tokens_per_step:.2f}) taken from the GPU run"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+
+    k = args.k
+    tw, data_kind = load_weights(args.target, 1, device, args.layers)
+    dw, _ = load_weights(args.draft, 2, device, args.layers)
+    g = torch.Generator().manual_seed(1234 + rank)
+    prompt = torch.randint(0, min(tw.cfg.vocab, dw.cfg.vocab), (args.prompt_len,), generator=g).tolist()
+    total_steps = args.warmup + args.steps
+    n_truth = total_steps * (k + 1) + 8
+    max_seq = args.prompt_len + n_truth + 16
+
+    # 1) autoregressive baseline (k = 0) on the same kernels: the truth stream
+    ar = SpecEngine(tw, None, EngineConfig(k=0, max_seq_len=max_seq, split_tokens=args.split_tokens,
+                                           use_graph=not args.no_graph, gen_capacity=n_truth + 64))
+    ar_tokens, ar_n, ar_dt, ar_prefill = run_generation(ar, prompt, n_truth - 4 - args.warmup,
+                                                        args.warmup, barrier)
+    ar_tps = ar_n / ar_dt
+    truth = torch.zeros(1, max_seq, dtype=torch.int32)
+    truth[0, :len(prompt)] = torch.tensor(prompt)
+    truth[0, len(prompt):len(prompt) + len(ar_tokens)] = torch.tensor(ar_tokens)
+    truth_dev = truth.to(device)
+    del ar
+    torch.cuda.empty_cache()
+
+    # 2) speculative run
+    def spec_run(alpha, steps, warmup):
+        eng = SpecEngine(tw, dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
+                                              use_graph=not args.no_graph, gen_capacity=n_truth + 64))
+        eng.set_synthetic_acceptance(truth_dev, alpha, seed=99 + rank)
+        toks, n_timed, dt, prefill = run_generation(eng, prompt, steps, warmup, barrier)
+        n_cmp = min(len(toks), len(ar_tokens))
+        exact = toks[:n_cmp] == ar_tokens[:n_cmp]
+        m = eng.metrics()
+        res = {"tokens": n_timed, "seconds": dt, "prefill_s": prefill, "exact": exact,
+               "accept_len": m["accepted"] / max(m["draft"] // k, 1),
+               "emitted_per_step": m["emitted"] / max(m["draft"] // k, 1),
+               "draft_acceptance_rate": m["accepted"] / max(m["draft"], 1),
+               "system_efficiency": m["emitted"] / max((m["draft"] // k) * (k + 1), 1)}
+        return eng, res
+
+    eng, main_res = spec_run(args.accept_prob, args.steps, args.warmup)
+    tokens, dt = main_res["tokens"], main_res["seconds"]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n = torch.tensor([tokens, int(main_res["exact"])], dtype=torch.float64, device=device)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        dt, tokens = float(t.item()), float(n[0].item())
+        all_exact = int(n[1].item()) == world
+    else:
+        all_exact = main_res["exact"]
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = tokens / dt
+    ms_per_step = dt / args.steps * 1e3
+    ctx_mid = args.prompt_len + (args.warmup + args.steps / 2) * main_res["emitted_per_step"]
+    sb = step_bytes(tw.cfg, dw.cfg, k, ctx_mid)
+    roof = kernel_roofline(eng, tw, k + 1)
+    attn = attention_roofline(device, k)
+    sweep = []
+    if not args.no_sweep and world == 1:
+        del eng
+        torch.cuda.empty_cache()
+        for a in (0.0, 0.6, 0.7, 0.9, 1.0):
+            e2, r = spec_run(a, max(16, args.steps // 2), 4)
+            sweep.append({"accept_prob": a, "tokens_per_s": round(r["tokens"] / r["seconds"], 1),
+                          "accept_len": round(r["accept_len"], 3), "speedup_vs_ar": round(
+                              r["tokens"] / r["seconds"] / ar_tps, 3), "exact": r["exact"]})
+            del e2
+            torch.cuda.empty_cache()
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args, main_res["emitted_per_step"])
+        except Exception as e:  # the baseline is a report item, never the product path
+            cpu = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(),
+                   "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
+
+    line = {
+        "metric": "output tokens/sec (+ accept-len), Llama-3-8B + Llama-3.2-1B draft, k=5, greedy",
+        "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": f"synthetic ({data_kind}; random-token prompt; draft proposals replaced by the "
+                f"target's own greedy token with probability {args.accept_prob})",
+        "config": {"workload": f"{args.target} target + {args.draft} draft, k={k}, batch 1 per GPU, "
+                               f"prompt {args.prompt_len}, TP=1 (BASELINE.json configs[1])",
+                   "accept_prob": args.accept_prob, "parallelism": f"dp{world} (independent replicas)",
+                   "hipgraph": not args.no_graph, "split_tokens": args.split_tokens},
+        "accept_len": round(main_res["accept_len"], 3),
+        "emitted_per_step": round(main_res["emitted_per_step"], 3),
+        "draft_acceptance_rate": round(main_res["draft_acceptance_rate"], 4),
+        "system_efficiency": round(main_res["system_efficiency"], 4),
+        "spec_stream_equals_ar_stream": bool(all_exact),
+        "ar_tokens_per_s": round(ar_tps, 2), "speedup_vs_ar": round(value / world / ar_tps, 3),
+        "prefill_s": round(main_res["prefill_s"], 3),
+        "step_roofline": {"bound": "hbm", "bytes_per_step": int(sb),
+                          "achieved": round(sb / (ms_per_step * 1e-3) * 1e-9, 1), "peak": HBM_PEAK_GBS,
+                          "unit": "GB/s", "frac": round(sb / (ms_per_step * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)},
+        "roofline": roof,
+        "verify_attention_roofline": attn,
+        "accept_sweep": sweep,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+"""Paged verify/decode attention and rope+append against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.attention import unpack_pages, verify_attention
+from tests.gpu_util import pack_cache, rb
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from vllm_omni_draft_amd import ops
+    return ops
+
+
+def _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed, shuffle=True):
+    """Random K/V for every sequence (context + the q_len new tokens), packed into a
+    shared page pool with shuffled block tables."""
+    g = torch.Generator().manual_seed(seed)
+    max_len = max(ctx_lens) + q_len
+    pages_per_seq = (max_len + 15) // 16
+    num_pages = B * pages_per_seq + 3
+    perm = torch.randperm(num_pages, generator=g) if shuffle else torch.arange(num_pages)
+    bt = perm[:B * pages_per_seq].view(B, pages_per_seq).to(torch.int32)
+    kc = torch.zeros(num_pages, Hkv, D * 16, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    ks, vs, qs = [], [], []
+    for b in range(B):
+        n = ctx_lens[b] + q_len
+        k = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
+        v = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
+        kb, vb = pack_cache(k, v, bt[b], num_pages)
+        used = bt[b].long()
+        kc[used], vc[used] = kb[used], vb[used]
+        ks.append(k); vs.append(v)
+        qs.append(torch.randn(q_len, Hq, D, generator=g).to(torch.bfloat16))
+    return kc, vc, bt, ks, vs, qs
+
+
+CASES = [
+    # B, ctx_lens, q_len, Hq, Hkv, D, split
+    (1, [0], 1, 4, 2, 64, 128),
+    (1, [15], 2, 4, 2, 64, 128),
+    (1, [16], 6, 4, 2, 64, 128),
+    (1, [17], 6, 32, 8, 128, 256),
+    (1, [100], 6, 32, 8, 128, 256),
+    (2, [300, 7], 6, 32, 8, 128, 128),       # several splits + merge, ragged batch
+    (3, [700, 129, 31], 2, 32, 8, 64, 256),   # draft-style first pass (2 tokens)
+    (1, [260], 6, 28, 4, 128, 128),           # group of 7 heads: two 32-row M tiles
+    (1, [500], 8, 8, 2, 128, 256),            # 8-token chunk (prefill path)
+    (2, [40, 1023], 4, 12, 12, 64, 256),      # MHA (OPT-like)
+]
+
+
+@pytest.mark.parametrize("B,ctx_lens,q_len,Hq,Hkv,D,split", CASES)
+def test_paged_attention_matches_oracle(B, ctx_lens, q_len, Hq, Hkv, D, split):
+    ops = _ops()
+    kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed=sum(ctx_lens) + q_len)
+    q = torch.cat(qs).reshape(B * q_len, Hq * D).cuda()
+    seq_lens = torch.tensor(ctx_lens, dtype=torch.int32).cuda()   # first new position = ctx
+    max_ctx = max(ctx_lens) + q_len
+    out = ops.paged_attention(q, kc.cuda(), vc.cuda(), bt.cuda(), seq_lens, 0, B, q_len, Hq, Hkv, D,
+                              D ** -0.5, max_ctx, split)
+    torch.cuda.synchronize()
+    out = out.float().cpu().view(B, q_len, Hq, D)
+    for b in range(B):
+        pos = [ctx_lens[b] + t for t in range(q_len)]
+        ref = verify_attention(qs[b], ks[b], vs[b], pos, D ** -0.5)
+        torch.testing.assert_close(out[b], ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("split,max_pad", [(128, 0), (256, 0), (128, 1000)])
+def test_verify_rows_equal_single_token_decode(split, max_pad):
+    """Bit-exact: token t scored inside a (k+1)-token verify pass == the same token
+    scored alone at the same position, for any batch mix and any max_ctx bound."""
+    ops = _ops()
+    B, ctx_lens, q_len, Hq, Hkv, D = 2, [333, 18], 6, 32, 8, 128
+    kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed=3)
+    pad = (max_pad + 15) // 16
+    bt = torch.cat([bt, torch.zeros(B, pad, dtype=torch.int32)], dim=1).contiguous()
+    kc, vc, btc = kc.cuda(), vc.cuda(), bt.cuda()
+    q = torch.cat(qs).reshape(B * q_len, Hq * D).cuda()
+    seq_lens = torch.tensor(ctx_lens, dtype=torch.int32).cuda()
+    max_ctx = max(ctx_lens) + q_len + max_pad
+    full = ops.paged_attention(q, kc, vc, btc, seq_lens, 0, B, q_len, Hq, Hkv, D, D ** -0.5, max_ctx,
+                               split).view(B, q_len, Hq * D)
+    for b in range(B):
+        for t in range(q_len):
+            one = ops.paged_attention(q.view(B, q_len, -1)[b, t:t + 1].contiguous(), kc, vc,
+                                      btc[b:b + 1].contiguous(), seq_lens[b:b + 1].contiguous(), t, 1, 1,
+                                      Hq, Hkv, D, D ** -0.5, ctx_lens[b] + t + 1, split)
+            assert torch.equal(one[0], full[b, t]), (b, t)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,rope", [(4, 2, 64, True), (32, 8, 128, True), (12, 12, 64, False)])
+def test_rope_append_layout_and_values(Hq, Hkv, D, rope):
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    g = torch.Generator().manual_seed(D + Hq)
+    n, B = 45, 2
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=64)
+    cs = rope_table(cfg) if rope else None
+    pages = 8
+    bt = torch.tensor([[5, 2, 7], [1, 6, 0]], dtype=torch.int32)
+    kc = torch.zeros(pages, Hkv, D * 16, dtype=torch.bfloat16).cuda()
+    vc = torch.zeros_like(kc)
+    qkv = torch.randn(B, n, (Hq + 2 * Hkv) * D, generator=g).to(torch.bfloat16)
+    q_out = torch.zeros(B, n, Hq * D)
+    seq0 = torch.tensor([0, 0], dtype=torch.int32).cuda()
+    c0 = 0
+    for q_len in (1, 2, 6, 8, 8, 8, 8, 4):        # uneven chunks, 45 tokens in total
+        chunk = qkv[:, c0:c0 + q_len].reshape(B * q_len, -1).contiguous().cuda()
+        ops.rope_append(chunk, None if cs is None else cs.cuda(), kc, vc, bt.cuda(), seq0, c0, B, q_len,
+                        Hq, Hkv, D)
+        q_out[:, c0:c0 + q_len] = chunk.float().cpu().view(B, q_len, -1)[:, :, :Hq * D]
+        c0 += q_len
+    assert c0 == n
+    kcn, vcn = kc.float().cpu().numpy(), vc.float().cpu().numpy()
+    half = D // 2
+    for b in range(B):
+        k_got, v_got = unpack_pages(kcn, vcn, bt[b].numpy(), n, Hkv, D)
+        x = qkv[b].float().view(n, Hq + 2 * Hkv, D)
+        q_ref, k_ref, v_ref = x[:, :Hq], x[:, Hq:Hq + Hkv], x[:, Hq + Hkv:]
+        if rope:
+            c, s = cs[:n, None, :half], cs[:n, None, half:]
+            rot = lambda u: torch.cat([u[..., :half] * c - u[..., half:] * s,
+                                       u[..., half:] * c + u[..., :half] * s], dim=-1)
+            q_ref, k_ref = rot(q_ref), rot(k_ref)
+        np.testing.assert_array_equal(v_got, v_ref.numpy())
+        torch.testing.assert_close(torch.from_numpy(k_got), rb(k_ref), rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(q_out[b].view(n, Hq, D), rb(q_ref), rtol=1e-2, atol=1e-2)
+
+
+def test_attention_rejects_unsupported_shapes():
+    from vllm_omni_draft_amd._lib import SdError
+    ops = _ops()
+    z = torch.zeros(8, 64 * 80, dtype=torch.bfloat16, device="cuda")
+    bt = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
+    sl = torch.zeros(1, dtype=torch.int32, device="cuda")
+    kc = torch.zeros(4, 1, 80 * 16, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(SdError):     # head_dim 80
+        ops.paged_attention(z, kc, kc, bt, sl, 0, 1, 1, 4, 1, 80, 1.0, 8, 128)
+    with pytest.raises(SdError):     # q_len * group > 64
+        ops.paged_attention(z, kc, kc, bt, sl, 0, 1, 8, 64, 4, 64, 1.0, 8, 128)
+    with pytest.raises(SdError):     # max_ctx beyond the block table
+        ops.paged_attention(z, kc, kc, bt, sl, 0, 1, 1, 4, 1, 64, 1.0, 100, 128)

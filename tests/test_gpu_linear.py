@@ -1,0 +1,105 @@
+"""Weight-streaming linear / norm / embedding kernels against fp32 torch math,
+and the row-independence (batch-invariance) property that greedy parity with
+autoregressive decoding rests on."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from vllm_omni_draft_amd import ops
+    return ops
+
+
+def rb(x):
+    return x.to(torch.bfloat16).float()
+
+
+def _ref_linear(W, x, bias, residual, epi, ops):
+    y = x.float() @ W.float().t()
+    if epi == ops.EPI_SILU_MUL:
+        N = W.shape[0] // 2
+        g, u = y[:, :N], y[:, N:]
+        if bias is not None:
+            g, u = g + bias[:N].float(), u + bias[N:].float()
+        return rb(rb(torch.nn.functional.silu(rb(g))) * rb(u))
+    if bias is not None:
+        y = y + bias.float()
+    if epi == ops.EPI_F32:
+        return y
+    if epi == ops.EPI_RESIDUAL:
+        return rb(rb(y) + residual.float())
+    if epi == ops.EPI_RELU:
+        return rb(torch.relu(rb(y)))
+    if epi == ops.EPI_GELU_TANH:
+        return rb(torch.nn.functional.gelu(rb(y), approximate="tanh"))
+    return rb(y)
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 6, 8])
+@pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (257, 896), (96, 14336)])
+def test_linear_epilogues(M, N, K):
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=gen, device="cuda")).to(torch.bfloat16)
+    bias = (torch.randn(2 * N, generator=gen, device="cuda") * 0.1).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=gen, device="cuda").to(torch.bfloat16)
+    W2 = (torch.randn(2 * N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    W = W2[:N].contiguous()
+    for epi in (ops.EPI_STORE, ops.EPI_RESIDUAL, ops.EPI_RELU, ops.EPI_F32, ops.EPI_GELU_TANH):
+        for b in (None, bias[:N].contiguous()):
+            got = ops.linear(W, x, b, res if epi == ops.EPI_RESIDUAL else None, epi).float()
+            ref = _ref_linear(W, x, b, res, epi, ops)
+            torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+    for b in (None, bias):
+        got = ops.linear(W2, x, b, None, ops.EPI_SILU_MUL).float()
+        ref = _ref_linear(W2, x, b, None, ops.EPI_SILU_MUL, ops)
+        torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
+
+
+def test_linear_f32_accuracy():
+    """f32 output vs float64 reference: accumulation error only."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    W = (torch.randn(512, 4096, generator=gen, device="cuda") * 0.02).to(torch.bfloat16)
+    x = torch.randn(6, 4096, generator=gen, device="cuda").to(torch.bfloat16)
+    got = ops.linear(W, x, None, None, ops.EPI_F32).double()
+    ref = x.double() @ W.double().t()
+    assert (got - ref).abs().max().item() < 2e-5 * 4096 ** 0.5
+
+
+@pytest.mark.parametrize("epi_name", ["EPI_STORE", "EPI_F32", "EPI_SILU_MUL", "EPI_RESIDUAL"])
+def test_linear_rows_are_independent(epi_name):
+    """Row m of an M-row call is bit-identical to the same row computed alone."""
+    ops = _ops()
+    epi = getattr(ops, epi_name)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    K, N = 2048, 384
+    W = (torch.randn(2 * N if epi == ops.EPI_SILU_MUL else N, K, generator=gen, device="cuda") * 0.03
+         ).to(torch.bfloat16)
+    x = torch.randn(8, K, generator=gen, device="cuda").to(torch.bfloat16)
+    res = torch.randn(8, N, generator=gen, device="cuda").to(torch.bfloat16)
+    full = ops.linear(W, x, None, res if epi == ops.EPI_RESIDUAL else None, epi)
+    for M in (1, 2, 6):
+        for m0 in (0, 8 - M):
+            part = ops.linear(W, x[m0:m0 + M].contiguous(), None,
+                              res[m0:m0 + M].contiguous() if epi == ops.EPI_RESIDUAL else None, epi)
+            assert torch.equal(part, full[m0:m0 + M]), (M, m0)
+
+
+@pytest.mark.parametrize("H", [64, 768, 896, 4096, 8192])
+def test_norms(H):
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(H)
+    x = (torch.randn(7, H, generator=gen, device="cuda") * 3).to(torch.bfloat16)
+    w = (1 + 0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
+    b = (0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
+    got = ops.rmsnorm(x, w, 1e-5).float()
+    xf = x.float()
+    ref = rb(rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-5)) * w.float())
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
+    got = ops.layernorm(x, w, b, 1e-5).float()
+    ref = rb(torch.nn.functional.layer_norm(xf, (H,), w.float(), b.float(), 1e-5))
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=2e-2)

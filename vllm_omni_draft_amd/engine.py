@@ -190,7 +190,7 @@ class SpecEngine:
             if logits is not None:
                 sub_logits = logits[b0 * q_len:(b0 + nb) * q_len]
             view = _KvView(kv, slot0 + b0)
-            model.forward(view, tokens[b0 * tok_stride:] if tok_stride else tokens, tok_stride,
+            model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens, tok_stride,
                           tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self.max_ctx)
 
     def _enqueue_step(self) -> None:
