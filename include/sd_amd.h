@@ -116,8 +116,7 @@ int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
  * position pos = seq_lens[b] + pos_offset + t: rotates q in place, rotates k,
  * and writes k, v into the page block_tables[b][pos/16].
  *   qkv        [B*q_len, (Hq + 2*Hkv) * D] bf16, q heads then k then v
- *   rope_cs    [max_pos, D] f32: cos (D/2) then sin (D/2); NULL = no rotation
- *   rot_dim    number of leading dims rotated (== D for Llama/Qwen2)         */
+ *   rope_cs    [max_pos, D] f32: cos (D/2) then sin (D/2); NULL = no rotation */
 int sd_rope_append(void* qkv, const float* rope_cs, int max_pos, void* k_cache,
                    void* v_cache, const int32_t* block_tables,
                    int max_blocks_per_seq, const int32_t* seq_lens,
@@ -169,6 +168,29 @@ typedef enum {
 int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
               const void* residual, void* out, int64_t ldo, int M, int N, int K,
               int epilogue, sd_stream_t stream);
+
+/* The same with a norm fused in front: x is first normalised per row (RMSNorm,
+ * or LayerNorm when layer_norm != 0; norm_b may be NULL) exactly as sd_rmsnorm /
+ * sd_layernorm would, then multiplied.  K is the hidden size; needs
+ * M * K * 2 <= 144 KiB (the normalised rows live in LDS).  Epilogues: STORE,
+ * SILU_MUL, RELU, F32.                                                        */
+int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w,
+                   const void* norm_b, float eps, int layer_norm,
+                   const void* bias, void* out, int64_t ldo, int M, int N,
+                   int K, int epilogue, sd_stream_t stream);
+
+/* Fused  norm -> QKV projection -> rotary embedding -> KV-cache append.
+ * W is [(Hq + 2*Hkv) * D, K] (q heads, k heads, v heads).  Rotated q goes to
+ * q_out [B*q_len, Hq*D] (row stride ldq); rotated k and v go straight into the
+ * cache pages (arguments as sd_rope_append).  norm_w == NULL skips the norm. */
+int sd_norm_qkv_rope(const void* W, const void* x, int64_t ldx,
+                     const void* norm_w, const void* norm_b, float eps,
+                     int layer_norm, const void* bias, void* q_out, int64_t ldq,
+                     const float* rope_cs, int max_pos, void* k_cache,
+                     void* v_cache, const int32_t* block_tables,
+                     int max_blocks_per_seq, const int32_t* seq_lens,
+                     int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
+                     int K, sd_stream_t stream);
 
 /* out = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w) per row; rows x H bf16. */
 int sd_rmsnorm(const void* x, int64_t ldx, const void* w, void* out,

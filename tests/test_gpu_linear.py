@@ -103,3 +103,59 @@ def test_norms(H):
     got = ops.layernorm(x, w, b, 1e-5).float()
     ref = rb(torch.nn.functional.layer_norm(xf, (H,), w.float(), b.float(), 1e-5))
     torch.testing.assert_close(got, ref, rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M", [1, 6, 8])
+@pytest.mark.parametrize("H,N", [(768, 3072), (2048, 512), (4096, 1024), (8192, 256)])
+def test_fused_norm_linear_matches_unfused(M, H, N):
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(H + M)
+    x = (torch.randn(M, H, generator=gen, device="cuda") * 2).to(torch.bfloat16)
+    g = (1 + 0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
+    b = (0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
+    W = (torch.randn(2 * N, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    for ln in (False, True):
+        xn = ops.layernorm(x, g, b, 1e-5) if ln else ops.rmsnorm(x, g, 1e-5)
+        for epi, Wm in ((ops.EPI_F32, W[:N].contiguous()), (ops.EPI_STORE, W[:N].contiguous()),
+                        (ops.EPI_SILU_MUL, W), (ops.EPI_RELU, W[:N].contiguous())):
+            ref = ops.linear(Wm, xn, None, None, epi).float()
+            got = ops.norm_linear(Wm, x, g, b if ln else None, 1e-5, ln, None, epi).float()
+            torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+    # rows are independent in the fused kernel too
+    full = ops.norm_linear(W[:N].contiguous(), x, g, None, 1e-5, False, None, ops.EPI_F32)
+    one = ops.norm_linear(W[:N].contiguous(), x[M - 1:].contiguous(), g, None, 1e-5, False, None,
+                          ops.EPI_F32)
+    assert torch.equal(one[0], full[M - 1])
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,H,rope", [(4, 2, 64, 256, True), (32, 8, 128, 4096, True),
+                                              (12, 12, 64, 768, False), (14, 2, 64, 896, True)])
+def test_fused_qkv_rope_append_matches_unfused(Hq, Hkv, D, H, rope):
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    gen = torch.Generator(device="cuda").manual_seed(Hq * D)
+    B, q_len = 2, 3
+    M = B * q_len
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=128)
+    cs = rope_table(cfg).cuda() if rope else None
+    x = torch.randn(M, H, generator=gen, device="cuda").to(torch.bfloat16)
+    g = (1 + 0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
+    W = (torch.randn((Hq + 2 * Hkv) * D, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    bias = (0.1 * torch.randn((Hq + 2 * Hkv) * D, generator=gen, device="cuda")).to(torch.bfloat16)
+    bt = torch.tensor([[3, 1, 4], [0, 5, 2]], dtype=torch.int32, device="cuda")
+    seq_lens = torch.tensor([17, 30], dtype=torch.int32, device="cuda")
+    caches = []
+    for fused in (False, True):
+        kc = torch.zeros(6, Hkv, D * 16, dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        if fused:
+            q = ops.norm_qkv_rope(W, x, g, None, 1e-5, False, bias, cs, kc, vc, bt, seq_lens, -1, B,
+                                  q_len, Hq, Hkv, D)
+        else:
+            qkv = ops.linear(W, ops.rmsnorm(x, g, 1e-5), bias, None, ops.EPI_STORE)
+            ops.rope_append(qkv, cs, kc, vc, bt, seq_lens, -1, B, q_len, Hq, Hkv, D)
+            q = qkv[:, :Hq * D].contiguous()
+        caches.append((q.float(), kc.float(), vc.float()))
+    for a, b in zip(*caches):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2)
+    assert caches[1][1].abs().sum() > 0 and caches[1][2].abs().sum() > 0

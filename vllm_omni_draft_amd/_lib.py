@@ -64,6 +64,9 @@ SIGNATURES = {
     "sd_paged_attention": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, i32,
                                  i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
     "sd_linear": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "sd_norm_linear": (i32, [vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "sd_norm_qkv_rope": (i32, [vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,
+                               i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sd_rmsnorm": (i32, [vp, i64, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_layernorm": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_embed": (i32, [vp, i64, i64, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),

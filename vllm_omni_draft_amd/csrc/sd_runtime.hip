@@ -168,30 +168,47 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
     void* vc = (char*)kv->v_cache + (size_t)li * kv->layer_stride_bytes;
-    if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
-    else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
-    SD_TRY(sd_linear(l.qkv_w, xn, H, l.qkv_b, nullptr, qkv, qkv_cols, rows, (int)qkv_cols, H,
-                     SD_EPI_STORE, stream));
-    SD_TRY(sd_rope_append(qkv, llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
-                          kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len, Hq,
-                          Hkv, D, stream));
-    SD_TRY(sd_paged_attention(qkv, qkv_cols, kc, vc, kv->block_tables, kv->max_blocks_per_seq,
-                              a->seq_lens, a->pos_offset, attn, (int64_t)Hq * D, a->B, a->q_len,
-                              Hq, Hkv, D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
-                              w.attn_ws_bytes, stream));
+    const bool fuse = (size_t)rows * H * 2 <= 144 * 1024;
+    if (fuse) {
+      SD_TRY(sd_norm_qkv_rope(l.qkv_w, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
+                              l.qkv_b, qkv, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos,
+                              kc, vc, kv->block_tables, kv->max_blocks_per_seq, a->seq_lens,
+                              a->pos_offset, a->B, a->q_len, Hq, Hkv, D, H, stream));
+    } else {
+      if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
+      else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
+      SD_TRY(sd_norm_qkv_rope(l.qkv_w, xn, H, nullptr, nullptr, 0.f, 0, l.qkv_b, qkv,
+                              (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos, kc, vc,
+                              kv->block_tables, kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
+                              a->B, a->q_len, Hq, Hkv, D, H, stream));
+    }
+    SD_TRY(sd_paged_attention(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                              kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
+                              (int64_t)Hq * D, a->B, a->q_len, Hq, Hkv, D, d.attn_scale, a->max_ctx,
+                              a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
     SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, l.o_b, h, h, H, rows, H, Hq * D,
                      SD_EPI_RESIDUAL, stream));
-    if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
-    else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
-    SD_TRY(sd_linear(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H,
-                     llama ? SD_EPI_SILU_MUL : SD_EPI_RELU, stream));
+    const int act_epi = llama ? SD_EPI_SILU_MUL : SD_EPI_RELU;
+    if (fuse) {
+      SD_TRY(sd_norm_linear(l.up_w, h, H, l.mlp_norm_w, l.mlp_norm_b, d.norm_eps, !llama, l.up_b,
+                            act, F, rows, F, H, act_epi, stream));
+    } else {
+      if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
+      else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
+      SD_TRY(sd_linear(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H, act_epi, stream));
+    }
     SD_TRY(sd_linear(l.down_w, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL, stream));
   }
   if (a->logits) {
-    if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
-    else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
-    SD_TRY(sd_linear(d.lm_head, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
-                     SD_EPI_F32, stream));
+    if ((size_t)rows * H * 2 <= 144 * 1024) {
+      SD_TRY(sd_norm_linear(d.lm_head, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
+                            nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, stream));
+    } else {
+      if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
+      else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
+      SD_TRY(sd_linear(d.lm_head, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
+                       SD_EPI_F32, stream));
+    }
   }
   return SD_OK;
 }

@@ -228,3 +228,37 @@ def advance_state(out_ids, seq_lens, tok_buf, gen_tokens, gen_counts, k) -> None
         0 if gen_tokens is None else gen_tokens.shape[1],
         0 if gen_tokens is None else gen_tokens.shape[1], _p(gen_counts), B, k, _stream()),
         "sd_advance_state")
+
+
+def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None,
+                epilogue=EPI_STORE, out=None) -> torch.Tensor:
+    """linear(norm(x)) in one kernel (RMSNorm, or LayerNorm when layer_norm)."""
+    _need(W, torch.bfloat16, "W")
+    _need(x, torch.bfloat16, "x")
+    _need(norm_w, torch.bfloat16, "norm_w")
+    M, K = x.shape
+    N = W.shape[0] // 2 if epilogue == EPI_SILU_MUL else W.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16,
+                          device=x.device)
+    _lib.check(_lib.load().sd_norm_linear(_p(W), _p(x), K, _p(norm_w), _p(norm_b), float(eps),
+                                          int(layer_norm), _p(bias), _p(out), N, M, N, K, epilogue,
+                                          _stream()), "sd_norm_linear")
+    return out
+
+
+def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache, v_cache,
+                  block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D) -> torch.Tensor:
+    """norm -> QKV projection -> rotary -> cache append; returns rotated q [B*q_len, Hq*D]."""
+    _need(W, torch.bfloat16, "W")
+    _need(x, torch.bfloat16, "x")
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    M, K = x.shape
+    q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().sd_norm_qkv_rope(
+        _p(W), _p(x), K, _p(norm_w), _p(norm_b), float(eps), int(layer_norm), _p(bias), _p(q),
+        Hq * D, _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache),
+        _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
+        _stream()), "sd_norm_qkv_rope")
+    return q
