@@ -111,20 +111,21 @@ def kernel_roofline(eng, tw, rows, reps=3):
     epi = ops.EPI_SILU_MUL if cfg.arch == "llama" else ops.EPI_RELU
     with torch.cuda.stream(eng.stream):
         for l in tw.layers:  # warm-up pass
-            ops.linear(l.up_w, x, None, None, epi, out=out)
+            ops.norm_linear(l.up_w, x, l.mlp_norm_w, l.mlp_norm_b, cfg.norm_eps, cfg.arch != 'llama', l.up_b, epi, out=out)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
             for l in tw.layers:
-                ops.linear(l.up_w, x, None, None, epi, out=out)
+                ops.norm_linear(l.up_w, x, l.mlp_norm_w, l.mlp_norm_b, cfg.norm_eps, cfg.arch != 'llama', l.up_b, epi, out=out)
         e1.record()
         e1.synchronize()
     n = reps * len(tw.layers)
     us = e0.elapsed_time(e1) * 1e3 / n
     w = tw.layers[0].up_w
-    bytes_per_launch = w.numel() * 2 + x.numel() * 2 + out.numel() * 2
+    bytes_per_launch = w.nbytes() + x.numel() * 2 + out.numel() * 2
     gbs = bytes_per_launch / us * 1e-3
-    return {"kernel": f"linear_kernel<M={rows},gate_up+silu_mul> [{w.shape[0]}x{w.shape[1]}] bf16",
+    n_rows = 2 * w.N if cfg.arch == "llama" else w.N
+    return {"kernel": f"linear_kernel<norm+gate_up+silu_mul>, M={rows} [{n_rows}x{w.K}] bf16",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}

@@ -145,34 +145,56 @@ int sd_paged_attention(const void* q, int64_t ldq, const void* k_cache,
                        size_t workspace_bytes, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
- * Dense ops of a decoder layer at <= 8 token rows (weight streaming; replaces
+ * Dense ops of a decoder layer at <= 16 token rows (weight streaming; replaces
  * the per-step model execution inside spec_decode.multi_step_worker and the
  * scorer's target forward).
+ *
+ * Weight matrices are consumed PRE-TILED for the 16x16x32 bf16 MFMA: tile
+ * (nt, ks) = 16 rows x 32 columns stored as [64 lanes][8 elements], lane l
+ * holding row (l & 15), columns 32*ks + 8*(l >> 4) .. +8; tiles ordered
+ * [nt][ks].  One wave load is then 1 KiB of contiguous memory.  Which source
+ * rows form tile nt depends on the mode:
+ *   SD_TILE_PLAIN   rows 16*nt .. 16*nt+15
+ *   SD_TILE_GATED   src = [2F, K] (gate rows, then up rows): tile nt holds gate
+ *                   rows 8*nt..8*nt+7 and up rows 8*nt..8*nt+7 (SILU_MUL epilogue)
+ *   SD_TILE_ROTARY  src = [heads*D, K]: tile nt holds dims i0..i0+7 of a head and
+ *                   their rotation partners i0+D/2..i0+D/2+7 (sd_norm_qkv_rope)
+ * sd_tile_weights converts a row-major bf16 matrix once, at load time.
  * ---------------------------------------------------------------------- */
+
+typedef enum { SD_TILE_PLAIN = 0, SD_TILE_GATED = 1, SD_TILE_ROTARY = 2 } sd_tile_mode;
+
+/* Elements (bf16) of the tiled copy of an N x K matrix (N = F outputs for
+ * SD_TILE_GATED).  K must be a multiple of 32.                              */
+size_t sd_tiled_weight_elems(int N, int K, int mode);
+/* src row-major -> dst tiled; param = head_dim for SD_TILE_ROTARY, else 0.  */
+int sd_tile_weights(const void* src, void* dst, int N, int K, int mode,
+                    int param, sd_stream_t stream);
 
 typedef enum {
   SD_EPI_STORE = 0,     /* out = bf16(acc + bias)                           */
   SD_EPI_RESIDUAL = 1,  /* out = bf16(bf16(acc + bias) + residual)          */
-  SD_EPI_SILU_MUL = 2,  /* W holds 2N rows: out = silu(row n) * row (N+n)   */
+  SD_EPI_SILU_MUL = 2,  /* GATED tiling: out = silu(gate row n) * up row n   */
   SD_EPI_RELU = 3,      /* out = bf16(max(acc + bias, 0))                   */
   SD_EPI_F32 = 4,       /* out (f32) = acc + bias                           */
   SD_EPI_GELU_TANH = 5  /* out = bf16(gelu_tanh(acc + bias))                */
 } sd_epilogue;
 
-/* out[m, n] = epilogue(sum_k x[m, k] * W[n, k]),  m < M <= 8.
- *   W [N(or 2N), K] bf16 row-major; x [M, K] bf16 (row stride ldx);
- *   bias [N] bf16 or NULL; residual [M, N] bf16 (row stride ldo) or NULL.
+/* out[m, n] = epilogue(sum_k x[m, k] * W[n, k]),  m < M <= 16.
+ *   W tiled (PLAIN; GATED for SD_EPI_SILU_MUL, then N = F outputs);
+ *   x [M, K] bf16 (row stride ldx); bias [N] (GATED: [2F]) bf16 or NULL;
+ *   residual [M, N] bf16 (row stride ldo) or NULL.
  * Each output element is accumulated in an order that depends only on K, so
  * a row's result does not depend on M or on the other rows.
- * Requires K % 8 == 0 and 16-byte aligned rows.                             */
+ * Requires K % 32 == 0 and 16-byte aligned rows.                            */
 int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
               const void* residual, void* out, int64_t ldo, int M, int N, int K,
               int epilogue, sd_stream_t stream);
 
 /* The same with a norm fused in front: x is first normalised per row (RMSNorm,
  * or LayerNorm when layer_norm != 0; norm_b may be NULL) exactly as sd_rmsnorm /
- * sd_layernorm would, then multiplied.  K is the hidden size; needs
- * M * K * 2 <= 144 KiB (the normalised rows live in LDS).  Epilogues: STORE,
+* sd_layernorm would, then multiplied.  K is the hidden size; needs
+ * (M + 1) * K * 2 <= 128 KiB (the normalised rows live in LDS).  Epilogues: STORE,
  * SILU_MUL, RELU, F32.                                                        */
 int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w,
                    const void* norm_b, float eps, int layer_norm,
@@ -180,7 +202,8 @@ int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w
                    int K, int epilogue, sd_stream_t stream);
 
 /* Fused  norm -> QKV projection -> rotary embedding -> KV-cache append.
- * W is [(Hq + 2*Hkv) * D, K] (q heads, k heads, v heads).  Rotated q goes to
+ * W is [(Hq + 2*Hkv) * D, K] (q heads, k heads, v heads), tiled SD_TILE_ROTARY;
+ * bias is indexed by source row.  Rotated q goes to
  * q_out [B*q_len, Hq*D] (row stride ldq); rotated k and v go straight into the
  * cache pages (arguments as sd_rope_append).  norm_w == NULL skips the norm. */
 int sd_norm_qkv_rope(const void* W, const void* x, int64_t ldx,
@@ -200,9 +223,10 @@ int sd_layernorm(const void* x, int64_t ldx, const void* w, const void* b,
                  void* out, int64_t ldo, int rows, int H, float eps,
                  sd_stream_t stream);
 /* out[r] = table[ids[r*id_stride]] (+ pos_table[pos(r) + pos_bias]) bf16.
- * pos(r) = seq_lens[r / q_len] + pos_offset + r % q_len.                    */
+ * pos(r) = seq_lens[r / q_len] + pos_offset + r % q_len.  table_tiled != 0:
+ * the table is stored in the SD_TILE_PLAIN layout (a tied LM head).  H % 32 == 0. */
 int sd_embed(const int32_t* ids, int64_t id_stride_seq, int64_t id_offset,
-             const void* table, const void* pos_table, int pos_bias,
+             const void* table, int table_tiled, const void* pos_table, int pos_bias,
              const int32_t* seq_lens, int pos_offset, void* out, int B,
              int q_len, int H, int vocab, sd_stream_t stream);
 
@@ -215,15 +239,15 @@ typedef enum { SD_ARCH_LLAMA = 0, SD_ARCH_OPT = 1 } sd_arch;
 typedef struct {
   const void* attn_norm_w;  /* [H] */
   const void* attn_norm_b;  /* [H] or NULL (OPT) */
-  const void* qkv_w;        /* [(Hq+2Hkv)*D, H] */
+  const void* qkv_w;        /* [(Hq+2Hkv)*D, H], tiled SD_TILE_ROTARY */
   const void* qkv_b;        /* or NULL */
-  const void* o_w;          /* [H, Hq*D] */
+  const void* o_w;          /* [H, Hq*D], tiled SD_TILE_PLAIN */
   const void* o_b;          /* or NULL */
   const void* mlp_norm_w;   /* [H] */
   const void* mlp_norm_b;   /* or NULL */
-  const void* up_w;         /* LLAMA: [2F, H] gate rows then up rows; OPT: [F, H] */
+  const void* up_w;         /* LLAMA: [2F, H] tiled SD_TILE_GATED; OPT: [F, H] tiled PLAIN */
   const void* up_b;         /* or NULL */
-  const void* down_w;       /* [H, F] */
+  const void* down_w;       /* [H, F], tiled SD_TILE_PLAIN */
   const void* down_b;       /* or NULL */
 } sd_layer_weights;
 
@@ -234,12 +258,13 @@ typedef struct {
   int pos_bias;    /* OPT learned positions start at row 2 */
   float norm_eps;
   float attn_scale;        /* usually head_dim^-0.5 */
-  const void* embed;       /* [vocab, H] bf16 */
+  const void* embed;       /* [vocab, H] bf16, row-major (tiled if embed_tiled) */
+  int embed_tiled;
   const void* pos_table;   /* [max_pos + pos_bias, H] bf16 or NULL */
   const float* rope_cs;    /* [max_pos, D] f32 or NULL */
   const void* final_norm_w;
   const void* final_norm_b; /* or NULL */
-  const void* lm_head;     /* [vocab, H] bf16 (== embed when tied) */
+  const void* lm_head;     /* [vocab, H] bf16 tiled SD_TILE_PLAIN (== embed when tied) */
   const sd_layer_weights* layers; /* n_layers entries (copied) */
 } sd_model_desc;
 
@@ -257,7 +282,7 @@ typedef struct {
 } sd_kv_cache;
 
 typedef struct {
-  int B, q_len;              /* q_len tokens per sequence, B*q_len <= 8 */
+  int B, q_len;              /* q_len tokens per sequence, B*q_len <= 16 */
   const int32_t* token_ids;  /* token t of seq b at [b*tok_stride + tok_offset + t] */
   int64_t tok_stride, tok_offset;
   const int32_t* seq_lens;   /* [B] device; first new position = seq_lens[b] + pos_offset */

@@ -38,7 +38,7 @@ def _ref_linear(W, x, bias, residual, epi, ops):
     return rb(y)
 
 
-@pytest.mark.parametrize("M", [1, 2, 5, 6, 8])
+@pytest.mark.parametrize("M", [1, 2, 5, 6, 8, 13, 16])
 @pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (257, 896), (96, 14336)])
 def test_linear_epilogues(M, N, K):
     ops = _ops()
@@ -76,14 +76,15 @@ def test_linear_rows_are_independent(epi_name):
     ops = _ops()
     epi = getattr(ops, epi_name)
     gen = torch.Generator(device="cuda").manual_seed(5)
-    K, N = 2048, 384
+    K, N = (14336, 384) if epi == ops.EPI_RESIDUAL else (2048, 384)   # 14336: x is chunked at M >= 5
     W = (torch.randn(2 * N if epi == ops.EPI_SILU_MUL else N, K, generator=gen, device="cuda") * 0.03
          ).to(torch.bfloat16)
-    x = torch.randn(8, K, generator=gen, device="cuda").to(torch.bfloat16)
-    res = torch.randn(8, N, generator=gen, device="cuda").to(torch.bfloat16)
+    x = torch.randn(16, K, generator=gen, device="cuda").to(torch.bfloat16)
+    res = torch.randn(16, N, generator=gen, device="cuda").to(torch.bfloat16)
+    W = ops.tile_weights(W, ops.TILE_GATED if epi == ops.EPI_SILU_MUL else ops.TILE_PLAIN)
     full = ops.linear(W, x, None, res if epi == ops.EPI_RESIDUAL else None, epi)
-    for M in (1, 2, 6):
-        for m0 in (0, 8 - M):
+    for M in (1, 2, 6, 11):
+        for m0 in (0, 16 - M):
             part = ops.linear(W, x[m0:m0 + M].contiguous(), None,
                               res[m0:m0 + M].contiguous() if epi == ops.EPI_RESIDUAL else None, epi)
             assert torch.equal(part, full[m0:m0 + M]), (M, m0)
@@ -114,6 +115,12 @@ def test_fused_norm_linear_matches_unfused(M, H, N):
     g = (1 + 0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
     b = (0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
     W = (torch.randn(2 * N, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    if (M + 1) * (H + 8) * 2 > 128 * 1024:
+        # the normalised rows must fit in LDS; callers fall back to the stand-alone norm
+        from vllm_omni_draft_amd._lib import SdError
+        with pytest.raises(SdError):
+            ops.norm_linear(W[:N].contiguous(), x, g, None, 1e-5, False, None, ops.EPI_F32)
+        return
     for ln in (False, True):
         xn = ops.layernorm(x, g, b, 1e-5) if ln else ops.rmsnorm(x, g, 1e-5)
         for epi, Wm in ((ops.EPI_F32, W[:N].contiguous()), (ops.EPI_STORE, W[:N].contiguous()),

@@ -33,7 +33,7 @@ class ModelDesc(C.Structure):
         ("arch", i32), ("n_layers", i32), ("hidden", i32), ("n_heads", i32), ("n_kv_heads", i32),
         ("head_dim", i32), ("ffn", i32), ("vocab", i32), ("max_pos", i32), ("pos_bias", i32),
         ("norm_eps", C.c_float), ("attn_scale", C.c_float),
-        ("embed", vp), ("pos_table", vp), ("rope_cs", vp), ("final_norm_w", vp),
+        ("embed", vp), ("embed_tiled", i32), ("pos_table", vp), ("rope_cs", vp), ("final_norm_w", vp),
         ("final_norm_b", vp), ("lm_head", vp), ("layers", C.POINTER(LayerWeights)),
     ]
 
@@ -69,7 +69,9 @@ SIGNATURES = {
                                i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sd_rmsnorm": (i32, [vp, i64, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_layernorm": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, C.c_float, vp]),
-    "sd_embed": (i32, [vp, i64, i64, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "sd_embed": (i32, [vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "sd_tiled_weight_elems": (C.c_size_t, [i32, i32, i32]),
+    "sd_tile_weights": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sd_model_create": (vp, [C.POINTER(ModelDesc)]),
     "sd_model_destroy": (None, [vp]),
     "sd_model_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),

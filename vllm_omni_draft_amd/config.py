@@ -41,8 +41,8 @@ class ModelConfig:
             raise ValueError(f"head_dim {self.head_dim} not supported (64 or 128)")
         if self.n_heads % self.n_kv_heads:
             raise ValueError("n_heads must be a multiple of n_kv_heads")
-        if self.hidden % 8 or self.ffn % 8:
-            raise ValueError("hidden and ffn must be multiples of 8")
+        if self.hidden % 32 or self.ffn % 32 or self.vocab % 16:
+            raise ValueError("hidden and ffn must be multiples of 32, vocab a multiple of 16")
 
     @property
     def qkv_rows(self) -> int:

@@ -65,7 +65,7 @@ extern "C" sd_model* sd_model_create(const sd_model_desc* desc) {
     sd_set_error("sd_model_create: unknown arch %d", d.arch);
     return nullptr;
   }
-  if (d.hidden % 8 || d.ffn % 8 || (d.head_dim != 64 && d.head_dim != 128) ||
+  if (d.hidden % 32 || d.ffn % 32 || d.vocab % 16 || (d.head_dim != 64 && d.head_dim != 128) ||
       d.n_heads % d.n_kv_heads || d.vocab < 1 || !d.embed || !d.lm_head || !d.final_norm_w) {
     sd_set_error("sd_model_create: unsupported shape (H=%d F=%d D=%d Hq=%d Hkv=%d)", d.hidden,
                  d.ffn, d.head_dim, d.n_heads, d.n_kv_heads);
@@ -140,8 +140,8 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   SD_REQUIRE(m && kv && a && workspace, SD_ERR_INVALID, "sd_model_forward: null argument");
   const sd_model_desc& d = m->d;
   const int rows = a->B * a->q_len;
-  SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= 8, SD_ERR_UNSUPPORTED,
-             "sd_model_forward: B*q_len = %d outside 1..8", rows);
+  SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= 16, SD_ERR_UNSUPPORTED,
+             "sd_model_forward: B*q_len = %d outside 1..16", rows);
   SD_REQUIRE(a->token_ids && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
              SD_ERR_INVALID, "sd_model_forward: null buffer");
   SD_REQUIRE(a->max_ctx >= 1 && a->max_ctx <= d.max_pos, SD_ERR_INVALID,
@@ -162,13 +162,13 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const int64_t qkv_cols = (int64_t)(Hq + 2 * Hkv) * D;
   const bool llama = d.arch == SD_ARCH_LLAMA;
 
-  SD_TRY(sd_embed(a->token_ids, a->tok_stride, a->tok_offset, d.embed, d.pos_table, d.pos_bias,
+  SD_TRY(sd_embed(a->token_ids, a->tok_stride, a->tok_offset, d.embed, d.embed_tiled, d.pos_table, d.pos_bias,
                   a->seq_lens, a->pos_offset, h, a->B, a->q_len, H, d.vocab, stream));
   for (int li = 0; li < d.n_layers; ++li) {
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
     void* vc = (char*)kv->v_cache + (size_t)li * kv->layer_stride_bytes;
-    const bool fuse = (size_t)rows * H * 2 <= 144 * 1024;
+    const bool fuse = (size_t)(rows + 1) * (H + 264) * 2 <= 128 * 1024;
     if (fuse) {
       SD_TRY(sd_norm_qkv_rope(l.qkv_w, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
                               l.qkv_b, qkv, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos,
@@ -200,7 +200,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     SD_TRY(sd_linear(l.down_w, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL, stream));
   }
   if (a->logits) {
-    if ((size_t)rows * H * 2 <= 144 * 1024) {
+    if ((size_t)(rows + 1) * (H + 264) * 2 <= 128 * 1024) {
       SD_TRY(sd_norm_linear(d.lm_head, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
                             nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, stream));
     } else {

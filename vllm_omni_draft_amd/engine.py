@@ -152,14 +152,17 @@ class SpecEngine:
         for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
             if model is None:
                 continue
-            for c0 in range(0, n, MAX_ROWS):
-                q = min(MAX_ROWS, n - c0)
+            # prefill in chunks: <= MAX_ROWS rows, and q_len * (Hq/Hkv) <= 64 for attention
+            chunk = min(MAX_ROWS, 64 // (model.cfg.n_heads // model.cfg.n_kv_heads))
+            for c0 in range(0, n, chunk):
+                q = min(chunk, n - c0)
                 last = c0 + q >= n
                 want = last and model is self.target
                 self._forward(model, kv, self.prompt_buf, 0, c0, zl, c0, 1, q,
                               self.t_logits if want else None, slot0=slot)
+                if want:
+                    q_last = q
         # first generated token from the last prompt row
-        q_last = n - ((n - 1) // MAX_ROWS) * MAX_ROWS
         row = self.t_logits[q_last - 1:q_last]
         if self.sampling:
             u = torch.rand(1, generator=self.rng, device=self.device)

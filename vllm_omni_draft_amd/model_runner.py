@@ -15,11 +15,13 @@ from .config import ModelConfig
 from .kv_cache import PagedKVCache
 from .weights import ModelWeights
 
-MAX_ROWS = 8  # token rows one forward pass may carry (B * q_len)
+MAX_ROWS = 16  # token rows one forward pass may carry (B * q_len)
 
 
-def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+def _ptr(t):
+    if t is None:
+        return None
+    return t.data.data_ptr() if hasattr(t, "mode") else t.data_ptr()
 
 
 class DecoderModel:
@@ -41,7 +43,8 @@ class DecoderModel:
             n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads, head_dim=cfg.head_dim, ffn=cfg.ffn,
             vocab=cfg.vocab, max_pos=cfg.max_pos, pos_bias=cfg.pos_bias if cfg.arch == "opt" else 0,
             norm_eps=cfg.norm_eps, attn_scale=cfg.head_dim ** -0.5,
-            embed=_ptr(weights.embed), pos_table=_ptr(weights.pos_table),
+            embed=_ptr(weights.embed), embed_tiled=int(weights.embed_tiled),
+            pos_table=_ptr(weights.pos_table),
             rope_cs=_ptr(weights.rope_cs), final_norm_w=_ptr(weights.final_norm_w),
             final_norm_b=_ptr(weights.final_norm_b), lm_head=_ptr(weights.lm_head), layers=layers)
         self._handle = lib.sd_model_create(C.byref(desc))

@@ -172,19 +172,59 @@ def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, 
 
 
 # ---------------------------------------------------------------- dense ops
-def linear(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None) -> torch.Tensor:
+TILE_PLAIN, TILE_GATED, TILE_ROTARY = 0, 1, 2
+
+
+class TiledWeight:
+    """A weight matrix re-laid-out for the kernels (see include/sd_amd.h):
+    `data` is the flat tiled bf16 buffer, N the number of OUTPUT columns of the
+    linear (F for a gated [2F, K] matrix), K the input width."""
+
+    __slots__ = ("data", "N", "K", "mode")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int, mode: int):
+        self.data, self.N, self.K, self.mode = data, N, K, mode
+
+    def nbytes(self) -> int:
+        return self.data.numel() * 2
+
+
+def tile_weights(W: torch.Tensor, mode: int = TILE_PLAIN, head_dim: int = 0) -> TiledWeight:
+    """Row-major [rows, K] bf16 -> TiledWeight (one pass on the GPU, at load time)."""
     _need(W, torch.bfloat16, "W")
+    rows, K = W.shape
+    N = rows // 2 if mode == TILE_GATED else rows
+    lib = _lib.load()
+    n = int(lib.sd_tiled_weight_elems(N, K, mode))
+    if n == 0:
+        raise _lib.SdError(f"tile_weights: unsupported shape {tuple(W.shape)} (K must be a multiple of 32)")
+    dst = torch.empty(n, dtype=torch.bfloat16, device=W.device)
+    _lib.check(lib.sd_tile_weights(_p(W), _p(dst), N, K, mode, head_dim, _stream()),
+               "sd_tile_weights")
+    return TiledWeight(dst, N, K, mode)
+
+
+def _tiled(W, epilogue, head_dim=0) -> TiledWeight:
+    if isinstance(W, TiledWeight):
+        return W
+    mode = TILE_GATED if epilogue == EPI_SILU_MUL else (TILE_ROTARY if head_dim else TILE_PLAIN)
+    return tile_weights(W, mode, head_dim)
+
+
+def linear(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None) -> torch.Tensor:
+    """W: TiledWeight (or a row-major tensor, tiled on the fly — tests only)."""
     _need(x, torch.bfloat16, "x")
+    Wt = _tiled(W, epilogue)
     M, K = x.shape
-    n_rows = W.shape[0]
-    N = n_rows // 2 if epilogue == EPI_SILU_MUL else n_rows
-    if W.shape[1] != K:
-        raise _lib.SdError(f"linear: W is {tuple(W.shape)}, x is {tuple(x.shape)}")
+    N = Wt.N
+    if Wt.K != K or (Wt.mode == TILE_GATED) != (epilogue == EPI_SILU_MUL):
+        raise _lib.SdError(f"linear: weight (N={Wt.N}, K={Wt.K}, mode={Wt.mode}) does not fit "
+                           f"x {tuple(x.shape)} / epilogue {epilogue}")
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16,
                           device=x.device)
-    _lib.check(_lib.load().sd_linear(_p(W), _p(x), K, _p(bias), _p(residual), _p(out), N, M, N, K,
-                                     epilogue, _stream()), "sd_linear")
+    _lib.check(_lib.load().sd_linear(_p(Wt.data), _p(x), K, _p(bias), _p(residual), _p(out), N, M, N,
+                                     K, epilogue, _stream()), "sd_linear")
     return out
 
 
@@ -233,15 +273,15 @@ def advance_state(out_ids, seq_lens, tok_buf, gen_tokens, gen_counts, k) -> None
 def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None,
                 epilogue=EPI_STORE, out=None) -> torch.Tensor:
     """linear(norm(x)) in one kernel (RMSNorm, or LayerNorm when layer_norm)."""
-    _need(W, torch.bfloat16, "W")
     _need(x, torch.bfloat16, "x")
     _need(norm_w, torch.bfloat16, "norm_w")
+    Wt = _tiled(W, epilogue)
     M, K = x.shape
-    N = W.shape[0] // 2 if epilogue == EPI_SILU_MUL else W.shape[0]
+    N = Wt.N
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16,
                           device=x.device)
-    _lib.check(_lib.load().sd_norm_linear(_p(W), _p(x), K, _p(norm_w), _p(norm_b), float(eps),
+    _lib.check(_lib.load().sd_norm_linear(_p(Wt.data), _p(x), K, _p(norm_w), _p(norm_b), float(eps),
                                           int(layer_norm), _p(bias), _p(out), N, M, N, K, epilogue,
                                           _stream()), "sd_norm_linear")
     return out
@@ -250,14 +290,16 @@ def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None
 def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache, v_cache,
                   block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D) -> torch.Tensor:
     """norm -> QKV projection -> rotary -> cache append; returns rotated q [B*q_len, Hq*D]."""
-    _need(W, torch.bfloat16, "W")
     _need(x, torch.bfloat16, "x")
     _need(block_tables, torch.int32, "block_tables")
     _need(seq_lens, torch.int32, "seq_lens")
+    Wt = _tiled(W, EPI_STORE, head_dim=D)
+    if Wt.mode != TILE_ROTARY:
+        raise _lib.SdError("norm_qkv_rope: the QKV weight must be tiled in TILE_ROTARY mode")
     M, K = x.shape
     q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=x.device)
     _lib.check(_lib.load().sd_norm_qkv_rope(
-        _p(W), _p(x), K, _p(norm_w), _p(norm_b), float(eps), int(layer_norm), _p(bias), _p(q),
+        _p(Wt.data), _p(x), K, _p(norm_w), _p(norm_b), float(eps), int(layer_norm), _p(bias), _p(q),
         Hq * D, _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache),
         _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
         _stream()), "sd_norm_qkv_rope")

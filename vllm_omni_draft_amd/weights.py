@@ -1,5 +1,6 @@
 """Device-resident model weights in the layout the kernels stream: bf16,
-row-major [out, in], q/k/v fused into one matrix and gate/up fused into one.
+q/k/v fused into one matrix and gate/up fused into one, every matrix re-tiled
+once for the 16x16x32 MFMA (ops.tile_weights; layouts in include/sd_amd.h).
 
 Sources: a Hugging Face style state dict (names as in transformers), a local
 directory of *.safetensors shards, or seeded random initialisation.  The
@@ -15,17 +16,18 @@ from typing import Dict, List, Optional
 
 import torch
 
+from . import ops
 from .config import ModelConfig, rope_table
 
 
 @dataclass
 class LayerTensors:
     attn_norm_w: torch.Tensor
-    qkv_w: torch.Tensor
-    o_w: torch.Tensor
+    qkv_w: "ops.TiledWeight"      # TILE_ROTARY
+    o_w: "ops.TiledWeight"        # TILE_PLAIN
     mlp_norm_w: torch.Tensor
-    up_w: torch.Tensor
-    down_w: torch.Tensor
+    up_w: "ops.TiledWeight"       # TILE_GATED (llama) / TILE_PLAIN (opt)
+    down_w: "ops.TiledWeight"     # TILE_PLAIN
     attn_norm_b: Optional[torch.Tensor] = None
     qkv_b: Optional[torch.Tensor] = None
     o_b: Optional[torch.Tensor] = None
@@ -37,10 +39,11 @@ class LayerTensors:
 @dataclass
 class ModelWeights:
     cfg: ModelConfig
-    embed: torch.Tensor
+    embed: torch.Tensor           # row-major, or the tiled LM head's buffer when tied
     final_norm_w: torch.Tensor
-    lm_head: torch.Tensor
+    lm_head: "ops.TiledWeight"    # TILE_PLAIN
     layers: List[LayerTensors]
+    embed_tiled: bool = False
     pos_table: Optional[torch.Tensor] = None
     final_norm_b: Optional[torch.Tensor] = None
     rope_cs: Optional[torch.Tensor] = None
@@ -56,15 +59,28 @@ class ModelWeights:
     def tensors(self):
         for t in (self.embed, self.final_norm_w, self.lm_head, self.pos_table, self.final_norm_b):
             if t is not None:
-                yield t
+                yield t.data if isinstance(t, ops.TiledWeight) else t
         for l in self.layers:
             for t in vars(l).values():
                 if t is not None:
-                    yield t
+                    yield t.data if isinstance(t, ops.TiledWeight) else t
 
 
 def _dev(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def _tile(w: torch.Tensor, mode: int = ops.TILE_PLAIN, head_dim: int = 0) -> "ops.TiledWeight":
+    return ops.tile_weights(w, mode, head_dim)
+
+
+def _embed_and_head(embed: torch.Tensor, head, device):
+    """Untied: row-major embedding + tiled head.  Tied: ONE tiled buffer serves
+    both (the embedding gather reads rows out of the tiled layout)."""
+    if head is None:
+        t = _tile(embed)
+        return t.data, t, True
+    return embed, _tile(_dev(head, device)), False
 
 
 def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cuda") -> ModelWeights:
@@ -84,15 +100,17 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
             up_w = torch.cat([g(lp + "mlp.gate_proj.weight"), g(lp + "mlp.up_proj.weight")], dim=0)
             layers.append(LayerTensors(
                 attn_norm_w=_dev(g(lp + "input_layernorm.weight"), device),
-                qkv_w=_dev(qkv_w, device), qkv_b=None if qkv_b is None else _dev(qkv_b, device),
-                o_w=_dev(g(lp + "self_attn.o_proj.weight"), device),
+                qkv_w=_tile(_dev(qkv_w, device), ops.TILE_ROTARY, cfg.head_dim),
+                qkv_b=None if qkv_b is None else _dev(qkv_b, device),
+                o_w=_tile(_dev(g(lp + "self_attn.o_proj.weight"), device)),
                 mlp_norm_w=_dev(g(lp + "post_attention_layernorm.weight"), device),
-                up_w=_dev(up_w, device), down_w=_dev(g(lp + "mlp.down_proj.weight"), device)))
-        embed = _dev(g(pre + "embed_tokens.weight"), device)
-        head = opt("lm_head.weight")
-        return ModelWeights(cfg=cfg, embed=embed, final_norm_w=_dev(g(pre + "norm.weight"), device),
-                            lm_head=embed if head is None else _dev(head, device), layers=layers,
-                            rope_cs=rope_table(cfg, device))
+                up_w=_tile(_dev(up_w, device), ops.TILE_GATED),
+                down_w=_tile(_dev(g(lp + "mlp.down_proj.weight"), device))))
+        embed, lm_head, tied = _embed_and_head(_dev(g(pre + "embed_tokens.weight"), device),
+                                               opt("lm_head.weight"), device)
+        return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied,
+                            final_norm_w=_dev(g(pre + "norm.weight"), device), lm_head=lm_head,
+                            layers=layers, rope_cs=rope_table(cfg, device))
     pre = "model.decoder."
     for i in range(cfg.n_layers):
         lp = f"{pre}layers.{i}."
@@ -101,19 +119,20 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
         layers.append(LayerTensors(
             attn_norm_w=_dev(g(lp + "self_attn_layer_norm.weight"), device),
             attn_norm_b=_dev(g(lp + "self_attn_layer_norm.bias"), device),
-            qkv_w=_dev(qkv_w, device), qkv_b=_dev(qkv_b, device),
-            o_w=_dev(g(lp + "self_attn.out_proj.weight"), device),
+            qkv_w=_tile(_dev(qkv_w, device), ops.TILE_ROTARY, cfg.head_dim), qkv_b=_dev(qkv_b, device),
+            o_w=_tile(_dev(g(lp + "self_attn.out_proj.weight"), device)),
             o_b=_dev(g(lp + "self_attn.out_proj.bias"), device),
             mlp_norm_w=_dev(g(lp + "final_layer_norm.weight"), device),
             mlp_norm_b=_dev(g(lp + "final_layer_norm.bias"), device),
-            up_w=_dev(g(lp + "fc1.weight"), device), up_b=_dev(g(lp + "fc1.bias"), device),
-            down_w=_dev(g(lp + "fc2.weight"), device), down_b=_dev(g(lp + "fc2.bias"), device)))
-    embed = _dev(g(pre + "embed_tokens.weight"), device)
-    head = opt("lm_head.weight")
-    return ModelWeights(cfg=cfg, embed=embed, pos_table=_dev(g(pre + "embed_positions.weight"), device),
+            up_w=_tile(_dev(g(lp + "fc1.weight"), device)), up_b=_dev(g(lp + "fc1.bias"), device),
+            down_w=_tile(_dev(g(lp + "fc2.weight"), device)), down_b=_dev(g(lp + "fc2.bias"), device)))
+    embed, lm_head, tied = _embed_and_head(_dev(g(pre + "embed_tokens.weight"), device),
+                                           opt("lm_head.weight"), device)
+    return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied,
+                        pos_table=_dev(g(pre + "embed_positions.weight"), device),
                         final_norm_w=_dev(g(pre + "final_layer_norm.weight"), device),
                         final_norm_b=_dev(g(pre + "final_layer_norm.bias"), device),
-                        lm_head=embed if head is None else _dev(head, device), layers=layers)
+                        lm_head=lm_head, layers=layers)
 
 
 def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02) -> ModelWeights:
@@ -134,19 +153,22 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
     for _ in range(cfg.n_layers):
         if cfg.arch == "llama":
             layers.append(LayerTensors(
-                attn_norm_w=ones(H), qkv_w=rn(cfg.qkv_rows, H),
+                attn_norm_w=ones(H), qkv_w=_tile(rn(cfg.qkv_rows, H), ops.TILE_ROTARY, cfg.head_dim),
                 qkv_b=rn(cfg.qkv_rows) if cfg.qkv_bias else None,
-                o_w=rn(H, cfg.n_heads * cfg.head_dim), mlp_norm_w=ones(H), up_w=rn(2 * F, H),
-                down_w=rn(H, F)))
+                o_w=_tile(rn(H, cfg.n_heads * cfg.head_dim)), mlp_norm_w=ones(H),
+                up_w=_tile(rn(2 * F, H), ops.TILE_GATED), down_w=_tile(rn(H, F))))
         else:
             layers.append(LayerTensors(
-                attn_norm_w=ones(H), attn_norm_b=rn(H), qkv_w=rn(cfg.qkv_rows, H),
-                qkv_b=rn(cfg.qkv_rows), o_w=rn(H, cfg.n_heads * cfg.head_dim), o_b=rn(H),
-                mlp_norm_w=ones(H), mlp_norm_b=rn(H), up_w=rn(F, H), up_b=rn(F),
-                down_w=rn(H, F), down_b=rn(H)))
+                attn_norm_w=ones(H), attn_norm_b=rn(H),
+                qkv_w=_tile(rn(cfg.qkv_rows, H), ops.TILE_ROTARY, cfg.head_dim),
+                qkv_b=rn(cfg.qkv_rows), o_w=_tile(rn(H, cfg.n_heads * cfg.head_dim)), o_b=rn(H),
+                mlp_norm_w=ones(H), mlp_norm_b=rn(H), up_w=_tile(rn(F, H)), up_b=rn(F),
+                down_w=_tile(rn(H, F)), down_b=rn(H)))
     embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5)
-    lm_head = embed if cfg.tie_embeddings else rn(cfg.vocab, H)
-    w = ModelWeights(cfg=cfg, embed=embed, final_norm_w=ones(H), lm_head=lm_head, layers=layers)
+    embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(cfg.vocab, H),
+                                           device)
+    w = ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, final_norm_w=ones(H), lm_head=lm_head,
+                     layers=layers)
     if cfg.arch == "llama":
         w.rope_cs = rope_table(cfg, device)
     else:
