@@ -66,10 +66,14 @@ template <int EPI, int NORM>
 __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   constexpr bool GATED = EPI == SD_EPI_SILU_MUL;
   constexpr bool QKV = EPI == EPI_QKV_ROPE;
+  // Without a norm the activations need no staging: each lane loads its B-operand
+  // pieces straight from global memory (they sit in L2) beside the weight loads.
+  constexpr bool DIRECT = NORM == NORM_NONE;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int LDX = a.KC + kXPad;
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);                               // [M+1][LDX]
-  float* red = reinterpret_cast<float*>(smem_raw + (size_t)(a.M + 1) * LDX * 2);  // [2][waves][256]
+  float* red = reinterpret_cast<float*>(
+      smem_raw + (DIRECT ? 0 : (size_t)(a.M + 1) * LDX * 2));                     // [2][waves][256]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,13 +85,17 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   const bool single = n_chunks == 1;
 
   // zero row: B-operand lanes of token rows >= M read it
-  for (int c = tid * 8; c < LDX; c += kLinThreads * 8)
-    *reinterpret_cast<bf16x8*>(xs + (size_t)M * LDX + c) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  if (!DIRECT)
+    for (int c = tid * 8; c < LDX; c += kLinThreads * 8)
+      *reinterpret_cast<bf16x8*>(xs + (size_t)M * LDX + c) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   const int xc = lane & 15, xq = lane >> 4;
-  const bf16_t* xrow = xs + (size_t)(xc < M ? xc : M) * LDX + 8 * xq;
+  const bf16_t* xrow = xs + (size_t)(xc < M ? xc : M) * LDX + 8 * xq;           // LDS
+  const bf16_t* xglob = a.x + (size_t)(xc < M ? xc : 0) * a.ldx + 8 * xq;        // DIRECT
+  const bool x_live = xc < M;
 
-  // A fragments of this wave's next segment
+  // A fragments (and, DIRECT, B fragments) of this wave's next segment
   bf16x8 nxt[kSeg];
+  bf16x8 nxt_x[DIRECT ? kSeg : 1];
   auto load_seg = [&](int tile, int seg) {
     const bf16_t* p = a.W + ((size_t)tile * KS + (size_t)seg * kSeg) * 512 + lane * 8;
 #pragma unroll
@@ -96,6 +104,15 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
       if (seg * kSeg + j < KS)
         v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + (size_t)j * 512));
       nxt[j] = v;
+    }
+    if (DIRECT) {
+#pragma unroll
+      for (int j = 0; j < kSeg; ++j) {
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (seg * kSeg + j < KS && x_live)
+          v = *reinterpret_cast<const bf16x8*>(xglob + (size_t)(seg * kSeg + j) * 32);
+        nxt_x[DIRECT ? j : 0] = v;
+      }
     }
   };
   // Stages x[:, kc0 : kc0 + kc_len] (normalised if asked) into LDS; all threads.
@@ -155,8 +172,10 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
 #pragma unroll
     for (int j = 0; j < kSeg; ++j) nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
-  if (single) stage_x(0, a.K);
-  __syncthreads();
+  if (!DIRECT) {
+    if (single) stage_x(0, a.K);
+    __syncthreads();
+  }
 
   int parity = 0;
   for (; tile < a.n_tiles; tile += gridDim.x, parity ^= 1) {
@@ -164,7 +183,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     const int next_tile = tile + (int)gridDim.x;
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
       const int seg_lo = chunk * SC, seg_hi = min(seg_lo + SC, n_seg);
-      if (!single) {
+      if (!DIRECT && !single) {
         const int kc0 = seg_lo * kSeg * 32;
         stage_x(kc0, min(a.KC, a.K - kc0));
         __syncthreads();
@@ -175,18 +194,24 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         bf16x8 cur[kSeg];
 #pragma unroll
         for (int j = 0; j < kSeg; ++j) cur[j] = nxt[j];
+        bf16x8 cur_x[DIRECT ? kSeg : 1];
+        if (DIRECT) {
+#pragma unroll
+          for (int j = 0; j < kSeg; ++j) cur_x[DIRECT ? j : 0] = nxt_x[DIRECT ? j : 0];
+        }
         if (seg + kLinWaves < n_seg) load_seg(tile, seg + kLinWaves);
         else if (next_tile < a.n_tiles) load_seg(next_tile, wave);
         const bf16_t* xp = xrow + (size_t)(seg - seg_lo) * kSeg * 32;
 #pragma unroll
         for (int j = 0; j < kSeg; ++j) {
           if (seg * kSeg + j < KS) {
-            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xp + j * 32);
+            const bf16x8 b = DIRECT ? cur_x[DIRECT ? j : 0]
+                                    : *reinterpret_cast<const bf16x8*>(xp + j * 32);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], b, acc, 0, 0, 0);
           }
         }
       }
-      if (!single && chunk + 1 < n_chunks) __syncthreads();  // LDS is restaged next
+      if (!DIRECT && !single && chunk + 1 < n_chunks) __syncthreads();  // LDS is restaged next
     }
 
     // add the 8 wave tiles in wave order
@@ -292,8 +317,8 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
 constexpr size_t kXBudget = 80 * 1024;       // LDS bytes for staged x (chunked beyond this)
 constexpr size_t kXBudgetNorm = 128 * 1024;  // a fused norm needs whole rows
 
-size_t lin_lds_bytes(int M, int KC) {
-  return (size_t)(M + 1) * (KC + kXPad) * 2 + (size_t)2 * kLinWaves * 256 * 4;
+size_t lin_lds_bytes(int M, int KC, bool direct) {
+  return (direct ? 0 : (size_t)(M + 1) * (KC + kXPad) * 2) + (size_t)2 * kLinWaves * 256 * 4;
 }
 
 // Chooses the K-chunk (a whole number of 256-column segments); 0 if a fused
@@ -310,7 +335,7 @@ int choose_kc(int M, int K, bool norm) {
 
 template <int EPI, int NORM>
 int launch_one(LinArgs& a, hipStream_t st) {
-  const size_t lds = lin_lds_bytes(a.M, a.KC);
+  const size_t lds = lin_lds_bytes(a.M, a.KC, NORM == NORM_NONE);
   static bool attr_set = false;  // once per instantiation and process
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM>),
@@ -322,7 +347,7 @@ int launch_one(LinArgs& a, hipStream_t st) {
     attr_set = true;
   }
   // Up to two workgroups per CU (LDS permitting), each walking a strided tile list.
-  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+  const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // 16 waves per CU
   const int blocks = a.n_tiles < 256 * per_cu ? a.n_tiles : 256 * per_cu;
   hipLaunchKernelGGL((linear_kernel<EPI, NORM>), dim3(blocks), dim3(kLinThreads), lds, st, a);
   SD_CHECK_LAUNCH("sd_linear");
@@ -359,7 +384,7 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
              "sd_linear: residual epilogue without residual pointer");
   SD_REQUIRE(norm == NORM_NONE || a.norm_w, SD_ERR_INVALID, "sd_linear: fused norm without weight");
   if (a.M == 0) return SD_OK;
-  a.KC = choose_kc(a.M, a.K, norm != NORM_NONE);
+  a.KC = norm == NORM_NONE ? (a.K + 255) / 256 * 256 : choose_kc(a.M, a.K, true);
   SD_REQUIRE(a.KC > 0, SD_ERR_UNSUPPORTED,
              "sd_linear: fused norm needs (M+1)*K*2 <= %zu bytes of LDS (M=%d K=%d)", kXBudgetNorm,
              a.M, a.K);
