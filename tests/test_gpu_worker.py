@@ -1,0 +1,116 @@
+"""The plugin surface (SpecDecodeWorker / Top1Proposer / MQAScorer /
+RejectionSampler) on the GPU: same token streams as plain autoregressive
+decoding, component path == graph path, sampler module == oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampling
+from oracle.models import OracleConfig, random_state
+from tests.test_gpu_model import MODELS, _bf, _engine, _generate, _product
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(tw, dw, k, use_graph, max_num_seqs=3, temperature=0.0):
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
+    w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=dw, num_speculative_tokens=k,
+                                          max_num_seqs=max_num_seqs, max_model_len=200,
+                                          split_tokens=128, use_graph=use_graph,
+                                          temperature=temperature))
+    w.init_device()
+    w.load_model()
+    assert w.determine_num_available_blocks()[0] > 0
+    return w
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_worker_streams_equal_autoregressive(use_graph):
+    from vllm_omni_draft_amd.spec_decode_worker import ExecuteModelRequest, SequenceGroupMetadata
+    tcfg = MODELS["llama"]
+    dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    prompts = {"r0": [5, 9, 200, 31, 7], "r1": list(range(40, 73)), "r2": [3, 3, 3]}
+    want = {r: _generate(_engine(tw, None, 0), [p], 30)[0] for r, p in prompts.items()}
+    w = _worker(tw, dw, 3, use_graph)
+    got = {r: [] for r in prompts}
+    out = w.execute_model(ExecuteModelRequest(
+        [SequenceGroupMetadata(r, True, p) for r, p in list(prompts.items())[:2]]))
+    for r, toks in zip(out.req_ids, out.sampled_token_ids):
+        got[r].extend(toks)
+    step = 0
+    running = ["r0", "r1"]
+    while min(len(got[r]) for r in prompts) < 30:
+        groups = [SequenceGroupMetadata(r, False) for r in running]
+        finished = []
+        if step == 2:                       # a request joins mid-flight
+            groups.append(SequenceGroupMetadata("r2", True, prompts["r2"]))
+        if step == 6 and "r0" in running:   # and one leaves (its slot is reused)
+            running.remove("r0")
+            groups = [g for g in groups if g.request_id != "r0"]
+            finished = ["r0"]
+        out = w.execute_model(ExecuteModelRequest(groups, finished_requests_ids=finished))
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            assert 1 <= len(toks) <= 4
+            got[r].extend(toks)
+        if step == 2:
+            running.append("r2")
+        step += 1
+        if "r0" not in running:
+            got["r0"] = want["r0"]          # stopped early on purpose
+    for r in prompts:
+        assert got[r][:30] == want[r][:30], r
+    m = w.metrics.maybe_collect(force=True)
+    assert m.num_spec_tokens == 3 and m.emitted_tokens == m.accepted_tokens + m.draft_tokens // 3
+
+
+def test_proposer_and_scorer_views():
+    tcfg = MODELS["llama"]
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    w = _worker(tw, tw, 3, use_graph=False, temperature=1.0)
+    eng = w.engine
+    eng.add_request(0, [1, 2, 3, 4])
+    eng.add_request(1, [9, 8, 7])
+    eng.prepare_step()
+    props = w.proposer.get_spec_proposals(None, frozenset())
+    assert props.proposal_token_ids.shape == (2, 3) and props.proposal_probs.shape == (2, 3, tcfg.vocab)
+    assert props.proposal_lens.tolist() == [3, 3]
+    scores = w.scorer.score_proposals(None, props)
+    assert scores.probs.shape == (2, 4, tcfg.vocab) and scores.token_ids.shape == (2, 4)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(props.proposal_probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-4)
+    np.testing.assert_allclose(scores.probs.sum(-1).cpu().numpy(), 1.0, rtol=1e-4)
+    # draft == target and same position => identical distributions row by row
+    np.testing.assert_allclose(props.proposal_probs[:, 0].cpu().numpy(), scores.probs[:, 0].cpu().numpy(),
+                               rtol=1e-5, atol=1e-8)
+    w._verify_tokens(props, scores)
+    emitted = eng.finish_step()
+    assert all(1 <= len(t) <= 4 for t in emitted)
+
+
+def test_rejection_sampler_module():
+    from vllm_omni_draft_amd.spec_decode_worker import RejectionSampler
+    rng = np.random.default_rng(3)
+    B, k, V = 5, 4, 512
+    p = sampling.softmax_rows(rng.standard_normal((B * (k + 1), V)).astype(np.float32) * 2).reshape(B, k + 1, V)
+    q = sampling.softmax_rows(rng.standard_normal((B * k, V)).astype(np.float32) * 2).reshape(B, k, V)
+    ids = np.array([[sampling.inverse_cdf(q[b, i], rng.random()) for i in range(k)] for b in range(B)])
+    bonus = rng.integers(0, V, size=(B, 1))
+    ua, ur = rng.random((B, k), dtype=np.float32), rng.random((B, k + 1), dtype=np.float32)
+    rs = RejectionSampler(seed=1)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    out = rs(cu(p), cu(bonus), cu(q), cu(ids), uniforms=(cu(ua), cu(ur)))
+    ref, cnt = sampling.rejection_sample(p, bonus, q, ids, ua, ur)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    rs.sync_counters()
+    assert [rs.num_accepted_tokens, rs.num_emitted_tokens, rs.num_draft_tokens] == cnt.tolist()
+    # generator-driven call: valid tokens, prefix property, seeded rows reproducible
+    g = {2: torch.Generator(device="cuda").manual_seed(7)}
+    a = rs(cu(p), cu(bonus), cu(q), cu(ids), seeded_seqs=g).cpu().numpy()
+    g = {2: torch.Generator(device="cuda").manual_seed(7)}
+    b = rs(cu(p), cu(bonus), cu(q), cu(ids), seeded_seqs=g).cpu().numpy()
+    np.testing.assert_array_equal(a[2], b[2])
+    for row, x in zip(a, ids):
+        n = int((row >= 0).sum())
+        assert 1 <= n <= k + 1 and (row[:n - 1] == x[:n - 1]).all() and (row[n:] == -1).all()

@@ -1,0 +1,161 @@
+"""Host-side logic that needs no GPU: page allocation, configuration, metrics,
+the worker's request bookkeeping (with a stand-in engine), and the data-parallel
+helpers under a 2-process gloo group."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from vllm_omni_draft_amd import config, parallel
+from vllm_omni_draft_amd.kv_cache import OutOfPages, PageAllocator
+from vllm_omni_draft_amd.metrics import AsyncMetricsCollector, SpecDecodeWorkerMetrics
+
+
+def test_page_allocator():
+    a = PageAllocator(4)
+    got = [a.alloc() for _ in range(4)]
+    assert sorted(got) == [0, 1, 2, 3] and a.num_free == 0
+    with pytest.raises(OutOfPages):
+        a.alloc()
+    a.free(got[:2])
+    assert a.num_free == 2 and a.alloc() in got[:2]
+
+
+def test_config_presets_and_overrides():
+    c = config.preset("llama-3-8b")
+    assert (c.n_layers, c.hidden, c.n_heads, c.n_kv_heads, c.head_dim, c.ffn, c.vocab) == \
+        (32, 4096, 32, 8, 128, 14336, 128256)
+    assert abs(c.param_bytes() / 1e9 - 15.0) < 0.2          # streamed bf16 bytes per pass
+    assert c.kv_bytes_per_token() == 128 * 1024              # 128 KiB per token
+    d = config.preset("llama-3.2-1b")
+    assert d.tie_embeddings and d.rope_scaling["rope_type"] == "llama3"
+    assert d.kv_bytes_per_token() == 32 * 1024
+    with pytest.raises(ValueError):
+        config.create_model_config(None, not_a_field=1)      # unknown keys are rejected
+    with pytest.raises(ValueError):
+        config.create_model_config(None, head_dim=80)
+    hf = {"model_type": "qwen2", "num_hidden_layers": 24, "hidden_size": 896, "num_attention_heads": 14,
+          "num_key_value_heads": 2, "intermediate_size": 4864, "vocab_size": 151936,
+          "rms_norm_eps": 1e-6, "rope_theta": 1e6, "tie_word_embeddings": True}
+    q = config.from_hf_config(hf)
+    assert q.qkv_bias and q.head_dim == 64 and q.tie_embeddings
+
+
+def test_metrics_definitions():
+    m = SpecDecodeWorkerMetrics.from_counts(accepted=27, emitted=37, draft=50, k=5)
+    assert m.draft_acceptance_rate == 27 / 50
+    assert m.accept_len == 2.7 and abs(m.system_efficiency - 37 / 60) < 1e-12
+
+    class Eng:
+        k = 5
+        def metrics(self):
+            return {"accepted": 5, "emitted": 6, "draft": 5}
+    now = [0.0]
+    col = AsyncMetricsCollector(Eng(), collect_interval_s=5.0, timer=lambda: now[0])
+    assert col.maybe_collect() is None
+    now[0] = 6.0
+    assert col.maybe_collect().accept_len == 5.0
+    assert col.maybe_collect() is None and col.maybe_collect(force=True) is not None
+
+
+class FakeEngine:
+    """Emits token 100*slot_owner + step for every running sequence; records calls."""
+
+    class _Cfg:
+        max_batch = 3
+        use_graph = True
+
+    def __init__(self):
+        self.cfg = self._Cfg()
+        self.k = 3
+        self.active = 0
+        self.owners = []
+        self.steps = 0
+
+    def add_request(self, slot, prompt):
+        assert slot == self.active
+        self.owners.append(prompt[0])
+        self.active += 1
+        return prompt[0] * 100
+
+    def step(self):
+        self.steps += 1
+        return [[o * 100 + self.steps] * (1 + i % 2) for i, o in enumerate(self.owners)]
+
+    def remove_request(self, slot):
+        last = self.active - 1
+        if slot != last:
+            self.owners[slot] = self.owners[last]
+        self.owners.pop()
+        self.active = last
+
+    def metrics(self):
+        return {"accepted": 0, "emitted": 0, "draft": 0}
+
+
+def test_worker_request_bookkeeping():
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeWorker)
+    eng = FakeEngine()
+    w = SpecDecodeWorker(vllm_config=None, engine=eng)
+    P = lambda rid, tok: SequenceGroupMetadata(rid, True, [tok, 1, 2])
+    R = lambda rid: SequenceGroupMetadata(rid, False)
+    out = w.execute_model(ExecuteModelRequest([P("a", 1), P("b", 2)]))
+    assert out.sampled_token_ids == [[100], [200]] and out.req_ids == ["a", "b"]
+    # running sequences step; a new prompt joins in the same call
+    out = w.execute_model(ExecuteModelRequest([R("b"), R("a"), P("c", 3)]))
+    assert out.sampled_token_ids == [[201, 201], [101], [300]]
+    assert out.req_id_to_index == {"b": 0, "a": 1, "c": 2}
+    # finishing the first slot moves the last sequence into it
+    out = w.execute_model(ExecuteModelRequest([R("c"), R("b")], finished_requests_ids=["a"]))
+    assert eng.owners == [3, 2] and out.sampled_token_ids == [[302], [202, 202]]
+    with pytest.raises(KeyError):
+        w.execute_model(ExecuteModelRequest([R("zzz"), R("b"), R("c")]))
+    with pytest.raises(ValueError):
+        w.execute_model(ExecuteModelRequest([R("b")]))            # a running request is missing
+    w.execute_model(ExecuteModelRequest([R("b"), R("c"), P("d", 4)]))
+    with pytest.raises(RuntimeError):
+        w.execute_model(ExecuteModelRequest([R("b"), R("c"), R("d"), P("e", 5)]))  # no free slot
+
+
+def test_shard_requests():
+    reqs = list(range(10))
+    parts = [parallel.shard_requests(reqs, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == reqs and parts[1] == [1, 5, 9]
+    assert all(parallel.owner_of(i, 4) == r for r in range(4) for i in parts[r])
+    with pytest.raises(ValueError):
+        parallel.shard_requests(reqs, 4, 4)
+    assert parallel.aggregate_throughput(10, 2.0) == (10.0, 2.0)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = parallel.init_from_env("gloo")
+    mine = parallel.shard_requests([[i, i + 1] for i in range(5)], r, w)
+    streams = [[p[0] * 10 + j for j in range(3)] for p in mine]      # stand-in generation
+    tokens = sum(len(s) for s in streams)
+    total, secs = parallel.aggregate_throughput(tokens, 1.0 + rank)
+    gathered = parallel.gather_streams(streams, w)
+    dist.barrier()
+    q.put((rank, total, secs, gathered))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_helpers_world_size_2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, total, secs, gathered in res:
+        assert total == 15.0 and secs == 2.0                     # sum of tokens, max of time
+        assert gathered == [[[0, 1, 2], [20, 21, 22], [40, 41, 42]], [[10, 11, 12], [30, 31, 32]]]

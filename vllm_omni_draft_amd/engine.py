@@ -197,19 +197,32 @@ class SpecEngine:
                           tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self.max_ctx)
 
     def _enqueue_step(self) -> None:
+        """One whole step: propose (k draft passes), score (one target pass),
+        accept (verification + state update).  Enqueues only."""
+        if self.k == 0:
+            self._enqueue_ar_step()
+            return
+        self._enqueue_propose()
+        self._enqueue_score()
+        self._enqueue_accept()
+
+    def _enqueue_ar_step(self) -> None:
+        B = self.active
+        self._forward(self.target, self.t_kv, self.tok_buf, 2, 1, self.seq_lens, -1, B, 1,
+                      self.t_logits)
+        if self.sampling:
+            ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V))
+            ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp)
+        else:
+            ops.argmax_rows(self.t_logits[:B], out=self.ids_tmp)
+        ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf, self.gen_tokens,
+                          self.gen_counts, 0)
+
+    def _enqueue_propose(self) -> None:
+        """k draft passes; proposals land in tok_buf[:, 2:], their probability
+        rows (sampling mode) in d_probs."""
         B, k = self.active, self.k
         stride = k + 2
-        if k == 0:
-            self._forward(self.target, self.t_kv, self.tok_buf, stride, 1, self.seq_lens, -1, B, 1,
-                          self.t_logits)
-            if self.sampling:
-                ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V))
-                ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp)
-            else:
-                ops.argmax_rows(self.t_logits[:B], out=self.ids_tmp)
-            ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf, self.gen_tokens,
-                              self.gen_counts, 0)
-            return
         for i in range(k):
             if i == 0:
                 self._forward(self.draft, self.d_kv, self.tok_buf, stride, 0, self.seq_lens, -2, B, 2,
@@ -229,25 +242,57 @@ class SpecEngine:
                 ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
             ops.store_proposal(self.ids_tmp, self.tok_buf, k, i, self.seq_lens, self.truth,
                                self.accept_prob, self.accept_seed)
-        self._forward(self.target, self.t_kv, self.tok_buf, stride, 1, self.seq_lens, -1, B, k + 1,
-                      self.t_logits)
         ops.gather_proposals(self.tok_buf, self.draft_ids, k)
+
+    def _enqueue_score(self) -> None:
+        """One target pass over {last token, k proposals} of every sequence:
+        t_logits [B*(k+1), V], plus target_ids (greedy) or t_probs / bonus_ids."""
+        B, k = self.active, self.k
+        self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, k + 1,
+                      self.t_logits)
         rows = self.t_logits[:B * (k + 1)]
         if self.sampling:
             ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V))
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
                             out=self.bonus_ids, row_offset=k, row_step=k + 1)
+        else:
+            ops.argmax_rows(rows, out=self.target_ids.view(-1))
+
+    def _enqueue_accept(self) -> None:
+        """Acceptance (rejection sampling or greedy match) and the state update."""
+        B, k = self.active, self.k
+        if self.sampling:
             _lib.check(_lib.load().sd_rejection_sample(
                 self.t_probs.data_ptr(), self.bonus_ids.data_ptr(), self.d_probs.data_ptr(),
                 self.draft_ids.data_ptr(), self.u_accept.data_ptr(), self.u_recover.data_ptr(),
                 None, self.out_ids.data_ptr(), self.counters.data_ptr(), B, k, self.V,
                 torch.cuda.current_stream().cuda_stream), "sd_rejection_sample")
         else:
-            ops.argmax_rows(rows, out=self.target_ids.view(-1))
             ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], None, self.counters,
                               out=self.out_ids)
         ops.advance_state(self.out_ids, self.seq_lens, self.tok_buf, self.gen_tokens,
                           self.gen_counts, k)
+
+    def remove_request(self, slot: int) -> None:
+        """Frees batch slot `slot`; the last active sequence moves into it so
+        that active sequences stay contiguous (synchronises)."""
+        with torch.cuda.stream(self.stream):
+            last = self.active - 1
+            if not 0 <= slot <= last:
+                raise ValueError(f"slot {slot} is not active")
+            for kv in (self.t_kv, self.d_kv):
+                if kv is None:
+                    continue
+                kv.release(slot)
+                if slot != last:
+                    kv.move_slot(last, slot)
+            if slot != last:
+                for t in (self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts):
+                    t[slot].copy_(t[last])
+                self.host_lens[slot], self.host_gen[slot] = self.host_lens[last], self.host_gen[last]
+            self.host_lens[last] = self.host_gen[last] = 0
+            self.active = last
+            torch.cuda.synchronize(self.device)
 
     # ------------------------------------------------------------------ stepping
     def _refresh_uniforms(self) -> None:
@@ -261,10 +306,14 @@ class SpecEngine:
         with torch.cuda.stream(self.stream):
             return self._step(sync)
 
-    def _step(self, sync: bool) -> Optional[List[List[int]]]:
+    def prepare_step(self) -> None:
+        """Host work that must precede a step's kernels: cache pages for the
+        tokens the step may write, fresh uniforms (sampling)."""
+        with torch.cuda.stream(self.stream):
+            self._prepare_step()
+
+    def _prepare_step(self) -> None:
         B, k = self.active, self.k
-        if B == 0:
-            return [] if sync else None
         for b in range(B):
             need = self.host_lens[b] + k + 2
             if need > self.max_ctx:
@@ -274,6 +323,20 @@ class SpecEngine:
                 self.d_kv.ensure_capacity(b, need)
         if self.sampling:
             self._refresh_uniforms()
+
+    def finish_step(self) -> List[List[int]]:
+        """After a step's kernels were enqueued piecewise: reads the emitted
+        tokens back (synchronises)."""
+        with torch.cuda.stream(self.stream):
+            for b in range(self.active):
+                self.host_lens[b] += self.k + 1
+            return self._read_back()
+
+    def _step(self, sync: bool) -> Optional[List[List[int]]]:
+        B, k = self.active, self.k
+        if B == 0:
+            return [] if sync else None
+        self._prepare_step()
         stream = torch.cuda.current_stream().cuda_stream
         lib = _lib.load()
         if self.cfg.use_graph:

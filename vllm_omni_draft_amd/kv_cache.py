@@ -79,6 +79,14 @@ class PagedKVCache:
         self.allocator.free(self._host_tables[slot])
         self._host_tables[slot] = []
 
+    def move_slot(self, src: int, dst: int) -> None:
+        """Batch slot `dst` (empty) takes over the pages of slot `src`."""
+        if self._host_tables[dst]:
+            raise ValueError(f"slot {dst} still owns pages")
+        self._host_tables[dst] = self._host_tables[src]
+        self._host_tables[src] = []
+        self.block_tables[dst].copy_(self.block_tables[src])
+
     @staticmethod
     def pages_for(cfg: ModelConfig, max_batch: int, max_seq_len: int) -> int:
         return max_batch * ((max_seq_len + PAGE - 1) // PAGE)

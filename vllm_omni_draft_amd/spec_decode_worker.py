@@ -1,0 +1,342 @@
+"""The speculative-decoding plugin surface: SpecDecodeWorker, Proposer, Scorer,
+RejectionSampler and their data carriers.
+
+Names and call shapes follow vLLM's V0 `vllm.spec_decode` package (the
+surface the task names); that package is not part of the reference tree
+(/root/reference/pyproject.toml:31 only depends on `vllm`), so the shapes are
+restated here.  The worker plugs into an engine the way the reference's custom
+workers do: an executor sets `parallel_config.worker_cls` to this class
+(/root/reference/src/qwen_image_gen/executor.py:14-26), the engine constructs
+it with `(vllm_config, local_rank, rank, distributed_init_method,
+is_driver_worker)` (/root/reference/src/qwen_image_gen/worker.py:19-29), calls
+`load_model()` and then `execute_model(...)` once per step
+(/root/reference/src/doc/engine_core.md:117-122).  `execute_model` returns one
+variable-length token list per request — `ModelRunnerOutput.sampled_token_ids`
+(/root/reference/src/doc/engine_core.md:323-324).
+
+Everything heavy happens in SpecEngine (engine.py) on the device; these classes
+only sequence it and hand out views of its buffers.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, field
+from typing import Dict, FrozenSet, List, Optional, Sequence, Set
+
+import torch
+from torch import nn
+
+from . import ops
+from .engine import EngineConfig, SpecEngine
+from .metrics import AsyncMetricsCollector, SpecDecodeWorkerMetrics
+from .weights import ModelWeights
+
+
+# --------------------------------------------------------------------------- carriers
+@dataclass
+class SamplingParams:
+    temperature: float = 0.0
+    max_tokens: int = 16
+    seed: Optional[int] = None
+    ignore_eos: bool = True
+
+
+@dataclass
+class SequenceGroupMetadata:
+    """One request in a step: a new prompt (is_prompt) or a running sequence."""
+    request_id: str
+    is_prompt: bool
+    prompt_token_ids: List[int] = field(default_factory=list)
+    sampling_params: SamplingParams = field(default_factory=SamplingParams)
+
+
+@dataclass
+class ExecuteModelRequest:
+    seq_group_metadata_list: List[SequenceGroupMetadata]
+    num_lookahead_slots: int = 0
+    finished_requests_ids: List[str] = field(default_factory=list)
+
+
+@dataclass
+class SpeculativeProposals:
+    """Draft proposals of one step (device tensors; views of engine buffers)."""
+    proposal_token_ids: torch.Tensor            # [B, k] int64
+    proposal_probs: Optional[torch.Tensor]      # [B, k, V] float32 (None under greedy decoding)
+    proposal_lens: torch.Tensor                 # [B] int32
+    no_proposals: bool = False
+
+
+@dataclass
+class SpeculativeScores:
+    """Target scores of the k proposals plus the bonus position."""
+    probs: Optional[torch.Tensor]               # [B, k+1, V] float32 (None under greedy decoding)
+    token_ids: torch.Tensor                     # [B, k+1] int64: target argmax / bonus sample
+    logits: torch.Tensor                        # [B, k+1, V] float32
+    hidden_states: Optional[torch.Tensor] = None
+
+
+@dataclass
+class ModelRunnerOutput:
+    req_ids: List[str]
+    req_id_to_index: Dict[str, int]
+    sampled_token_ids: List[List[int]]
+    spec_decode_metrics: Optional[SpecDecodeWorkerMetrics] = None
+
+
+# --------------------------------------------------------------------------- components
+class SpeculativeProposer(ABC):
+    @abstractmethod
+    def get_spec_proposals(self, execute_model_req: Optional[ExecuteModelRequest],
+                           seq_ids_with_bonus_token_in_last_step: Set[int]) -> SpeculativeProposals:
+        ...
+
+
+class SpeculativeScorer(ABC):
+    @abstractmethod
+    def score_proposals(self, execute_model_req: Optional[ExecuteModelRequest],
+                        proposals: SpeculativeProposals) -> SpeculativeScores:
+        ...
+
+
+class MultiStepWorker:
+    """The draft model: k sequential single-token passes with on-device
+    sampling and KV append, no host synchronisation in between."""
+
+    def __init__(self, engine: SpecEngine):
+        self.engine = engine
+
+    def sampler_output(self, execute_model_req: Optional[ExecuteModelRequest], sample_len: int,
+                       seq_ids_with_bonus_token_in_last_step: Set[int]) -> None:
+        if sample_len != self.engine.k:
+            raise ValueError(f"this engine proposes k={self.engine.k} tokens, asked for {sample_len}")
+        # A sequence whose previous step accepted every proposal lacks the draft KV of
+        # its last proposal.  The first draft pass always feeds the last two tokens,
+        # so no per-sequence expansion is needed and the set can be ignored.
+        with torch.cuda.stream(self.engine.stream):
+            self.engine._enqueue_propose()
+
+
+class Top1Proposer(SpeculativeProposer):
+    """Proposes the draft model's single best (or sampled) continuation."""
+
+    def __init__(self, worker: MultiStepWorker):
+        self.worker = worker
+
+    def get_spec_proposals(self, execute_model_req=None,
+                           seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
+        eng = self.worker.engine
+        B, k = eng.active, eng.k
+        self.worker.sampler_output(execute_model_req, k, set(seq_ids_with_bonus_token_in_last_step))
+        lens = torch.full((B,), k, dtype=torch.int32, device=eng.device)
+        return SpeculativeProposals(
+            proposal_token_ids=eng.draft_ids[:B],
+            proposal_probs=eng.d_probs[:B] if eng.sampling else None,
+            proposal_lens=lens, no_proposals=(B == 0))
+
+
+class MQAScorer(SpeculativeScorer):
+    """Scores all k+1 positions of every sequence in ONE target pass: the k+1
+    query tokens of a sequence share each KV page read (no batch expansion)."""
+
+    def __init__(self, engine: SpecEngine):
+        self.engine = engine
+
+    def score_proposals(self, execute_model_req=None, proposals=None) -> SpeculativeScores:
+        eng = self.engine
+        B, k = eng.active, eng.k
+        with torch.cuda.stream(eng.stream):
+            eng._enqueue_score()
+        logits = eng.t_logits[:B * (k + 1)].view(B, k + 1, eng.V)
+        if eng.sampling:
+            token_ids = eng.target_ids[:B]
+            with torch.cuda.stream(eng.stream):
+                ops.argmax_rows(eng.t_logits[:B * (k + 1)], out=eng.target_ids.view(-1))
+                token_ids[:, k] = eng.bonus_ids[:B]
+            return SpeculativeScores(probs=eng.t_probs[:B], token_ids=token_ids, logits=logits)
+        return SpeculativeScores(probs=None, token_ids=eng.target_ids[:B], logits=logits)
+
+
+# Same results as upstream's batch-expansion scorer, without expanding the batch.
+BatchExpansionTop1Scorer = MQAScorer
+
+
+class RejectionSampler(nn.Module):
+    """Modified rejection sampling (Leviathan et al. 2023, Alg. 1) as one HIP
+    kernel per batch.  Call shape of vLLM's `RejectionSampler.forward`; uniforms
+    come from a device generator (per-sequence generators via `seeded_seqs`)."""
+
+    def __init__(self, seed: int = 0):
+        super().__init__()
+        self._seed = seed
+        self._gen: Optional[torch.Generator] = None
+        self.num_accepted_tokens = 0
+        self.num_emitted_tokens = 0
+        self.num_draft_tokens = 0
+        self._counters: Optional[torch.Tensor] = None
+
+    def _uniform(self, shape, device, seeded_seqs, row_of_seq):
+        if self._gen is None:
+            self._gen = torch.Generator(device=device).manual_seed(self._seed)
+        u = torch.rand(shape, generator=self._gen, device=device)
+        for b, g in (seeded_seqs or {}).items():
+            u[row_of_seq(b)] = torch.rand(shape[1:], generator=g, device=device)
+        return u
+
+    def forward(self, target_with_bonus_probs: torch.Tensor, bonus_token_ids: torch.Tensor,
+                draft_probs: torch.Tensor, draft_token_ids: torch.Tensor,
+                seeded_seqs: Optional[Dict[int, torch.Generator]] = None,
+                uniforms: Optional[tuple] = None) -> torch.Tensor:
+        """Returns [B, k+1] int64: the accepted prefix, one recovered / bonus
+        token, then -1.  `uniforms=(u_accept [B,k], u_recover [B,k+1])` makes the
+        call deterministic (tests)."""
+        B, k1, V = target_with_bonus_probs.shape
+        k = k1 - 1
+        dev = target_with_bonus_probs.device
+        if uniforms is None:
+            ident = lambda b: b
+            uniforms = (self._uniform((B, k), dev, seeded_seqs, ident),
+                        self._uniform((B, k + 1), dev, seeded_seqs, ident))
+        if self._counters is None or self._counters.device != dev:
+            self._counters = torch.zeros(3, dtype=torch.int64, device=dev)
+        out = ops.rejection_sample(target_with_bonus_probs.contiguous(), bonus_token_ids.contiguous(),
+                                   draft_probs.contiguous(), draft_token_ids.contiguous(),
+                                   uniforms[0].contiguous(), uniforms[1].contiguous(), None,
+                                   self._counters)
+        return out
+
+    def sync_counters(self) -> None:
+        if self._counters is not None:
+            a, e, d = self._counters.tolist()
+            self.num_accepted_tokens, self.num_emitted_tokens, self.num_draft_tokens = a, e, d
+
+
+# --------------------------------------------------------------------------- worker
+@dataclass
+class SpecDecodeConfig:
+    target: ModelWeights
+    draft: ModelWeights
+    num_speculative_tokens: int = 5
+    max_num_seqs: int = 1
+    max_model_len: int = 2048
+    temperature: float = 0.0
+    seed: int = 0
+    split_tokens: int = 256
+    use_graph: bool = True
+
+
+class SpecDecodeWorker:
+    """Worker that runs draft-k / verify / accept for every running sequence.
+
+    Construction mirrors a vLLM worker; `vllm_config` may be a SpecDecodeConfig
+    (stand-alone use) or any object with a `spec_decode_config` attribute holding
+    one (when an engine builds the worker from its own config object)."""
+
+    def __init__(self, vllm_config, local_rank: int = 0, rank: int = 0,
+                 distributed_init_method: Optional[str] = None, is_driver_worker: bool = True,
+                 engine: Optional[SpecEngine] = None):
+        cfg = getattr(vllm_config, "spec_decode_config", vllm_config)
+        self.config: SpecDecodeConfig = cfg
+        self.local_rank, self.rank = local_rank, rank
+        self.distributed_init_method = distributed_init_method
+        self.is_driver_worker = is_driver_worker
+        self.engine: Optional[SpecEngine] = engine
+        self.proposer_worker: Optional[MultiStepWorker] = None
+        self.proposer: Optional[SpeculativeProposer] = None
+        self.scorer: Optional[SpeculativeScorer] = None
+        self.metrics: Optional[AsyncMetricsCollector] = None
+        self._slot_of: Dict[str, int] = {}
+        self._req_at: List[str] = []
+        if engine is not None:
+            self._wire()
+
+    # -- life cycle (vLLM worker protocol) ----------------------------------------
+    def init_device(self) -> None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("SpecDecodeWorker needs a GPU: there is no CPU path")
+        torch.cuda.set_device(self.local_rank)
+
+    def load_model(self) -> None:
+        c = self.config
+        self.engine = SpecEngine(c.target, c.draft, EngineConfig(
+            k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
+            split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
+            use_graph=c.use_graph))
+        self._wire()
+
+    def _wire(self) -> None:
+        self.proposer_worker = MultiStepWorker(self.engine)
+        self.proposer = Top1Proposer(self.proposer_worker)
+        self.scorer = MQAScorer(self.engine)
+        self.metrics = AsyncMetricsCollector(self.engine)
+
+    def determine_num_available_blocks(self):
+        """(gpu_blocks, cpu_blocks): pages each model's cache holds; caches are
+        sized at construction for max_num_seqs x max_model_len."""
+        return self.engine.t_kv.num_pages, 0
+
+    def initialize_cache(self, num_gpu_blocks: int, num_cpu_blocks: int = 0) -> None:
+        if num_gpu_blocks > self.engine.t_kv.num_pages:
+            raise ValueError("the cache was sized at load time; cannot grow it")
+
+    # -- one step -----------------------------------------------------------------
+    def execute_model(self, execute_model_req: ExecuteModelRequest) -> ModelRunnerOutput:
+        """Runs one step: running sequences get a speculative step (1..k+1 tokens
+        each), new prompts are prefilled in both models and get their first token."""
+        eng = self.engine
+        for rid in execute_model_req.finished_requests_ids:
+            self._finish(rid)
+        running = [g for g in execute_model_req.seq_group_metadata_list if not g.is_prompt]
+        prompts = [g for g in execute_model_req.seq_group_metadata_list if g.is_prompt]
+        unknown = [g.request_id for g in running if g.request_id not in self._slot_of]
+        if unknown:
+            raise KeyError(f"requests {unknown} are not running on this worker")
+        if len(running) != eng.active:
+            raise ValueError(f"{eng.active} sequences are running but the step names {len(running)}: "
+                             "list every running request or finish it")
+        out: Dict[str, List[int]] = {}
+        if running:
+            emitted = self._run_speculative_decoding_step(execute_model_req)
+            for slot, toks in enumerate(emitted):
+                out[self._req_at[slot]] = toks
+        for g in prompts:
+            if g.request_id in self._slot_of:
+                raise KeyError(f"request {g.request_id} is already running")
+            if eng.active >= eng.cfg.max_batch:
+                raise RuntimeError("no free sequence slot (max_num_seqs reached)")
+            slot = eng.active
+            first = eng.add_request(slot, g.prompt_token_ids)
+            self._slot_of[g.request_id] = slot
+            self._req_at.append(g.request_id)
+            out[g.request_id] = [first]
+        ids = [g.request_id for g in execute_model_req.seq_group_metadata_list]
+        return ModelRunnerOutput(
+            req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
+            sampled_token_ids=[out[r] for r in ids],
+            spec_decode_metrics=self.metrics.maybe_collect() if self.metrics else None)
+
+    def _run_speculative_decoding_step(self, req: ExecuteModelRequest) -> List[List[int]]:
+        """propose -> score -> verify, as one replayed graph when enabled."""
+        eng = self.engine
+        if eng.cfg.use_graph:
+            return eng.step()
+        eng.prepare_step()
+        proposals = self.proposer.get_spec_proposals(req, frozenset())
+        scores = self.scorer.score_proposals(req, proposals)
+        self._verify_tokens(proposals, scores)
+        return eng.finish_step()
+
+    def _verify_tokens(self, proposals: SpeculativeProposals, scores: SpeculativeScores) -> None:
+        with torch.cuda.stream(self.engine.stream):
+            self.engine._enqueue_accept()
+
+    def _finish(self, request_id: str) -> None:
+        slot = self._slot_of.pop(request_id, None)
+        if slot is None:
+            return
+        last = len(self._req_at) - 1
+        self.engine.remove_request(slot)
+        if slot != last:
+            moved = self._req_at[last]
+            self._req_at[slot] = moved
+            self._slot_of[moved] = slot
+        self._req_at.pop()
