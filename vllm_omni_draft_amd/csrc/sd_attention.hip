@@ -44,7 +44,7 @@ struct AttnArgs {
   float* part_ml;  // [B, Hkv, n_splits, MT*32, 2]
 };
 
-template <int D, int MT>
+template <int D, int MT, int NBUF>
 __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
   constexpr int KS = D / 16;  // k-steps of the K.Q^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
@@ -54,7 +54,11 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
   float* sm_m = sm_o + 4 * MT * D * LDM;                      // [4][MT][32]
   float* sm_l = sm_m + 4 * MT * 32;                           // [4][MT][32]
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // The wave index is made provably uniform so that block-table lookups are scalar loads:
+  // a vector load there would sit behind the K/V loads in the in-order load counter and
+  // force the whole ring to drain before the next address is known.
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
   const int G = a.Hq / a.Hkv;
@@ -98,69 +102,103 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
   }
 
   const size_t page_elems = (size_t)D * 16;
-  for (int tile = (split_start >> 5) + w; tile * 32 < split_end; tile += 4) {
-    const int key0 = tile * 32;
-    const int pgA = min(tile * 2, last_page), pgB = min(tile * 2 + 1, last_page);
-    const int blkA = bt[pgA], blkB = bt[pgB];
-    // K fragments (A operand): lane (r, h) holds K[key0 + r][16s + 8h .. +8],
-    // which is chunk 2s+h, token r&15 of page r>>4.
-    const bf16_t* kpage = a.kc + ((size_t)((r >> 4) ? blkB : blkA) * a.Hkv + kvh) * page_elems;
-    bf16x8 kf[KS];
+  // K fragments (A operand): lane (r, h) holds K[key0 + r][16s + 8h .. +8], which is
+  // chunk 2s+h, token r&15 of page r>>4.  V^T fragments (A operand): lane (r, h) holds
+  // row d = 32dt + r, slots 8h..8h+7 of page s.
+  //
+  // The wave keeps NBUF tiles in registers and reloads each buffer in place as soon as
+  // its last MFMA has consumed it, so nearly all buffer registers are loads in flight:
+  // the stream is bound by bytes in flight per CU, not by arithmetic.  Loads past the
+  // split are redirected to one 16-byte address (cheap, never consumed), which keeps the
+  // load sequence branch-free and the wait counts exact.
+  bf16x8 kf[NBUF][KS], vf[NBUF][2][DT];
+  const bf16x8* dummy = reinterpret_cast<const bf16x8*>(a.kc);
+  auto load_k = [&](bf16x8(&dst)[KS], int tile) {
+    const bool in = tile * 32 < split_end;
+    const int blkA = bt[min(tile * 2, last_page)], blkB = bt[min(tile * 2 + 1, last_page)];
+    const int blk = (r >> 4) ? blkB : blkA;
+    const bf16_t* kpage = a.kc + ((size_t)blk * a.Hkv + kvh) * page_elems;
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-      kf[s] = *reinterpret_cast<const bf16x8*>(kpage + ((2 * s + h) * 16 + (r & 15)) * 8);
-    // V^T fragments (A operand): lane (r, h) holds row d = 32dt + r, slots 8h..8h+7
-    // of page s.
-    const bf16_t* vpage[2] = {a.vc + ((size_t)blkA * a.Hkv + kvh) * page_elems,
-                              a.vc + ((size_t)blkB * a.Hkv + kvh) * page_elems};
-    bf16x8 vf[2][DT];
+    for (int s = 0; s < KS; ++s) {
+      const bf16x8* src =
+          reinterpret_cast<const bf16x8*>(kpage + ((2 * s + h) * 16 + (r & 15)) * 8);
+      dst[s] = __builtin_nontemporal_load(in ? src : dummy);
+    }
+  };
+  auto load_v = [&](bf16x8(&dst)[2][DT], int tile) {
+    const bool in = tile * 32 < split_end;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-        vf[s][dt] = *reinterpret_cast<const bf16x8*>(vpage[s] + (dt * 32 + r) * 16 + 8 * h);
-
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      f32x16 s_acc;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-        s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[s], qf[mt][s], s_acc, 0, 0, 0);
-
-      // Online softmax of row m = 32mt + r over this lane's 16 keys.
-      float sv[16];
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        sv[i] = key < kvlen_m[mt] ? s_acc[i] * a.scale_log2 : -INFINITY;
-        tmax = fmaxf(tmax, sv[i]);
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run[mt], tmax);
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_use);
-      float psum = 0.f;
-      bf16x8 pf[2];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(sv[i] - m_use);
-        psum += p;
-        pf[i >> 3][i & 7] = (bf16_t)p;
-      }
-      l_run[mt] = l_run[mt] * alpha + psum;
-      m_run[mt] = m_new;
+    for (int s = 0; s < 2; ++s) {
+      const int blk = bt[min(tile * 2 + s, last_page)];
+      const bf16_t* vpage = a.vc + ((size_t)blk * a.Hkv + kvh) * page_elems;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o_acc[mt][dt][i] *= alpha;
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-          o_acc[mt][dt] =
-              __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[s][dt], pf[s], o_acc[mt][dt], 0, 0, 0);
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(vpage + (dt * 32 + r) * 16 + 8 * h);
+        dst[s][dt] = __builtin_nontemporal_load(in ? src : dummy);
       }
+    }
+  };
+  const int tile0 = (split_start >> 5) + w;
+#pragma unroll
+  for (int u = 0; u < NBUF; ++u) {
+    load_k(kf[u], tile0 + 4 * u);
+    load_v(vf[u], tile0 + 4 * u);
+  }
+  for (int base = tile0; base * 32 < split_end; base += 4 * NBUF) {
+#pragma unroll
+    for (int u = 0; u < NBUF; ++u) {
+      const int tile = base + 4 * u;
+      const int key0 = tile * 32;
+      const bool live = key0 < split_end;  // wave-uniform; dead tiles only keep the ring turning
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        bf16x8 pf[2];
+        float alpha = 1.f;
+        if (live) {
+          f32x16 s_acc;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s_acc[i] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            s_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[u][s], qf[mt][s], s_acc, 0, 0, 0);
+
+          // Online softmax of row m = 32mt + r over this lane's 16 keys.
+          float sv[16];
+          float tmax = -INFINITY;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+            sv[i] = key < kvlen_m[mt] ? s_acc[i] * a.scale_log2 : -INFINITY;
+            tmax = fmaxf(tmax, sv[i]);
+          }
+          tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+          const float m_new = fmaxf(m_run[mt], tmax);
+          const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+          alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_use);
+          float psum = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float p = __builtin_amdgcn_exp2f(sv[i] - m_use);
+            psum += p;
+            pf[i >> 3][i & 7] = (bf16_t)p;
+          }
+          l_run[mt] = l_run[mt] * alpha + psum;
+          m_run[mt] = m_new;
+        }
+        if (mt == MT - 1) load_k(kf[u], tile + 4 * NBUF);
+        if (live) {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o_acc[mt][dt][i] *= alpha;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u][s][dt], pf[s],
+                                                                      o_acc[mt][dt], 0, 0, 0);
+          }
+        }
+      }
+      load_v(vf[u], tile + 4 * NBUF);
     }
   }
 
@@ -185,35 +223,42 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
 
   const bool direct = a.n_splits == 1;
   const size_t part_base = ((size_t)(b * a.Hkv + kvh) * a.n_splits + split) * (MT * 32);
-  for (int e = tid; e < MT * 32 * D; e += 256) {
-    const int d = e % D;
-    const int m = e / D;  // 0 .. MT*32-1
-    const int mt = m >> 5, mr = m & 31;
-    float mx = -INFINITY;
+  // TPR threads share a query row: the row's four wave weights are computed once,
+  // then each thread walks its d values with independent LDS reads.
+  constexpr int TPR = 256 / (MT * 32);
+  const int m = tid / TPR;  // 0 .. MT*32-1
+  const int mt = m >> 5, mr = m & 31;
+  float wgt[4];
+  float mx = -INFINITY;
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) mx = fmaxf(mx, sm_m[(ww * MT + mt) * 32 + mr]);
-    float o = 0.f, l = 0.f;
-    if (mx != -INFINITY) {
+  for (int ww = 0; ww < 4; ++ww) {
+    wgt[ww] = sm_m[(ww * MT + mt) * 32 + mr];
+    mx = fmaxf(mx, wgt[ww]);
+  }
+  float l = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 4; ++ww) {
-        const float f = __builtin_amdgcn_exp2f(sm_m[(ww * MT + mt) * 32 + mr] - mx);
-        o += f * sm_o[((size_t)(ww * MT + mt) * D + d) * LDM + mr];
-        l += f * sm_l[(ww * MT + mt) * 32 + mr];
-      }
-    }
+  for (int ww = 0; ww < 4; ++ww) {
+    wgt[ww] = (mx == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(wgt[ww] - mx);
+    l += wgt[ww] * sm_l[(ww * MT + mt) * 32 + mr];
+  }
+  const bool row_live = m < m_rows;
+  const int t = row_live ? m / G : 0, g = row_live ? m % G : 0;
+  bf16_t* orow = a.out + (size_t)(b * a.q_len + t) * a.ldo + (size_t)(kvh * G + g) * D;
+#pragma unroll 4
+  for (int d = tid % TPR; d < D; d += TPR) {
+    float o = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww)
+      o += wgt[ww] * sm_o[((size_t)(ww * MT + mt) * D + d) * LDM + mr];
     if (direct) {
-      if (m < m_rows) {
-        const int t = m / G, g = m % G;
-        a.out[(size_t)(b * a.q_len + t) * a.ldo + (size_t)(kvh * G + g) * D + d] =
-            (bf16_t)(l > 0.f ? o / l : 0.f);
-      }
+      if (row_live) orow[d] = (bf16_t)(l > 0.f ? o / l : 0.f);
     } else {
       a.part_o[(part_base + m) * D + d] = o;
-      if (d == 0) {
-        a.part_ml[(part_base + m) * 2 + 0] = mx;
-        a.part_ml[(part_base + m) * 2 + 1] = l;
-      }
     }
+  }
+  if (!direct && tid % TPR == 0) {
+    a.part_ml[(part_base + m) * 2 + 0] = mx;
+    a.part_ml[(part_base + m) * 2 + 1] = l;
   }
 }
 
@@ -297,9 +342,11 @@ size_t attn_lds_bytes() {
 template <int D, int MT>
 int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
   const size_t lds = attn_lds_bytes<D, MT>();
+  // Ring depth: as many 32-key tiles in flight per wave as the register file allows.
+  constexpr int NBUF = D == 64 ? 4 : (MT == 1 ? 3 : 2);
   static bool attr_set = false;  // raise the dynamic-LDS limit once per process
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attn_kernel<D, MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attn_kernel<D, MT, NBUF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       sd_set_error("sd_paged_attention: hipFuncSetAttribute(%zu) failed: %s", lds,
@@ -308,7 +355,7 @@ int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((paged_attn_kernel<D, MT>), dim3(a.Hkv, a.n_splits, B), dim3(256), lds,
+  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF>), dim3(a.Hkv, a.n_splits, B), dim3(256), lds,
                      stream, a);
   SD_CHECK_LAUNCH("sd_paged_attention");
   if (a.n_splits > 1) {
