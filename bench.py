@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--target", default="llama-3-8b")
     ap.add_argument("--draft", default="llama-3.2-1b")
     ap.add_argument("--split-tokens", type=int, default=256)
+    ap.add_argument("--draft-split-tokens", type=int, default=0)
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -282,6 +283,7 @@ def main():
     # 2) speculative run
     def spec_run(alpha, steps, warmup):
         eng = SpecEngine(tw, dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
+                                              draft_split_tokens=args.draft_split_tokens,
                                               use_graph=not args.no_graph, gen_capacity=n_truth + 64))
         eng.set_synthetic_acceptance(truth_dev, alpha, seed=99 + rank)
         toks, n_timed, dt, prefill = run_generation(eng, prompt, steps, warmup, barrier)

@@ -324,10 +324,43 @@ int sd_gather_proposals(const int32_t* tok_buf, int64_t* draft_ids, int B,
 
 /* Applies out_ids [B, k+1] (i64, -1 padded) to the state: appends the emitted
  * tokens to gen_tokens[b, gen_counts[b]..] (bounded by gen_capacity),
- * advances seq_lens and gen_counts, and rebuilds tok_buf[:, 0:2].           */
+ * advances seq_lens and gen_counts, and rebuilds tok_buf[:, 0:2].
+ * step_out (optional) [B, k+3] i32 receives the step record
+ * {n_emitted, seq_len after the step, token_0 .. token_k (-1 padded)}; it may
+ * be pinned host memory, so that a host needs one stream synchronisation and
+ * no copy to return a step's tokens (the V1 worker's sampled_token_ids).    */
 int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32_t* tok_buf,
                      int32_t* gen_tokens, int64_t gen_stride, int gen_capacity,
-                     int32_t* gen_counts, int B, int k, sd_stream_t stream);
+                     int32_t* gen_counts, int32_t* step_out, int B, int k,
+                     sd_stream_t stream);
+
+/* Greedy steps without a logits round trip per helper.  The row argmax is
+ * split in two: sd_argmax_partial scans each row in SD_ARGMAX_PARTS slices
+ * (part_val / part_idx [R, SD_ARGMAX_PARTS]); the consumers below finish it
+ * (smallest index among equal maxima, as sd_argmax_rows) and go straight on:
+ *  - sd_propose_from_partials: rows row_offset + b*row_step are the draft's
+ *    last-token logits; stores proposal `step` like sd_store_proposal
+ *    (replaces top1_proposer's sampler + token append of one draft step);
+ *  - sd_verify_from_partials: rows b*(k+1)+i are the target's k+1 rows;
+ *    greedy acceptance against tok_buf[:, 2:2+k] (as sd_greedy_verify;
+ *    out_ids and counters optional), then the state update and step record
+ *    of sd_advance_state.  k == 0 is plain autoregressive decoding.          */
+#define SD_ARGMAX_PARTS 64
+int sd_argmax_partial(const float* logits, int64_t ld, float* part_val,
+                      int32_t* part_idx, int R, int V, sd_stream_t stream);
+int sd_propose_from_partials(const float* part_val, const int32_t* part_idx,
+                             int row_offset, int row_step, int32_t* tok_buf,
+                             int k, int step, const int32_t* seq_lens,
+                             const int32_t* truth, int64_t truth_stride,
+                             float accept_prob, uint32_t seed, int B,
+                             sd_stream_t stream);
+int sd_verify_from_partials(const float* part_val, const int32_t* part_idx,
+                            int32_t* tok_buf, const int32_t* proposal_lens,
+                            int64_t* out_ids, int64_t* counters,
+                            int32_t* seq_lens, int32_t* gen_tokens,
+                            int64_t gen_stride, int gen_capacity,
+                            int32_t* gen_counts, int32_t* step_out, int B,
+                            int k, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Stream capture helpers (one spec step = one hipGraph launch).

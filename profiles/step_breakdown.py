@@ -1,26 +1,51 @@
-"""Breaks one speculative step out of a rocprofv3 kernel trace CSV:
-   python profiles/step_breakdown.py <kernel_trace.csv>"""
+"""Breaks one speculative step out of a rocprofv3 kernel trace (CSV or rocpd .db):
+   python profiles/step_breakdown.py <kernel_trace.csv | results.db> [steps_back]
+
+Per kernel kind (name, grid, LDS): launches in the step, the slot time (start of
+the kernel to start of the next one, i.e. duration + boundary) and the duration."""
 import collections
 import csv
 import re
+import sqlite3
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'advance_state' in r['Kernel_Name']]
-a, b = idx[-2], idx[-1]
-seg = rows[a + 1:b + 1]
-t0, t1 = int(seg[0]['Start_Timestamp']), int(seg[-1]['End_Timestamp'])
-busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)
-print(f"kernels in step: {len(seg)}  wall us: {(t1 - t0) / 1e3:.1f}  busy us: {busy / 1e3:.1f}")
-agg = collections.OrderedDict()
-for r in seg:
-    n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
-    n = re.sub(r'^void ', '', n)[:52]
-    key = (n, r['Grid_Size_X'] + '/lds' + r['LDS_Block_Size'])
-    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    g = agg.setdefault(key, [0, 0.0])
-    g[0] += 1
-    g[1] += d
-for (n, gx), (c, t) in sorted(agg.items(), key=lambda x: -x[1][1]):
-    print(f"{n:52s} grid={gx:>16s} n={c:4d} total_us={t:9.1f} avg={t / c:7.2f}")
+
+def load(path):
+    if path.endswith(".db"):
+        db = sqlite3.connect(path)
+        q = "select name, start, end, grid_x, grid_y, grid_z, lds_size from kernels order by start"
+        return [dict(name=n, start=s, end=e, grid=f"{gx}x{gy}x{gz}", lds=l)
+                for n, s, e, gx, gy, gz, l in db.execute(q)]
+    rows = list(csv.DictReader(open(path)))
+    out = [dict(name=r["Kernel_Name"], start=int(r["Start_Timestamp"]), end=int(r["End_Timestamp"]),
+                grid=f"{r['Grid_Size_X']}x{r['Grid_Size_Y']}x{r['Grid_Size_Z']}",
+                lds=r["LDS_Block_Size"]) for r in rows]
+    out.sort(key=lambda r: r["start"])
+    return out
+
+
+def main():
+    rows = load(sys.argv[1])
+    back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    idx = [i for i, r in enumerate(rows) if "advance_state" in r["name"]]
+    a, b = idx[-1 - back], idx[-back]
+    seg = rows[a + 1:b + 1]
+    t0, t1 = seg[0]["start"], seg[-1]["end"]
+    busy = sum(r["end"] - r["start"] for r in seg)
+    print(f"kernels in step: {len(seg)}  wall us: {(t1 - t0) / 1e3:.1f}  busy us: {busy / 1e3:.1f}")
+    agg = collections.OrderedDict()
+    for i, r in enumerate(seg):
+        n = re.sub(r"\(anonymous namespace\)::", "", r["name"])
+        n = re.sub(r"^void ", "", n)[:50]
+        key = (n, f"{r['grid']}/lds{r['lds']}")
+        nxt = seg[i + 1]["start"] if i + 1 < len(seg) else r["end"]
+        g = agg.setdefault(key, [0, 0.0, 0.0])
+        g[0] += 1
+        g[1] += (r["end"] - r["start"]) / 1e3
+        g[2] += (nxt - r["start"]) / 1e3
+    for (n, gx), (c, t, sl) in sorted(agg.items(), key=lambda x: -x[1][2]):
+        print(f"{n:50s} {gx:>22s} n={c:4d} slot_us={sl:8.1f} avg_slot={sl / c:7.2f} avg_dur={t / c:7.2f}")
+
+
+if __name__ == "__main__":
+    main()

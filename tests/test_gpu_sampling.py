@@ -123,3 +123,98 @@ def test_bad_arguments_raise():
                              torch.zeros(1, 1, device="cuda"), torch.zeros(1, 2, device="cuda"))
     with pytest.raises(SdError):                              # CPU tensors are refused: no CPU path
         ops.argmax_rows(torch.zeros(2, 8))
+
+
+def _partials(ops, logits):
+    R = logits.shape[0]
+    pv = torch.empty(R, ops.ARGMAX_PARTS, dtype=torch.float32, device="cuda")
+    pi = torch.empty(R, ops.ARGMAX_PARTS, dtype=torch.int32, device="cuda")
+    ops.argmax_partial(logits, pv, pi)
+    return pv, pi
+
+
+def test_fused_greedy_glue_matches_golden_and_oracle():
+    """argmax partials -> proposal store / verification + state update, against the
+    golden greedy cases and the oracle's greedy_verify, with the step record in pinned
+    host memory."""
+    ops = _ops()
+    g = np.load(os.path.join(GOLDEN, "greedy_cases.npz"))
+    for i in range(int(g["n_cases"])):
+        logits = g[f"c{i}_logits"]
+        B, k1, V = logits.shape
+        k = k1 - 1
+        draft = g[f"c{i}_draft_ids"]
+        pv, pi = _partials(ops, cu(logits).view(B * k1, V))
+        tok_buf = torch.zeros(B, k + 2, dtype=torch.int32, device="cuda")
+        tok_buf[:, 0] = 11
+        tok_buf[:, 1] = 12
+        tok_buf[:, 2:] = cu(draft).to(torch.int32)
+        seq_lens = torch.full((B,), 40, dtype=torch.int32, device="cuda")
+        gen = torch.zeros(B, 32, dtype=torch.int32, device="cuda")
+        cnt = torch.full((B,), 3, dtype=torch.int32, device="cuda")
+        out = torch.zeros(B, k1, dtype=torch.int64, device="cuda")
+        counters = torch.zeros(3, dtype=torch.int64, device="cuda")
+        rec = torch.full((B, k + 3), -7, dtype=torch.int32).pin_memory()
+        ops.verify_from_partials(pv, pi, tok_buf, out, counters, seq_lens, gen, cnt, k, rec)
+        torch.cuda.synchronize()
+        ref = g[f"c{i}_out_ids"]
+        np.testing.assert_array_equal(out.cpu().numpy(), ref)
+        np.testing.assert_array_equal(counters.cpu().numpy(), g[f"c{i}_counters"])
+        n_emit = (ref >= 0).sum(axis=1)
+        np.testing.assert_array_equal(rec[:, 0].numpy(), n_emit)
+        np.testing.assert_array_equal(rec[:, 1].numpy(), 40 + n_emit)
+        np.testing.assert_array_equal(rec[:, 2:].numpy(), ref)
+        np.testing.assert_array_equal(seq_lens.cpu().numpy(), 40 + n_emit)
+        np.testing.assert_array_equal(cnt.cpu().numpy(), 3 + n_emit)
+        for b in range(B):
+            toks = ref[b, :n_emit[b]]
+            np.testing.assert_array_equal(gen[b, 3:3 + n_emit[b]].cpu().numpy(), toks)
+            prev = toks[-2] if n_emit[b] >= 2 else 12
+            assert tok_buf[b, :2].tolist() == [prev, toks[-1]]
+
+
+@pytest.mark.parametrize("V", [64, 50272, 128256, 151936])
+def test_argmax_partials_ties_and_strided_rows(V):
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(V)
+    x = torch.randn(6, V, generator=gen, device="cuda")
+    x[0, [V - 1, 3, V // 2]] = 9.0          # ties across slices: smallest index wins
+    x[1, V - 1] = 9.0                       # maximum in the last (short) slice
+    x[2] = -float("inf")                    # no finite entry: index 0
+    pv, pi = _partials(ops, x)
+    ref = sampling.argmax_rows(x.cpu().numpy())
+    # draft side: rows 1, 3, 5 (the q_len = 2 first pass reads every other row)
+    tok_buf = torch.zeros(3, 7, dtype=torch.int32, device="cuda")
+    ops.propose_from_partials(pv, pi, 1, 2, tok_buf, 5, 4, None)
+    assert tok_buf[:, 6].tolist() == [int(ref[1]), int(ref[3]), int(ref[5])]
+    assert tok_buf[:, :6].abs().sum().item() == 0
+    # k = 0 verification is plain decoding: every row emits its argmax
+    seq_lens = torch.full((6,), 9, dtype=torch.int32, device="cuda")
+    tb = torch.zeros(6, 2, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(6, dtype=torch.int32, device="cuda")
+    rec = torch.zeros(6, 3, dtype=torch.int32).pin_memory()
+    ops.verify_from_partials(pv, pi, tb, None, None, seq_lens, None, cnt, 0, rec)
+    torch.cuda.synchronize()
+    assert rec[:, 2].tolist() == [int(v) for v in ref]
+    assert rec[:, 0].tolist() == [1] * 6 and seq_lens.tolist() == [10] * 6
+    assert tb[:, 1].tolist() == [int(v) for v in ref]
+
+
+def test_store_proposal_forcing_is_the_same_in_both_paths():
+    ops = _ops()
+    B, k, V = 8, 5, 4096
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, V, generator=gen, device="cuda")
+    truth = torch.randint(0, V, (B, 64), generator=gen, device="cuda").to(torch.int32)
+    seq_lens = torch.arange(10, 10 + B, dtype=torch.int32, device="cuda")
+    pv, pi = _partials(ops, x)
+    forced = 0
+    rows = torch.arange(B, device="cuda")
+    for step in range(k):
+        a = torch.zeros(B, k + 2, dtype=torch.int32, device="cuda")
+        b = torch.zeros(B, k + 2, dtype=torch.int32, device="cuda")
+        ops.store_proposal(ops.argmax_rows(x), a, k, step, seq_lens, truth, 0.5, 1234)
+        ops.propose_from_partials(pv, pi, 0, 1, b, k, step, seq_lens, truth, 0.5, 1234)
+        assert torch.equal(a, b)
+        forced += (a[:, 2 + step] == truth[rows, (seq_lens + step).long()]).sum().item()
+    assert 8 <= forced <= 32     # 40 draws at probability 0.5

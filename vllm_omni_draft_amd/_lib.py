@@ -79,7 +79,12 @@ SIGNATURES = {
                                C.c_size_t, vp]),
     "sd_store_proposal": (i32, [vp, vp, i32, i32, vp, vp, i64, C.c_float, C.c_uint32, i32, vp]),
     "sd_gather_proposals": (i32, [vp, vp, i32, i32, vp]),
-    "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, i32, i32, vp]),
+    "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
+    "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),
+    "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i64, C.c_float,
+                                       C.c_uint32, i32, vp]),
+    "sd_verify_from_partials": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, i32,
+                                      vp]),
     "sd_graph_begin": (i32, [vp]),
     "sd_graph_end": (i32, [vp, C.POINTER(vp)]),
     "sd_graph_launch": (i32, [vp, vp]),

@@ -62,7 +62,10 @@ struct LinArgs {
   RopeArgs rope;
 };
 
-template <int EPI, int NORM>
+// HALF: a work unit is 8 of a tile's 16 rows (lanes of the other 8 rows load nothing and
+// feed zeros), so a matrix with fewer than 256 tiles still spreads over every CU.  A
+// row's arithmetic is the same as in a whole-tile unit.
+template <int EPI, int NORM, bool HALF>
 __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   constexpr bool GATED = EPI == SD_EPI_SILU_MUL;
   constexpr bool QKV = EPI == EPI_QKV_ROPE;
@@ -92,6 +95,9 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   const bf16_t* xrow = xs + (size_t)(xc < M ? xc : M) * LDX + 8 * xq;           // LDS
   const bf16_t* xglob = a.x + (size_t)(xc < M ? xc : 0) * a.ldx + 8 * xq;        // DIRECT
   const bool x_live = xc < M;
+  // the grid is even in HALF mode, so a workgroup keeps one row half for all its units
+  const int row_half = HALF ? (int)(blockIdx.x & 1) : 0;
+  const bool w_live = !HALF || ((lane >> 3) & 1) == row_half;
 
   // A fragments (and, DIRECT, B fragments) of this wave's next segment
   bf16x8 nxt[kSeg];
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
 #pragma unroll
     for (int j = 0; j < kSeg; ++j) {
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (seg * kSeg + j < KS)
+      if (seg * kSeg + j < KS && w_live)
         v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + (size_t)j * 512));
       nxt[j] = v;
     }
@@ -165,9 +171,11 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     }
   };
 
-  int tile = blockIdx.x;
+  const int n_units = HALF ? 2 * a.n_tiles : a.n_tiles;
+  auto tile_of = [&](int unit) { return HALF ? unit >> 1 : unit; };
+  int unit = blockIdx.x;
   if (wave < n_seg) {
-    load_seg(min(tile, a.n_tiles - 1), wave);  // in flight while x is staged
+    load_seg(tile_of(min(unit, n_units - 1)), wave);  // in flight while x is staged
   } else {
 #pragma unroll
     for (int j = 0; j < kSeg; ++j) nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -178,9 +186,53 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   }
 
   int parity = 0;
-  for (; tile < a.n_tiles; tile += gridDim.x, parity ^= 1) {
+  // Epilogue role of this thread (waves 0..3): element e = tid of the summed tile is
+  // output (row nl = 4*(l>>4) + reg of the tile, token m = l & 15), l = tid >> 2.
+  const int nl = 4 * (tid >> 6) + (tid & 3), m = (tid >> 2) & 15;
+  const bool epi_live = tid < 256 && m < M && (!HALF || (nl >> 3) == row_half);
+  // Inputs of the epilogue are fetched while the weights stream, not after the sum.
+  int q_pos = -1, q_page = 0, q_b = 0;
+  if (QKV && epi_live) {
+    const RopeArgs& rp = a.rope;
+    q_b = m / rp.q_len;
+    q_pos = rp.seq_lens[q_b] + rp.pos_offset + (m - q_b * rp.q_len);
+    if (q_pos >= 0) q_page = rp.block_tables[(size_t)q_b * rp.max_blocks + (q_pos >> 4)];
+  }
+  for (; unit < n_units; unit += gridDim.x, parity ^= 1) {
+    const int tile = tile_of(unit);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int next_tile = tile + (int)gridDim.x;
+    const int next_unit = unit + (int)gridDim.x;
+    float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f;  // bias / residual / cos, sin
+    if (epi_live) {
+      if (QKV) {
+        if (nl < 8) {
+          const RopeArgs& rp = a.rope;
+          const int D = rp.D, half = D / 2, tiles_per_head = D / 16;
+          const int head = tile / tiles_per_head, i = (tile % tiles_per_head) * 8 + nl;
+          if (a.bias) {
+            pre0 = (float)a.bias[head * D + i];
+            pre1 = (float)a.bias[head * D + i + half];
+          }
+          if (q_pos >= 0 && head < rp.Hq + rp.Hkv && rp.cs) {
+            const float* cs = rp.cs + (size_t)min(q_pos, rp.max_pos - 1) * D;
+            pre2 = cs[i];
+            pre3 = cs[half + i];
+          }
+        }
+      } else if (GATED) {
+        const int n = tile * 8 + nl;
+        if (nl < 8 && n < a.N && a.bias) {
+          pre0 = (float)a.bias[n];
+          pre1 = (float)a.bias[a.N + n];
+        }
+      } else {
+        const int n = tile * 16 + nl;
+        if (n < a.N) {
+          if (a.bias) pre0 = (float)a.bias[n];
+          if (EPI == SD_EPI_RESIDUAL) pre1 = (float)a.residual[(size_t)m * a.ldo + n];
+        }
+      }
+    }
     for (int chunk = 0; chunk < n_chunks; ++chunk) {
       const int seg_lo = chunk * SC, seg_hi = min(seg_lo + SC, n_seg);
       if (!DIRECT && !single) {
@@ -200,7 +252,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
           for (int j = 0; j < kSeg; ++j) cur_x[DIRECT ? j : 0] = nxt_x[DIRECT ? j : 0];
         }
         if (seg + kLinWaves < n_seg) load_seg(tile, seg + kLinWaves);
-        else if (next_tile < a.n_tiles) load_seg(next_tile, wave);
+        else if (next_unit < n_units) load_seg(tile_of(next_unit), wave);
         const bf16_t* xp = xrow + (size_t)(seg - seg_lo) * kSeg * 32;
 #pragma unroll
         for (int j = 0; j < kSeg; ++j) {
@@ -218,92 +270,67 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     float* rbuf = red + parity * kLinWaves * 256;
     *reinterpret_cast<f32x4*>(rbuf + wave * 256 + lane * 4) = acc;
     __syncthreads();
-    if (tid < 256) {
+    if (epi_live) {
       auto total = [&](int e) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < kLinWaves; ++w) s += rbuf[w * 256 + e];
         return s;
       };
-      // element e = 4*l + reg of a wave tile is output (row 4*(l>>4) + reg, token l&15)
-      const int l2 = tid >> 2, reg = tid & 3;
-      const int nl = 4 * (l2 >> 4) + reg, m = l2 & 15;
-      if (m < M) {
-        if (QKV) {
-          // tile rows 0..7 are dims i0..i0+7 of a head, rows 8..15 their rotation partners
-          // (row nl + 8 is element e + 128)
-          if (nl < 8) {
-            const RopeArgs& rp = a.rope;
-            const int D = rp.D, half = D / 2;
-            const int tiles_per_head = D / 16;
-            const int head = tile / tiles_per_head, i = (tile % tiles_per_head) * 8 + nl;
-            float lo = total(tid), hi = total(tid + 128);
-            if (a.bias) {
-              lo += (float)a.bias[head * D + i];
-              hi += (float)a.bias[head * D + i + half];
-            }
-            lo = round_bf16(lo);
-            hi = round_bf16(hi);
-            const int b = m / rp.q_len, t = m - b * rp.q_len;
-            const int pos = rp.seq_lens[b] + rp.pos_offset + t;
-            if (pos >= 0) {
-              if (head < rp.Hq + rp.Hkv && rp.cs) {
-                const float* cs = rp.cs + (size_t)min(pos, rp.max_pos - 1) * D;
-                const float c = cs[i], s = cs[half + i];
-                const float nlo = lo * c - hi * s, nhi = hi * c + lo * s;
-                lo = nlo;
-                hi = nhi;
-              }
-              if (head < rp.Hq) {
-                bf16_t* q = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + (size_t)head * D;
-                q[i] = (bf16_t)lo;
-                q[i + half] = (bf16_t)hi;
-              } else {
-                const int page = rp.block_tables[(size_t)b * rp.max_blocks + (pos >> 4)];
-                const int slot = pos & 15;
-                if (head < rp.Hq + rp.Hkv) {
-                  bf16_t* kp = rp.kc + ((size_t)page * rp.Hkv + (head - rp.Hq)) * D * 16;
-                  const int i2 = i + half;
-                  kp[((i >> 3) * 16 + slot) * 8 + (i & 7)] = (bf16_t)lo;
-                  kp[((i2 >> 3) * 16 + slot) * 8 + (i2 & 7)] = (bf16_t)hi;
-                } else {
-                  bf16_t* vp = rp.vc + ((size_t)page * rp.Hkv + (head - rp.Hq - rp.Hkv)) * D * 16;
-                  const int sl = sd_v_slot(slot);
-                  vp[i * 16 + sl] = (bf16_t)lo;
-                  vp[(i + half) * 16 + sl] = (bf16_t)hi;
-                }
-              }
-            }
+      if (QKV) {
+        // tile rows 0..7 are dims i0..i0+7 of a head, rows 8..15 their rotation partners
+        // (row nl + 8 is element e + 128)
+        if (nl < 8 && q_pos >= 0) {
+          const RopeArgs& rp = a.rope;
+          const int D = rp.D, half = D / 2;
+          const int tiles_per_head = D / 16;
+          const int head = tile / tiles_per_head, i = (tile % tiles_per_head) * 8 + nl;
+          float lo = round_bf16(total(tid) + pre0), hi = round_bf16(total(tid + 128) + pre1);
+          if (head < rp.Hq + rp.Hkv && rp.cs) {
+            const float nlo = lo * pre2 - hi * pre3, nhi = hi * pre2 + lo * pre3;
+            lo = nlo;
+            hi = nhi;
           }
-        } else if (GATED) {
-          // tile rows 0..7 are gate rows 8*tile.., rows 8..15 the matching up rows
-          if (nl < 8) {
-            const int n = tile * 8 + nl;
-            if (n < a.N) {
-              float g = total(tid), u = total(tid + 128);
-              if (a.bias) {
-                g += (float)a.bias[n];
-                u += (float)a.bias[a.N + n];
-              }
-              g = round_bf16(silu_f(round_bf16(g)));
-              reinterpret_cast<bf16_t*>(a.out)[(size_t)m * a.ldo + n] = (bf16_t)(g * round_bf16(u));
-            }
-          }
-        } else {
-          const int n = tile * 16 + nl;
-          if (n < a.N) {
-            float y = total(tid);
-            if (a.bias) y += (float)a.bias[n];
-            const size_t o = (size_t)m * a.ldo + n;
-            if (EPI == SD_EPI_F32) {
-              reinterpret_cast<float*>(a.out)[o] = y;
+          if (head < rp.Hq) {
+            bf16_t* q = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + (size_t)head * D;
+            q[i] = (bf16_t)lo;
+            q[i + half] = (bf16_t)hi;
+          } else {
+            const int slot = q_pos & 15;
+            if (head < rp.Hq + rp.Hkv) {
+              bf16_t* kp = rp.kc + ((size_t)q_page * rp.Hkv + (head - rp.Hq)) * D * 16;
+              const int i2 = i + half;
+              kp[((i >> 3) * 16 + slot) * 8 + (i & 7)] = (bf16_t)lo;
+              kp[((i2 >> 3) * 16 + slot) * 8 + (i2 & 7)] = (bf16_t)hi;
             } else {
-              bf16_t* ob = reinterpret_cast<bf16_t*>(a.out);
-              if (EPI == SD_EPI_STORE) ob[o] = (bf16_t)y;
-              else if (EPI == SD_EPI_RESIDUAL) ob[o] = (bf16_t)(round_bf16(y) + (float)a.residual[o]);
-              else if (EPI == SD_EPI_RELU) ob[o] = (bf16_t)fmaxf(round_bf16(y), 0.f);
-              else ob[o] = (bf16_t)gelu_tanh_f(round_bf16(y));
+              bf16_t* vp = rp.vc + ((size_t)q_page * rp.Hkv + (head - rp.Hq - rp.Hkv)) * D * 16;
+              const int sl = sd_v_slot(slot);
+              vp[i * 16 + sl] = (bf16_t)lo;
+              vp[(i + half) * 16 + sl] = (bf16_t)hi;
             }
+          }
+        }
+      } else if (GATED) {
+        // tile rows 0..7 are gate rows 8*tile.., rows 8..15 the matching up rows
+        const int n = tile * 8 + nl;
+        if (nl < 8 && n < a.N) {
+          float g = total(tid) + pre0, u = total(tid + 128) + pre1;
+          g = round_bf16(silu_f(round_bf16(g)));
+          reinterpret_cast<bf16_t*>(a.out)[(size_t)m * a.ldo + n] = (bf16_t)(g * round_bf16(u));
+        }
+      } else {
+        const int n = tile * 16 + nl;
+        if (n < a.N) {
+          const float y = total(tid) + pre0;
+          const size_t o = (size_t)m * a.ldo + n;
+          if (EPI == SD_EPI_F32) {
+            reinterpret_cast<float*>(a.out)[o] = y;
+          } else {
+            bf16_t* ob = reinterpret_cast<bf16_t*>(a.out);
+            if (EPI == SD_EPI_STORE) ob[o] = (bf16_t)y;
+            else if (EPI == SD_EPI_RESIDUAL) ob[o] = (bf16_t)(round_bf16(y) + pre1);
+            else if (EPI == SD_EPI_RELU) ob[o] = (bf16_t)fmaxf(round_bf16(y), 0.f);
+            else ob[o] = (bf16_t)gelu_tanh_f(round_bf16(y));
           }
         }
       }
@@ -333,12 +360,12 @@ int choose_kc(int M, int K, bool norm) {
   return ((kpad / 256 + n_chunks - 1) / n_chunks) * 256;
 }
 
-template <int EPI, int NORM>
-int launch_one(LinArgs& a, hipStream_t st) {
+template <int EPI, int NORM, bool HALF>
+int launch_half(LinArgs& a, hipStream_t st) {
   const size_t lds = lin_lds_bytes(a.M, a.KC, NORM == NORM_NONE);
   static bool attr_set = false;  // once per instantiation and process
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM, HALF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       sd_set_error("sd_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -348,10 +375,23 @@ int launch_one(LinArgs& a, hipStream_t st) {
   }
   // Up to two workgroups per CU (LDS permitting), each walking a strided tile list.
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // 16 waves per CU
-  const int blocks = a.n_tiles < 256 * per_cu ? a.n_tiles : 256 * per_cu;
-  hipLaunchKernelGGL((linear_kernel<EPI, NORM>), dim3(blocks), dim3(kLinThreads), lds, st, a);
+  const int n_units = HALF ? 2 * a.n_tiles : a.n_tiles;
+  const int blocks = n_units < 256 * per_cu ? n_units : 256 * per_cu;
+  hipLaunchKernelGGL((linear_kernel<EPI, NORM, HALF>), dim3(blocks), dim3(kLinThreads), lds, st,
+                     a);
   SD_CHECK_LAUNCH("sd_linear");
   return SD_OK;
+}
+
+template <int EPI, int NORM>
+int launch_one(LinArgs& a, hipStream_t st) {
+  // Row-half units where whole tiles would leave CUs idle (plain row-per-output tiles only:
+  // gated and rotary tiles pair row r with row r + 8).
+  constexpr bool kCanHalve = NORM == NORM_NONE && EPI != SD_EPI_SILU_MUL && EPI != EPI_QKV_ROPE;
+  if constexpr (kCanHalve) {
+    if (a.n_tiles < 256) return launch_half<EPI, NORM, true>(a, st);
+  }
+  return launch_half<EPI, NORM, false>(a, st);
 }
 
 template <int NORM>

@@ -280,6 +280,22 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
+// The proposal of sequence b at draft step `step`, or (synthetic acceptance control) the
+// true token of that position with probability accept_prob.
+__device__ __forceinline__ int32_t forced_proposal(int32_t tok, int b, int step,
+                                                   const int32_t* __restrict__ seq_lens,
+                                                   const int32_t* __restrict__ truth,
+                                                   int64_t truth_stride, float accept_prob,
+                                                   uint32_t seed) {
+  if (truth) {
+    const int pos = seq_lens[b] + step;  // position the proposal would occupy
+    const uint32_t h = mix32(mix32(seed ^ (uint32_t)b * 0x9e3779b9u) + (uint32_t)pos);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    if (u < accept_prob && pos < truth_stride) tok = truth[(size_t)b * truth_stride + pos];
+  }
+  return tok;
+}
+
 __global__ void store_proposal_kernel(const int64_t* __restrict__ ids,
                                       int32_t* __restrict__ tok_buf, int k, int step,
                                       const int32_t* __restrict__ seq_lens,
@@ -288,14 +304,39 @@ __global__ void store_proposal_kernel(const int64_t* __restrict__ ids,
                                       uint32_t seed, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  int32_t tok = (int32_t)ids[b];
-  if (truth) {
-    const int pos = seq_lens[b] + step;  // position the proposal would occupy
-    const uint32_t h = mix32(mix32(seed ^ (uint32_t)b * 0x9e3779b9u) + (uint32_t)pos);
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    if (u < accept_prob && pos < truth_stride) tok = truth[(size_t)b * truth_stride + pos];
+  tok_buf[(size_t)b * (k + 2) + 2 + step] =
+      forced_proposal((int32_t)ids[b], b, step, seq_lens, truth, truth_stride, accept_prob, seed);
+}
+
+// Applies the emitted tokens o[0..k] (-1 padded) of sequence b to the device state and
+// writes the step record {n_emitted, sequence length, tokens} if asked.
+__device__ __forceinline__ void apply_emitted(const int64_t* o, int b,
+                                              int32_t* __restrict__ seq_lens,
+                                              int32_t* __restrict__ tok_buf,
+                                              int32_t* __restrict__ gen_tokens,
+                                              int64_t gen_stride, int gen_capacity,
+                                              int32_t* __restrict__ gen_counts,
+                                              int32_t* __restrict__ step_out, int k) {
+  int n_emit = 0;
+  while (n_emit <= k && o[n_emit] >= 0) ++n_emit;
+  int32_t* rec = step_out ? step_out + (size_t)b * (k + 3) : nullptr;
+  if (rec) {
+    rec[0] = n_emit;
+    rec[1] = seq_lens[b] + n_emit;
+    for (int i = 0; i <= k; ++i) rec[2 + i] = i < n_emit ? (int32_t)o[i] : -1;
   }
-  tok_buf[(size_t)b * (k + 2) + 2 + step] = tok;
+  if (n_emit == 0) return;  // nothing emitted (should not happen)
+  int32_t* tb = tok_buf + (size_t)b * (k + 2);
+  const int32_t last = (int32_t)o[n_emit - 1];
+  const int32_t prev = n_emit >= 2 ? (int32_t)o[n_emit - 2] : tb[1];
+  const int g = gen_counts[b];
+  for (int i = 0; i < n_emit; ++i)
+    if (gen_tokens && g + i < gen_capacity)
+      gen_tokens[(size_t)b * gen_stride + g + i] = (int32_t)o[i];
+  gen_counts[b] = g + n_emit;
+  seq_lens[b] += n_emit;
+  tb[0] = prev;
+  tb[1] = last;
 }
 
 __global__ void gather_proposals_kernel(const int32_t* __restrict__ tok_buf,
@@ -311,24 +352,126 @@ __global__ void advance_state_kernel(const int64_t* __restrict__ out_ids,
                                      int32_t* __restrict__ tok_buf,
                                      int32_t* __restrict__ gen_tokens, int64_t gen_stride,
                                      int gen_capacity, int32_t* __restrict__ gen_counts,
-                                     int B, int k) {
+                                     int32_t* __restrict__ step_out, int B, int k) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const int64_t* o = out_ids + (size_t)b * (k + 1);
-  int n_emit = 0;
-  while (n_emit <= k && o[n_emit] >= 0) ++n_emit;
-  int32_t* tb = tok_buf + (size_t)b * (k + 2);
-  if (n_emit == 0) return;  // nothing emitted (should not happen)
-  const int32_t last = (int32_t)o[n_emit - 1];
-  const int32_t prev = n_emit >= 2 ? (int32_t)o[n_emit - 2] : tb[1];
-  int g = gen_counts[b];
-  for (int i = 0; i < n_emit; ++i)
-    if (gen_tokens && g + i < gen_capacity)
-      gen_tokens[(size_t)b * gen_stride + g + i] = (int32_t)o[i];
-  gen_counts[b] = g + n_emit;
-  seq_lens[b] += n_emit;
-  tb[0] = prev;
-  tb[1] = last;
+  apply_emitted(out_ids + (size_t)b * (k + 1), b, seq_lens, tok_buf, gen_tokens, gen_stride,
+                gen_capacity, gen_counts, step_out, k);
+}
+
+constexpr int kArgmaxParts = SD_ARGMAX_PARTS;
+
+// Stage 1 of a split row argmax: block (part, row) scans one 1/64 slice of the row.
+__global__ __launch_bounds__(256) void argmax_partial_kernel(
+    const float* __restrict__ logits, int64_t ld, float* __restrict__ part_val,
+    int32_t* __restrict__ part_idx, int V) {
+  __shared__ float s_f[4];
+  __shared__ int s_i[4];
+  const int part = blockIdx.x, r = blockIdx.y;
+  const int chunk = ((V + kArgmaxParts - 1) / kArgmaxParts + 3) & ~3;
+  const int lo = part * chunk, hi = min(lo + chunk, V);
+  const float* row = logits + (size_t)r * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+    if (i + 3 < hi) {
+      const float4 v = *reinterpret_cast<const float4*>(row + i);
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (e[j] > best) { best = e[j]; bi = i + j; }
+    } else {
+      for (int j = 0; j < 4 && i + j < hi; ++j)
+        if (row[i + j] > best) { best = row[i + j]; bi = i + j; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_f[wave] = best; s_i[wave] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (s_f[w] > best || (s_f[w] == best && s_i[w] < bi)) { best = s_f[w]; bi = s_i[w]; }
+    part_val[(size_t)r * kArgmaxParts + part] = best;
+    part_idx[(size_t)r * kArgmaxParts + part] = bi;
+  }
+}
+
+// Stage 2, one wave per row: the smallest index among the row's maxima.
+__device__ __forceinline__ int wave_argmax_finish(const float* __restrict__ part_val,
+                                                  const int32_t* __restrict__ part_idx, int row,
+                                                  int lane) {
+  float best = part_val[(size_t)row * kArgmaxParts + lane];
+  int bi = part_idx[(size_t)row * kArgmaxParts + lane];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  return bi == 0x7fffffff ? 0 : bi;
+}
+
+__global__ __launch_bounds__(SD_WAVE) void propose_from_partials_kernel(
+    const float* __restrict__ part_val, const int32_t* __restrict__ part_idx, int row_offset,
+    int row_step, int32_t* __restrict__ tok_buf, int k, int step,
+    const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ truth, int64_t truth_stride,
+    float accept_prob, uint32_t seed) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int id = wave_argmax_finish(part_val, part_idx, row_offset + b * row_step, lane);
+  if (lane == 0)
+    tok_buf[(size_t)b * (k + 2) + 2 + step] =
+        forced_proposal(id, b, step, seq_lens, truth, truth_stride, accept_prob, seed);
+}
+
+// Greedy verification straight from the target's argmax partials: wave j finishes row j
+// of the sequence, wave 0 then matches the proposals in tok_buf and applies the result.
+__global__ __launch_bounds__(SD_WAVE * 8) void verify_from_partials_kernel(
+    const float* __restrict__ part_val, const int32_t* __restrict__ part_idx,
+    int32_t* __restrict__ tok_buf, const int32_t* __restrict__ proposal_lens,
+    int64_t* __restrict__ out_ids, unsigned long long* __restrict__ counters,
+    int32_t* __restrict__ seq_lens, int32_t* __restrict__ gen_tokens, int64_t gen_stride,
+    int gen_capacity, int32_t* __restrict__ gen_counts, int32_t* __restrict__ step_out, int k) {
+  __shared__ int s_target[8];
+  __shared__ int64_t s_out[8];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wave <= k) {
+    const int id = wave_argmax_finish(part_val, part_idx, b * (k + 1) + wave, lane);
+    if (lane == 0) s_target[wave] = id;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  int L = proposal_lens ? proposal_lens[b] : k;
+  L = min(max(L, 0), k);
+  const int32_t* prop = tok_buf + (size_t)b * (k + 2) + 2;
+  bool ok = true;
+  if (lane < L) ok = prop[lane] == s_target[lane];
+  const unsigned long long rejected = ~__ballot(ok);
+  const int first = rejected ? (__ffsll((long long)rejected) - 1) : SD_WAVE;
+  const int j = min(first, L);
+  if (lane <= k) {
+    int64_t v = -1;
+    if (lane < j) v = prop[lane];
+    else if (lane == j) v = s_target[j];
+    s_out[lane] = v;
+    if (out_ids) out_ids[(size_t)b * (k + 1) + lane] = v;
+  }
+  // s_out is written and read by lanes of this one wave only
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    if (counters) {
+      atomicAdd(&counters[0], (unsigned long long)j);
+      atomicAdd(&counters[1], (unsigned long long)(j + 1));
+      atomicAdd(&counters[2], (unsigned long long)L);
+    }
+    apply_emitted(s_out, b, seq_lens, tok_buf, gen_tokens, gen_stride, gen_capacity, gen_counts,
+                  step_out, k);
+  }
 }
 
 }  // namespace
@@ -437,13 +580,61 @@ extern "C" int sd_gather_proposals(const int32_t* tok_buf, int64_t* draft_ids, i
 
 extern "C" int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32_t* tok_buf,
                                 int32_t* gen_tokens, int64_t gen_stride, int gen_capacity,
-                                int32_t* gen_counts, int B, int k, sd_stream_t stream) {
+                                int32_t* gen_counts, int32_t* step_out, int B, int k,
+                                sd_stream_t stream) {
   SD_REQUIRE(out_ids && seq_lens && tok_buf && gen_counts && B >= 0 && k >= 0,
              SD_ERR_INVALID, "sd_advance_state: bad arguments");
   if (B == 0) return SD_OK;
   hipLaunchKernelGGL(advance_state_kernel, dim3((B + 63) / 64), dim3(64), 0,
                      (hipStream_t)stream, out_ids, seq_lens, tok_buf, gen_tokens, gen_stride,
-                     gen_capacity, gen_counts, B, k);
+                     gen_capacity, gen_counts, step_out, B, k);
   SD_CHECK_LAUNCH("sd_advance_state");
+  return SD_OK;
+}
+
+extern "C" int sd_argmax_partial(const float* logits, int64_t ld, float* part_val,
+                                 int32_t* part_idx, int R, int V, sd_stream_t stream) {
+  SD_REQUIRE(logits && part_val && part_idx && R >= 0 && V >= 1, SD_ERR_INVALID,
+             "sd_argmax_partial: bad arguments (R=%d V=%d)", R, V);
+  SD_REQUIRE(ld >= V && ld % 4 == 0 && sd_aligned16(logits), SD_ERR_INVALID,
+             "sd_argmax_partial: rows must be 16-byte aligned");
+  if (R == 0) return SD_OK;
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(kArgmaxParts, R), dim3(256), 0,
+                     (hipStream_t)stream, logits, ld, part_val, part_idx, V);
+  SD_CHECK_LAUNCH("sd_argmax_partial");
+  return SD_OK;
+}
+
+extern "C" int sd_propose_from_partials(const float* part_val, const int32_t* part_idx,
+                                        int row_offset, int row_step, int32_t* tok_buf, int k,
+                                        int step, const int32_t* seq_lens, const int32_t* truth,
+                                        int64_t truth_stride, float accept_prob, uint32_t seed,
+                                        int B, sd_stream_t stream) {
+  SD_REQUIRE(part_val && part_idx && tok_buf && B >= 0 && k >= 1 && step >= 0 && step < k &&
+                 row_offset >= 0 && row_step >= 1, SD_ERR_INVALID,
+             "sd_propose_from_partials: bad arguments (B=%d k=%d step=%d)", B, k, step);
+  SD_REQUIRE(!truth || seq_lens, SD_ERR_INVALID, "sd_propose_from_partials: truth without seq_lens");
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(propose_from_partials_kernel, dim3(B), dim3(SD_WAVE), 0, (hipStream_t)stream,
+                     part_val, part_idx, row_offset, row_step, tok_buf, k, step, seq_lens, truth,
+                     truth_stride, accept_prob, seed);
+  SD_CHECK_LAUNCH("sd_propose_from_partials");
+  return SD_OK;
+}
+
+extern "C" int sd_verify_from_partials(const float* part_val, const int32_t* part_idx,
+                                       int32_t* tok_buf, const int32_t* proposal_lens,
+                                       int64_t* out_ids, int64_t* counters, int32_t* seq_lens,
+                                       int32_t* gen_tokens, int64_t gen_stride, int gen_capacity,
+                                       int32_t* gen_counts, int32_t* step_out, int B, int k,
+                                       sd_stream_t stream) {
+  SD_REQUIRE(part_val && part_idx && tok_buf && seq_lens && gen_counts && B >= 0 && k >= 0 &&
+                 k <= 7, SD_ERR_INVALID, "sd_verify_from_partials: bad arguments (B=%d k=%d)", B, k);
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(verify_from_partials_kernel, dim3(B), dim3(SD_WAVE * 8), 0,
+                     (hipStream_t)stream, part_val, part_idx, tok_buf, proposal_lens, out_ids,
+                     reinterpret_cast<unsigned long long*>(counters), seq_lens, gen_tokens,
+                     gen_stride, gen_capacity, gen_counts, step_out, k);
+  SD_CHECK_LAUNCH("sd_verify_from_partials");
   return SD_OK;
 }

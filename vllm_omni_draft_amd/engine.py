@@ -35,7 +35,8 @@ class EngineConfig:
     k: int = 5                     # proposals per step; 0 = plain autoregressive decoding
     max_batch: int = 1
     max_seq_len: int = 2048        # prompt + generated tokens (+ k+1 slack is added)
-    split_tokens: int = 256        # attention keys per workgroup
+    split_tokens: int = 256        # attention keys per workgroup, target model
+    draft_split_tokens: int = 0    # same for the draft model (0 = like the target)
     temperature: float = 0.0       # 0 = greedy
     seed: int = 0
     use_graph: bool = True
@@ -58,7 +59,8 @@ class SpecEngine:
         B, k = cfg.max_batch, cfg.k
         self.max_ctx = cfg.max_seq_len + k + 2
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens)
-        self.draft = DecoderModel(draft, self.max_ctx, cfg.split_tokens) if k > 0 else None
+        self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens)
+                      if k > 0 else None)
         self.V = target.cfg.vocab
         pages = PagedKVCache.pages_for(target.cfg, B, self.max_ctx)
         self.t_kv = PagedKVCache(target.cfg, pages, B, self.max_ctx, dev)
@@ -79,6 +81,14 @@ class SpecEngine:
         self.target_ids = torch.zeros(B, k + 1, dtype=torch.int64, device=dev)
         self.draft_ids = torch.zeros(B, max(k, 1), dtype=torch.int64, device=dev)
         self.out_ids = torch.full((B, k + 1), -1, dtype=torch.int64, device=dev)
+        n_rows = max(MAX_ROWS, B * (k + 1))
+        self.part_val = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
+        self.part_idx = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.int32, device=dev)
+        # Step record {n_emitted, seq_len, tokens}: the last kernel of a step writes it to
+        # pinned host memory, so returning a step's tokens takes one stream
+        # synchronisation and no copy.
+        self.step_out = torch.full((B, k + 3), -1, dtype=torch.int32).pin_memory()
+        self._steps_pending = 0               # steps enqueued since the last read-back
         self.sampling = cfg.temperature > 0.0
         if self.sampling:
             f32 = dict(dtype=torch.float32, device=dev)
@@ -97,8 +107,8 @@ class SpecEngine:
         self.active = 0                       # sequences currently in the batch
         self.host_lens: List[int] = [0] * B   # upper bound of seq_lens known to the host
         self.host_gen: List[int] = [0] * B
-        self._graph = None
-        self._graph_key = None
+        self._graphs: dict = {}               # (B, k, truth?, ctx bucket) -> captured step
+        self._ctx = self.max_ctx              # context bound the passes are enqueued with
         # stream capture is not allowed on the legacy default stream
         self.stream = torch.cuda.Stream(device=dev)
         torch.cuda.synchronize(dev)  # buffers above were filled on the default stream
@@ -130,7 +140,7 @@ class SpecEngine:
         self.truth = truth
         self.accept_prob = float(accept_prob)
         self.accept_seed = int(seed)
-        self._graph = None
+        self._drop_graphs()
 
     def add_request(self, slot: int, prompt: Sequence[int]) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
@@ -148,6 +158,7 @@ class SpecEngine:
         if self.d_kv is not None:
             self.d_kv.ensure_capacity(slot, n + self.k + 2)
         self.prompt_buf[:n].copy_(torch.tensor(list(prompt), dtype=torch.int32))
+        self._ctx = self._ctx_bucket(n + self.k + 2)
         zl = self.zero_lens[slot:slot + 1]
         for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
             if model is None:
@@ -194,17 +205,18 @@ class SpecEngine:
                 sub_logits = logits[b0 * q_len:(b0 + nb) * q_len]
             view = _KvView(kv, slot0 + b0)
             model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens, tok_stride,
-                          tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self.max_ctx)
+                          tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self._ctx)
 
     def _enqueue_step(self) -> None:
         """One whole step: propose (k draft passes), score (one target pass),
         accept (verification + state update).  Enqueues only."""
+        fused = not self.sampling  # greedy: argmax partials feed the glue kernels directly
         if self.k == 0:
             self._enqueue_ar_step()
             return
-        self._enqueue_propose()
-        self._enqueue_score()
-        self._enqueue_accept()
+        self._enqueue_propose(fused)
+        self._enqueue_score(fused)
+        self._enqueue_accept(fused)
 
     def _enqueue_ar_step(self) -> None:
         B = self.active
@@ -213,14 +225,18 @@ class SpecEngine:
         if self.sampling:
             ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V))
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp)
+            ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf,
+                              self.gen_tokens, self.gen_counts, 0, self.step_out)
         else:
-            ops.argmax_rows(self.t_logits[:B], out=self.ids_tmp)
-        ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf, self.gen_tokens,
-                          self.gen_counts, 0)
+            ops.argmax_partial(self.t_logits[:B], self.part_val, self.part_idx)
+            ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf, None, None,
+                                     self.seq_lens, self.gen_tokens, self.gen_counts, 0,
+                                     self.step_out)
 
-    def _enqueue_propose(self) -> None:
+    def _enqueue_propose(self, fused: bool = False) -> None:
         """k draft passes; proposals land in tok_buf[:, 2:], their probability
-        rows (sampling mode) in d_probs."""
+        rows (sampling mode) in d_probs.  fused (greedy only): two glue kernels per
+        pass instead of three, and no draft_ids gather."""
         B, k = self.active, self.k
         stride = k + 2
         for i in range(k):
@@ -233,6 +249,12 @@ class SpecEngine:
                               -1 + i, B, 1, self.d_logits)
                 off, step = 0, 1
             rows = self.d_logits[:B * step]
+            if fused:
+                ops.argmax_partial(rows, self.part_val, self.part_idx)
+                ops.propose_from_partials(self.part_val, self.part_idx, off, step, self.tok_buf, k,
+                                          i, self.seq_lens, self.truth, self.accept_prob,
+                                          self.accept_seed)
+                continue
             if self.sampling:
                 ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
                                  out_ptr=self.d_probs.data_ptr() + i * self.V * 4, out_ld=k * self.V)
@@ -242,25 +264,33 @@ class SpecEngine:
                 ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
             ops.store_proposal(self.ids_tmp, self.tok_buf, k, i, self.seq_lens, self.truth,
                                self.accept_prob, self.accept_seed)
-        ops.gather_proposals(self.tok_buf, self.draft_ids, k)
+        if not fused:
+            ops.gather_proposals(self.tok_buf, self.draft_ids, k)
 
-    def _enqueue_score(self) -> None:
+    def _enqueue_score(self, fused: bool = False) -> None:
         """One target pass over {last token, k proposals} of every sequence:
         t_logits [B*(k+1), V], plus target_ids (greedy) or t_probs / bonus_ids."""
         B, k = self.active, self.k
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, k + 1,
                       self.t_logits)
         rows = self.t_logits[:B * (k + 1)]
-        if self.sampling:
+        if fused:
+            ops.argmax_partial(rows, self.part_val, self.part_idx)
+        elif self.sampling:
             ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V))
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
                             out=self.bonus_ids, row_offset=k, row_step=k + 1)
         else:
             ops.argmax_rows(rows, out=self.target_ids.view(-1))
 
-    def _enqueue_accept(self) -> None:
+    def _enqueue_accept(self, fused: bool = False) -> None:
         """Acceptance (rejection sampling or greedy match) and the state update."""
         B, k = self.active, self.k
+        if fused:
+            ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf, self.out_ids,
+                                     self.counters, self.seq_lens, self.gen_tokens,
+                                     self.gen_counts, k, self.step_out)
+            return
         if self.sampling:
             _lib.check(_lib.load().sd_rejection_sample(
                 self.t_probs.data_ptr(), self.bonus_ids.data_ptr(), self.d_probs.data_ptr(),
@@ -271,7 +301,7 @@ class SpecEngine:
             ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], None, self.counters,
                               out=self.out_ids)
         ops.advance_state(self.out_ids, self.seq_lens, self.tok_buf, self.gen_tokens,
-                          self.gen_counts, k)
+                          self.gen_counts, k, self.step_out)
 
     def remove_request(self, slot: int) -> None:
         """Frees batch slot `slot`; the last active sequence moves into it so
@@ -321,6 +351,11 @@ class SpecEngine:
             self.t_kv.ensure_capacity(b, need)
             if self.d_kv is not None:
                 self.d_kv.ensure_capacity(b, need)
+        # Attention launches one workgroup per `split_tokens` keys up to the context bound it
+        # is given; a bound that follows the live lengths in powers of two keeps short
+        # contexts on the single-split path (no partials, no merge kernel).  The split
+        # boundaries stay at fixed absolute positions, so results do not depend on the bound.
+        self._ctx = self._ctx_bucket()
         if self.sampling:
             self._refresh_uniforms()
 
@@ -330,6 +365,7 @@ class SpecEngine:
         with torch.cuda.stream(self.stream):
             for b in range(self.active):
                 self.host_lens[b] += self.k + 1
+            self._steps_pending += 1
             return self._read_back()
 
     def _step(self, sync: bool) -> Optional[List[List[int]]]:
@@ -340,14 +376,11 @@ class SpecEngine:
         stream = torch.cuda.current_stream().cuda_stream
         lib = _lib.load()
         if self.cfg.use_graph:
-            key = (B, k, self.truth is not None)
-            if self._graph is None or self._graph_key != key:
-                if self._graph is not None:
-                    lib.sd_graph_destroy(self._graph)
-                    self._graph = None
+            key = (B, k, self.truth is not None, self._ctx)
+            g = self._graphs.get(key)
+            if g is None:
                 self._enqueue_step()          # eager warm-up step (also a real step)
                 torch.cuda.synchronize()
-                self._graph_key = key
                 g = C.c_void_p()
                 _lib.check(lib.sd_graph_begin(stream), "sd_graph_begin")
                 try:
@@ -355,17 +388,32 @@ class SpecEngine:
                 finally:
                     rc = lib.sd_graph_end(stream, C.byref(g))
                 _lib.check(rc, "sd_graph_end")
-                self._graph = g
+                self._graphs[key] = g
                 # the captured step has not run: the warm-up step is this call's step
             else:
-                _lib.check(lib.sd_graph_launch(self._graph, stream), "sd_graph_launch")
+                _lib.check(lib.sd_graph_launch(g, stream), "sd_graph_launch")
         else:
             self._enqueue_step()
         for b in range(B):
             self.host_lens[b] += k + 1        # upper bound until the next read-back
+        self._steps_pending += 1
         if not sync:
             return None
         return self._read_back()
+
+    def _ctx_bucket(self, need: Optional[int] = None) -> int:
+        if need is None:
+            need = max(self.host_lens[:max(self.active, 1)]) + self.k + 2
+        bound = self.cfg.split_tokens
+        while bound < need:
+            bound *= 2
+        return min(bound, self.max_ctx)
+
+    def _drop_graphs(self) -> None:
+        lib = _lib.load()
+        for g in self._graphs.values():
+            lib.sd_graph_destroy(g)
+        self._graphs.clear()
 
     def read_back(self) -> List[List[int]]:
         """Synchronises and returns the tokens emitted since the last read-back."""
@@ -374,6 +422,18 @@ class SpecEngine:
 
     def _read_back(self) -> List[List[int]]:
         B = self.active
+        pending, self._steps_pending = self._steps_pending, 0
+        if pending == 1:
+            # the step's last kernel left its record in pinned host memory
+            torch.cuda.current_stream().synchronize()
+            rec = self.step_out[:B].tolist()
+            out = []
+            for b in range(B):
+                n = rec[b][0]
+                out.append(rec[b][2:2 + n])
+                self.host_gen[b] += n
+                self.host_lens[b] = rec[b][1]
+            return out
         counts = self.gen_counts[:B].tolist()
         lens = self.seq_lens[:B].tolist()
         out: List[List[int]] = []

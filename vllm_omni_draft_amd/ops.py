@@ -261,13 +261,47 @@ def gather_proposals(tok_buf, draft_ids, k) -> None:
                                                _stream()), "sd_gather_proposals")
 
 
-def advance_state(out_ids, seq_lens, tok_buf, gen_tokens, gen_counts, k) -> None:
+def advance_state(out_ids, seq_lens, tok_buf, gen_tokens, gen_counts, k, step_out=None) -> None:
+    """step_out: optional int32 [B, k+3] record {n_emitted, seq_len, tokens}; may be a
+    pinned host tensor."""
     B = seq_lens.shape[0]
     _lib.check(_lib.load().sd_advance_state(
         _p(out_ids), _p(seq_lens), _p(tok_buf), _p(gen_tokens),
         0 if gen_tokens is None else gen_tokens.shape[1],
-        0 if gen_tokens is None else gen_tokens.shape[1], _p(gen_counts), B, k, _stream()),
-        "sd_advance_state")
+        0 if gen_tokens is None else gen_tokens.shape[1], _p(gen_counts), _p(step_out), B, k,
+        _stream()), "sd_advance_state")
+
+
+ARGMAX_PARTS = 64
+
+
+def argmax_partial(logits, part_val, part_idx) -> None:
+    """Stage 1 of the split row argmax over logits [R, V] f32."""
+    _need(logits, torch.float32, "logits")
+    R, V = logits.shape
+    if part_val.numel() < R * ARGMAX_PARTS or part_idx.numel() < R * ARGMAX_PARTS:
+        raise _lib.SdError("argmax_partial: partial buffers too small")
+    _lib.check(_lib.load().sd_argmax_partial(_p(logits), logits.stride(0), _p(part_val),
+                                             _p(part_idx), R, V, _stream()), "sd_argmax_partial")
+
+
+def propose_from_partials(part_val, part_idx, row_offset, row_step, tok_buf, k, step, seq_lens,
+                          truth=None, accept_prob=0.0, seed=0) -> None:
+    B = tok_buf.shape[0]
+    _lib.check(_lib.load().sd_propose_from_partials(
+        _p(part_val), _p(part_idx), row_offset, row_step, _p(tok_buf), k, step, _p(seq_lens),
+        _p(truth), 0 if truth is None else truth.shape[1], float(accept_prob),
+        int(seed) & 0xFFFFFFFF, B, _stream()), "sd_propose_from_partials")
+
+
+def verify_from_partials(part_val, part_idx, tok_buf, out_ids, counters, seq_lens, gen_tokens,
+                         gen_counts, k, step_out=None, proposal_lens=None) -> None:
+    B = seq_lens.shape[0]
+    _lib.check(_lib.load().sd_verify_from_partials(
+        _p(part_val), _p(part_idx), _p(tok_buf), _p(proposal_lens), _p(out_ids), _p(counters),
+        _p(seq_lens), _p(gen_tokens), 0 if gen_tokens is None else gen_tokens.shape[1],
+        0 if gen_tokens is None else gen_tokens.shape[1], _p(gen_counts), _p(step_out), B, k,
+        _stream()), "sd_verify_from_partials")
 
 
 def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None,
