@@ -5,7 +5,8 @@ CSRC  := vllm_omni_draft_amd/csrc
 SRCS  := $(CSRC)/sd_runtime.hip $(CSRC)/sd_sampling.hip $(CSRC)/sd_linear.hip $(CSRC)/sd_attention.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vllm_omni_draft_amd/libsd_amd.so
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+EXTRA ?=
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(EXTRA)
 
 all: $(LIB)
 

@@ -19,6 +19,7 @@ stream = torch.cuda.Stream()
 
 
 def graph_time(enqueue, reps=5):
+    torch.cuda.synchronize()  # inputs were filled on the default stream
     with torch.cuda.stream(stream):
         enqueue()
         torch.cuda.synchronize()

@@ -27,7 +27,7 @@ def load(path):
 def main():
     rows = load(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    idx = [i for i, r in enumerate(rows) if "advance_state" in r["name"]]
+    idx = [i for i, r in enumerate(rows) if "advance_state" in r["name"] or "verify_from_partials" in r["name"]]
     a, b = idx[-1 - back], idx[-back]
     seg = rows[a + 1:b + 1]
     t0, t1 = seg[0]["start"], seg[-1]["end"]

@@ -44,8 +44,18 @@ struct AttnArgs {
   float* part_ml;  // [B, Hkv, n_splits, MT*32, 2]
 };
 
-template <int D, int MT, int NBUF>
+#ifdef SD_ATTN_STAMPS
+__device__ unsigned long long sd_stamps[16];
+#define STAMP(i)                                                              \
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+  sd_stamps[i] = wall_clock64()
+#else
+#define STAMP(i)
+#endif
+
+template <int D, int MT, int NBUF, int BT_PER_THREAD, bool RELOAD>
 __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
+  STAMP(0);
   constexpr int KS = D / 16;  // k-steps of the K.Q^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
   constexpr int LDM = 33;     // padded m-stride of the LDS merge image
@@ -53,33 +63,39 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
   float* sm_o = reinterpret_cast<float*>(smem_raw);          // [4][MT][D][LDM]
   float* sm_m = sm_o + 4 * MT * D * LDM;                      // [4][MT][32]
   float* sm_l = sm_m + 4 * MT * 32;                           // [4][MT][32]
+  float* sm_w = sm_l + 4 * MT * 32;                           // [MT*32][4] wave weights
+  float* sm_mx = sm_w + MT * 32 * 4;                          // [MT*32] row maximum
+  float* sm_lt = sm_mx + MT * 32;                             // [MT*32] row sum
+  int32_t* sm_bt = reinterpret_cast<int32_t*>(sm_lt + MT * 32);  // block-table slice
 
   const int tid = threadIdx.x, lane = tid & 63;
-  // The wave index is made provably uniform so that block-table lookups are scalar loads:
-  // a vector load there would sit behind the K/V loads in the in-order load counter and
-  // force the whole ring to drain before the next address is known.
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
   const int G = a.Hq / a.Hkv;
   const int m_rows = a.q_len * G;
-  const int pos0 = a.seq_lens[b] + a.pos_offset;
-  const int kv_len = pos0 + a.q_len;
   const int split_start = split * a.split_tokens;
-  if (split_start >= kv_len) return;
-  const int split_end = min(split_start + a.split_tokens, kv_len);
-  const int last_page = (kv_len - 1) >> 4;
-  const int32_t* bt = a.block_tables + (size_t)b * a.max_blocks;
 
+  // Everything whose address does not depend on the sequence length is requested at
+  // once: the split's slice of the block table (entries past the sequence's last page are
+  // read but never used), the Q^T fragments, and the length itself.  A block-table load
+  // issued later, beside the K/V stream, would sit behind it in the in-order load counter.
+  const int32_t* bt = a.block_tables + (size_t)b * a.max_blocks;
+  const int page0 = split_start >> 4;
+  const int n_bt = a.split_tokens / 16 + 8 * NBUF;
+  int32_t bt_reg[BT_PER_THREAD];
+#pragma unroll
+  for (int i = 0; i < BT_PER_THREAD; ++i) {
+    const int e = tid + i * 256;
+    bt_reg[i] = e < n_bt ? bt[min(page0 + e, a.max_blocks - 1)] : 0;
+  }
   // Q^T fragments (B operand): lane (r, h) holds Q[m = r][16s + 8h .. +8].
   bf16x8 qf[MT][KS];
-  int kvlen_m[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mt * 32 + r;
     const bool valid = m < m_rows;
     const int t = valid ? m / G : 0, g = valid ? m % G : 0;
-    kvlen_m[mt] = valid ? pos0 + t + 1 : 0;
     const bf16_t* qrow = a.q + (size_t)(b * a.q_len + t) * a.ldq + (size_t)(kvh * G + g) * D;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -88,7 +104,26 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
       qf[mt][s] = v;
     }
   }
+  const int pos0 = a.seq_lens[b] + a.pos_offset;
+  const int kv_len = pos0 + a.q_len;
+  if (split_start >= kv_len) return;
+  STAMP(1);
+  const int split_end = min(split_start + a.split_tokens, kv_len);
+  const int last_page = (kv_len - 1) >> 4;
+  int kvlen_m[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 32 + r;
+    kvlen_m[mt] = m < m_rows ? pos0 + m / G + 1 : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < BT_PER_THREAD; ++i) {
+    const int e = tid + i * 256;
+    if (e < n_bt) sm_bt[e] = bt_reg[i];
+  }
+  __syncthreads();
 
+  STAMP(2);
   f32x16 o_acc[MT][DT];
   float m_run[MT], l_run[MT];
 #pragma unroll
@@ -113,10 +148,15 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
   // load sequence branch-free and the wait counts exact.
   bf16x8 kf[NBUF][KS], vf[NBUF][2][DT];
   const bf16x8* dummy = reinterpret_cast<const bf16x8*>(a.kc);
+  // Page of a live tile: its first page always belongs to the sequence; a second page
+  // past the last one holds only masked keys, so the first stands in for it.
+  auto page_of = [&](int tile, int second) {
+    const int pg = tile * 2 + (second && tile * 2 + 1 <= last_page ? 1 : 0);
+    return sm_bt[pg - page0];
+  };
   auto load_k = [&](bf16x8(&dst)[KS], int tile) {
     const bool in = tile * 32 < split_end;
-    const int blkA = bt[min(tile * 2, last_page)], blkB = bt[min(tile * 2 + 1, last_page)];
-    const int blk = (r >> 4) ? blkB : blkA;
+    const int blk = in ? page_of(tile, r >> 4) : 0;
     const bf16_t* kpage = a.kc + ((size_t)blk * a.Hkv + kvh) * page_elems;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
@@ -129,7 +169,7 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
     const bool in = tile * 32 < split_end;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const int blk = bt[min(tile * 2 + s, last_page)];
+      const int blk = in ? page_of(tile, s) : 0;
       const bf16_t* vpage = a.vc + ((size_t)blk * a.Hkv + kvh) * page_elems;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
@@ -144,6 +184,7 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
     load_k(kf[u], tile0 + 4 * u);
     load_v(vf[u], tile0 + 4 * u);
   }
+  STAMP(3);
   for (int base = tile0; base * 32 < split_end; base += 4 * NBUF) {
 #pragma unroll
     for (int u = 0; u < NBUF; ++u) {
@@ -185,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
           l_run[mt] = l_run[mt] * alpha + psum;
           m_run[mt] = m_new;
         }
-        if (mt == MT - 1) load_k(kf[u], tile + 4 * NBUF);
+        if (RELOAD && mt == MT - 1) load_k(kf[u], tile + 4 * NBUF);
         if (live) {
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
@@ -198,10 +239,11 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
           }
         }
       }
-      load_v(vf[u], tile + 4 * NBUF);
+      if (RELOAD) load_v(vf[u], tile + 4 * NBUF);
     }
   }
 
+  STAMP(4);
   // Publish this wave's (m, l, O^T) to LDS; merge the 4 waves in index order.
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -221,45 +263,56 @@ __global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
   }
   __syncthreads();
 
+  STAMP(5);
   const bool direct = a.n_splits == 1;
   const size_t part_base = ((size_t)(b * a.Hkv + kvh) * a.n_splits + split) * (MT * 32);
-  // TPR threads share a query row: the row's four wave weights are computed once,
-  // then each thread walks its d values with independent LDS reads.
-  constexpr int TPR = 256 / (MT * 32);
-  const int m = tid / TPR;  // 0 .. MT*32-1
-  const int mt = m >> 5, mr = m & 31;
-  float wgt[4];
-  float mx = -INFINITY;
+  // Per query row: the four wave weights, the row maximum and the row sum.
+  if (tid < MT * 32) {
+    const int mt = tid >> 5, mr = tid & 31;
+    float wgt[4];
+    float mx = -INFINITY;
 #pragma unroll
-  for (int ww = 0; ww < 4; ++ww) {
-    wgt[ww] = sm_m[(ww * MT + mt) * 32 + mr];
-    mx = fmaxf(mx, wgt[ww]);
-  }
-  float l = 0.f;
+    for (int ww = 0; ww < 4; ++ww) {
+      wgt[ww] = sm_m[(ww * MT + mt) * 32 + mr];
+      mx = fmaxf(mx, wgt[ww]);
+    }
+    float l = 0.f;
 #pragma unroll
-  for (int ww = 0; ww < 4; ++ww) {
-    wgt[ww] = (mx == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(wgt[ww] - mx);
-    l += wgt[ww] * sm_l[(ww * MT + mt) * 32 + mr];
+    for (int ww = 0; ww < 4; ++ww) {
+      wgt[ww] = (mx == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(wgt[ww] - mx);
+      l += wgt[ww] * sm_l[(ww * MT + mt) * 32 + mr];
+      sm_w[tid * 4 + ww] = wgt[ww];
+    }
+    sm_mx[tid] = mx;
+    sm_lt[tid] = l;
+    if (!direct && tid < m_rows) {
+      a.part_ml[(part_base + tid) * 2 + 0] = mx;
+      a.part_ml[(part_base + tid) * 2 + 1] = l;
+    }
   }
-  const bool row_live = m < m_rows;
-  const int t = row_live ? m / G : 0, g = row_live ? m % G : 0;
-  bf16_t* orow = a.out + (size_t)(b * a.q_len + t) * a.ldo + (size_t)(kvh * G + g) * D;
+  __syncthreads();
+  // Live rows only; a thread keeps one d and walks rows 256/D apart.  The waves are added
+  // in index order.
+  constexpr int RP = 256 / D;
+  const int d = tid % D;
 #pragma unroll 4
-  for (int d = tid % TPR; d < D; d += TPR) {
+  for (int m = tid / D; m < m_rows; m += RP) {
+    const int mt = m >> 5, mr = m & 31;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(sm_w + m * 4);
     float o = 0.f;
 #pragma unroll
     for (int ww = 0; ww < 4; ++ww)
-      o += wgt[ww] * sm_o[((size_t)(ww * MT + mt) * D + d) * LDM + mr];
+      o += wv[ww] * sm_o[((size_t)(ww * MT + mt) * D + d) * LDM + mr];
     if (direct) {
-      if (row_live) orow[d] = (bf16_t)(l > 0.f ? o / l : 0.f);
+      const float l = sm_lt[m];
+      const int t = m / G, g = m % G;
+      a.out[(size_t)(b * a.q_len + t) * a.ldo + (size_t)(kvh * G + g) * D + d] =
+          (bf16_t)(l > 0.f ? o / l : 0.f);
     } else {
       a.part_o[(part_base + m) * D + d] = o;
     }
   }
-  if (!direct && tid % TPR == 0) {
-    a.part_ml[(part_base + m) * 2 + 0] = mx;
-    a.part_ml[(part_base + m) * 2 + 1] = l;
-  }
+  STAMP(6);
 }
 
 // Merges the per-split partials of one (sequence, token, head) in split order.
@@ -334,29 +387,28 @@ __global__ __launch_bounds__(256) void rope_append_kernel(
   }
 }
 
-template <int D, int MT>
-size_t attn_lds_bytes() {
-  return (size_t)(4 * MT * D * 33 + 2 * 4 * MT * 32) * sizeof(float);
+template <int D, int MT, int NBUF>
+size_t attn_lds_bytes(int split_tokens) {
+  const size_t floats = (size_t)4 * MT * D * 33 + 2 * 4 * MT * 32 + MT * 32 * 6;
+  return floats * sizeof(float) + (size_t)(split_tokens / 16 + 8 * NBUF) * sizeof(int32_t);
 }
 
-template <int D, int MT>
-int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
-  const size_t lds = attn_lds_bytes<D, MT>();
-  // Ring depth: as many 32-key tiles in flight per wave as the register file allows.
-  constexpr int NBUF = D == 64 ? 4 : (MT == 1 ? 3 : 2);
+template <int D, int MT, int NBUF, int BTP, bool RELOAD>
+int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
+  const size_t lds = attn_lds_bytes<D, MT, NBUF>(a.split_tokens);
   static bool attr_set = false;  // raise the dynamic-LDS limit once per process
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(paged_attn_kernel<D, MT, NBUF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
-      sd_set_error("sd_paged_attention: hipFuncSetAttribute(%zu) failed: %s", lds,
-                   hipGetErrorString(e));
+      sd_set_error("sd_paged_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return SD_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF>), dim3(a.Hkv, a.n_splits, B), dim3(256), lds,
-                     stream, a);
+  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>), dim3(a.Hkv, a.n_splits, B), dim3(256),
+                     lds, stream, a);
   SD_CHECK_LAUNCH("sd_paged_attention");
   if (a.n_splits > 1) {
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(a.Hq, a.q_len, B), dim3(D), 0, stream, a,
@@ -366,11 +418,39 @@ int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
   return SD_OK;
 }
 
+template <int D, int MT>
+int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
+  // Ring depth: as many 32-key tiles in flight per wave as the register file allows.
+  constexpr int NBUF = D == 64 ? 4 : (MT == 1 ? 3 : 2);
+  // A split of at most NBUF tiles per wave is loaded whole, with no ring to keep turning.
+  const int tiles_per_wave = a.split_tokens / 128;
+  if (tiles_per_wave == 1) return launch_attn_bt<D, MT, 1, 1, false>(a, B, stream);
+  if (tiles_per_wave == 2) return launch_attn_bt<D, MT, 2, 1, false>(a, B, stream);
+  if constexpr (NBUF >= 3) {
+    if (tiles_per_wave == 3) return launch_attn_bt<D, MT, 3, 1, false>(a, B, stream);
+  }
+  if constexpr (NBUF >= 4) {
+    if (tiles_per_wave == 4) return launch_attn_bt<D, MT, 4, 1, false>(a, B, stream);
+  }
+  // block-table entries staged per thread: 1 covers splits up to ~3.5k keys
+  const int n_bt = a.split_tokens / 16 + 8 * NBUF;
+  if (n_bt <= 256) return launch_attn_bt<D, MT, NBUF, 1, true>(a, B, stream);
+  if (n_bt <= 1024) return launch_attn_bt<D, MT, NBUF, 4, true>(a, B, stream);
+  sd_set_error("sd_paged_attention: split_tokens %d too large", a.split_tokens);
+  return SD_ERR_UNSUPPORTED;
+}
+
 int n_splits_for(int max_ctx, int split_tokens) {
   return max(1, (max_ctx + split_tokens - 1) / split_tokens);
 }
 
 }  // namespace
+
+#ifdef SD_ATTN_STAMPS
+extern "C" int sd_debug_read_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sd_stamps), sizeof(sd_stamps));
+}
+#endif
 
 extern "C" size_t sd_paged_attention_workspace_bytes(int B, int q_len, int Hq, int D,
                                                      int max_ctx, int split_tokens) {
@@ -399,8 +479,9 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
   const int G = Hq / Hkv;
   SD_REQUIRE(q_len * G <= 64, SD_ERR_UNSUPPORTED,
              "sd_paged_attention: q_len*(Hq/Hkv) = %d > 64", q_len * G);
-  SD_REQUIRE(split_tokens >= 128 && split_tokens % 128 == 0, SD_ERR_INVALID,
-             "sd_paged_attention: split_tokens %d must be a positive multiple of 128",
+  SD_REQUIRE(split_tokens >= 128 && split_tokens % 128 == 0 && split_tokens <= 15872,
+             SD_ERR_INVALID,
+             "sd_paged_attention: split_tokens %d must be a multiple of 128 in 128..15872",
              split_tokens);
   SD_REQUIRE(max_ctx >= 1 && max_blocks_per_seq * 16 >= max_ctx, SD_ERR_INVALID,
              "sd_paged_attention: max_ctx %d exceeds block table (%d pages)", max_ctx,
