@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // Error text is per host thread; set by the launch wrappers.
 void sd_set_error(const char* fmt, ...);
+// True if sd_norm_linear / sd_norm_qkv_rope can hold M normalised rows of K columns in LDS.
+bool sd_fused_norm_fits(int M, int K, bool layer_norm);
 
 #define SD_REQUIRE(cond, code, ...)            \
   do {                                         \

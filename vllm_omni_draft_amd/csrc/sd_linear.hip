@@ -10,14 +10,13 @@
 // an MFMA operand as it lands (no LDS round trip, no cross-lane reduction, no
 // VALU multiply work: the kernel is a pure HBM stream).
 //
-// linear_kernel: a workgroup of 8 waves stages the (optionally normalised)
-// activations x[M][K-chunk] in LDS once and walks a strided list of 16-row
-// output tiles.  K is cut into segments of 8 k-steps (256 columns); segment j
+// linear_kernel: a workgroup of 8 waves walks a strided list of 16-row output
+// tiles; with a fused norm it first stages the normalised activations x[M][K] in
+// LDS, otherwise its lanes read their activation fragments from global memory.  K is cut into segments of 8 k-steps (256 columns); segment j
 // always belongs to wave j % 8, which chains its segments in increasing order
 // into one accumulator tile; the 8 wave tiles are then added in wave order
 // through LDS.  That order is a function of K alone, so a token row gets the
-// same bits whether it runs alone (decode) or beside k other rows (verify),
-// whatever the chunking of x.
+// same bits whether it runs alone (decode) or beside k other rows (verify).
 #include "sd_common.h"
 
 namespace {
@@ -54,7 +53,7 @@ struct LinArgs {
   const bf16_t* residual;
   void* out;
   int64_t ldo;
-  int M, N, K, KC;         // N: output columns; KC: K-chunk staged in LDS (multiple of 256)
+  int M, N, K, KC;         // N: output columns; KC: K padded to whole 256-column segments
   int n_tiles;             // 16-row weight tiles
   const bf16_t* norm_w;    // fused norm parameters
   const bf16_t* norm_b;
@@ -65,8 +64,17 @@ struct LinArgs {
 // HALF: a work unit is 8 of a tile's 16 rows (lanes of the other 8 rows load nothing and
 // feed zeros), so a matrix with fewer than 256 tiles still spreads over every CU.  A
 // row's arithmetic is the same as in a whole-tile unit.
+#ifdef SD_LIN_STAMPS
+__device__ unsigned long long sd_lin_stamps[16];
+#define LSTAMP(i) \
+  if (blockIdx.x == 0 && threadIdx.x == 0) sd_lin_stamps[i] = wall_clock64()
+#else
+#define LSTAMP(i)
+#endif
+
 template <int EPI, int NORM, bool HALF>
 __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
+  LSTAMP(0);
   constexpr bool GATED = EPI == SD_EPI_SILU_MUL;
   constexpr bool QKV = EPI == EPI_QKV_ROPE;
   // Without a norm the activations need no staging: each lane loads its B-operand
@@ -83,9 +91,6 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   const int M = a.M;
   const int KS = a.K / 32;                         // k-steps in total
   const int n_seg = (KS + kSeg - 1) / kSeg;        // segments in total
-  const int SC = a.KC / (32 * kSeg);               // segments per chunk
-  const int n_chunks = (n_seg + SC - 1) / SC;
-  const bool single = n_chunks == 1;
 
   // zero row: B-operand lanes of token rows >= M read it
   if (!DIRECT)
@@ -121,42 +126,92 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
       }
     }
   };
-  // Stages x[:, kc0 : kc0 + kc_len] (normalised if asked) into LDS; all threads.
-  auto stage_x = [&](int kc0, int kc_len) {
-    if (NORM == NORM_NONE) {
-      for (int i = tid * 8; i < M * kc_len; i += kLinThreads * 8) {
-        const int m = i / kc_len, c = i - m * kc_len;
-        *reinterpret_cast<bf16x8*>(xs + (size_t)m * LDX + c) =
-            *reinterpret_cast<const bf16x8*>(a.x + (size_t)m * a.ldx + kc0 + c);
-      }
-    } else {  // single chunk: whole rows (K == hidden size); wave w normalises rows w, w + 8
-      for (int m = wave; m < M; m += kLinWaves) {
+  // Fused norm, part 1 (before any weight load is issued: loads return in issue order, so
+  // x asked for behind a weight segment would wait for it).  All of the staging's global
+  // loads go out together: this thread's pieces of the norm weight (and bias), and the
+  // wave's row in 4096-column pieces, which is summed and parked raw in LDS.  The norm
+  // parameters sit in the cross-wave sum buffer, unused until the first tile ends.
+  bf16_t* gs = reinterpret_cast<bf16_t*>(red);
+  bf16_t* bs = gs + a.K;  // LayerNorm only
+  float rs_m[2] = {0.f, 0.f}, mean_m[2] = {0.f, 0.f};  // rows wave, wave + 8
+  if (!DIRECT) {
+    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 g_pre[2], b_pre[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid * 8 + i * kLinThreads * 8;
+      g_pre[i] = c < a.K ? *reinterpret_cast<const bf16x8*>(a.norm_w + c) : z;
+      b_pre[i] = (NORM == NORM_LAYER && c < a.K && a.norm_b)
+                     ? *reinterpret_cast<const bf16x8*>(a.norm_b + c) : z;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int m = wave + rr * kLinWaves;
+      if (m < M) {
         const bf16_t* xr = a.x + (size_t)m * a.ldx;
-        float mean = 0.f;
+        bf16_t* xl = xs + (size_t)m * LDX;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c0 = 0; c0 < a.K; c0 += 4096) {
+          bf16x8 v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i * 512 + lane * 8;
+            v[i] = c < a.K ? *reinterpret_cast<const bf16x8*>(xr + c) : z;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int c = c0 + i * 512 + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float f = (float)v[i][j];
+              s1 += f;
+              s2 += f * f;
+            }
+            if (c < a.K) *reinterpret_cast<bf16x8*>(xl + c) = v[i];
+          }
+        }
         if (NORM == NORM_LAYER) {
-          float s = 0.f;
+          // variance around the mean, from the parked values (same-wave LDS round trip)
+          const float mean = wave_sum(s1) / (float)a.K;
+          float ss = 0.f;
           for (int c = lane * 8; c < a.K; c += 512) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xl + c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += (float)v[j];
+            for (int j = 0; j < 8; ++j) {
+              const float f = (float)v[j] - mean;
+              ss += f * f;
+            }
           }
-          mean = wave_sum(s) / (float)a.K;
+          mean_m[rr] = mean;
+          rs_m[rr] = rsqrtf(wave_sum(ss) / (float)a.K + a.eps);
+        } else {
+          rs_m[rr] = rsqrtf(wave_sum(s2) / (float)a.K + a.eps);
         }
-        float ss = 0.f;
-        for (int c = lane * 8; c < a.K; c += 512) {
-          const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
+      }
+    }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float f = (float)v[j] - mean;
-            ss += f * f;
-          }
-        }
-        const float rs = rsqrtf(wave_sum(ss) / (float)a.K + a.eps);
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid * 8 + i * kLinThreads * 8;
+      if (c < a.K) {
+        *reinterpret_cast<bf16x8*>(gs + c) = g_pre[i];
+        if (NORM == NORM_LAYER) *reinterpret_cast<bf16x8*>(bs + c) = b_pre[i];
+      }
+    }
+  }
+  // Part 2, while the first weight segment is in flight: scale the parked rows in place.
+  auto finish_norm = [&]() {
+    __syncthreads();  // norm parameters are in LDS
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int m = wave + rr * kLinWaves;
+      if (m < M) {
+        bf16_t* xl = xs + (size_t)m * LDX;
+        const float rs = rs_m[rr], mean = mean_m[rr];
         for (int c = lane * 8; c < a.K; c += 512) {
-          const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
-          const bf16x8 g = *reinterpret_cast<const bf16x8*>(a.norm_w + c);
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(xl + c);
+          const bf16x8 g = *reinterpret_cast<const bf16x8*>(gs + c);
           bf16x8 bb = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (NORM == NORM_LAYER && a.norm_b) bb = *reinterpret_cast<const bf16x8*>(a.norm_b + c);
+          if (NORM == NORM_LAYER) bb = *reinterpret_cast<const bf16x8*>(bs + c);
           bf16x8 o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -165,10 +220,11 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
             else
               o[j] = (bf16_t)(((float)v[j] - mean) * rs * (float)g[j] + (float)bb[j]);
           }
-          *reinterpret_cast<bf16x8*>(xs + (size_t)m * LDX + c) = o;
+          *reinterpret_cast<bf16x8*>(xl + c) = o;
         }
       }
     }
+    __syncthreads();
   };
 
   const int n_units = HALF ? 2 * a.n_tiles : a.n_tiles;
@@ -180,10 +236,9 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
 #pragma unroll
     for (int j = 0; j < kSeg; ++j) nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
-  if (!DIRECT) {
-    if (single) stage_x(0, a.K);
-    __syncthreads();
-  }
+  LSTAMP(1);
+  if (!DIRECT) finish_norm();
+  LSTAMP(2);
 
   int parity = 0;
   // Epilogue role of this thread (waves 0..3): element e = tid of the summed tile is
@@ -233,39 +288,30 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         }
       }
     }
-    for (int chunk = 0; chunk < n_chunks; ++chunk) {
-      const int seg_lo = chunk * SC, seg_hi = min(seg_lo + SC, n_seg);
-      if (!DIRECT && !single) {
-        const int kc0 = seg_lo * kSeg * 32;
-        stage_x(kc0, min(a.KC, a.K - kc0));
-        __syncthreads();
+    // this wave's segments: the j with j % 8 == wave, in increasing order
+    for (int seg = wave; seg < n_seg; seg += kLinWaves) {
+      bf16x8 cur[kSeg];
+#pragma unroll
+      for (int j = 0; j < kSeg; ++j) cur[j] = nxt[j];
+      bf16x8 cur_x[DIRECT ? kSeg : 1];
+      if (DIRECT) {
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) cur_x[DIRECT ? j : 0] = nxt_x[DIRECT ? j : 0];
       }
-      // this wave's segments inside the chunk: the j in [seg_lo, seg_hi) with j % 8 == wave
-      int seg = seg_lo + ((wave - seg_lo) % kLinWaves + kLinWaves) % kLinWaves;
-      for (; seg < seg_hi; seg += kLinWaves) {
-        bf16x8 cur[kSeg];
+      if (seg + kLinWaves < n_seg) load_seg(tile, seg + kLinWaves);
+      else if (next_unit < n_units) load_seg(tile_of(next_unit), wave);
+      const bf16_t* xp = xrow + (size_t)seg * kSeg * 32;
 #pragma unroll
-        for (int j = 0; j < kSeg; ++j) cur[j] = nxt[j];
-        bf16x8 cur_x[DIRECT ? kSeg : 1];
-        if (DIRECT) {
-#pragma unroll
-          for (int j = 0; j < kSeg; ++j) cur_x[DIRECT ? j : 0] = nxt_x[DIRECT ? j : 0];
-        }
-        if (seg + kLinWaves < n_seg) load_seg(tile, seg + kLinWaves);
-        else if (next_unit < n_units) load_seg(tile_of(next_unit), wave);
-        const bf16_t* xp = xrow + (size_t)(seg - seg_lo) * kSeg * 32;
-#pragma unroll
-        for (int j = 0; j < kSeg; ++j) {
-          if (seg * kSeg + j < KS) {
-            const bf16x8 b = DIRECT ? cur_x[DIRECT ? j : 0]
-                                    : *reinterpret_cast<const bf16x8*>(xp + j * 32);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], b, acc, 0, 0, 0);
-          }
+      for (int j = 0; j < kSeg; ++j) {
+        if (seg * kSeg + j < KS) {
+          const bf16x8 b = DIRECT ? cur_x[DIRECT ? j : 0]
+                                  : *reinterpret_cast<const bf16x8*>(xp + j * 32);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], b, acc, 0, 0, 0);
         }
       }
-      if (!DIRECT && !single && chunk + 1 < n_chunks) __syncthreads();  // LDS is restaged next
     }
 
+    LSTAMP(3);
     // add the 8 wave tiles in wave order
     float* rbuf = red + parity * kLinWaves * 256;
     *reinterpret_cast<f32x4*>(rbuf + wave * 256 + lane * 4) = acc;
@@ -335,34 +381,33 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         }
       }
     }
+    LSTAMP(4);
     // No barrier here: the next tile writes the other half of `red`, and no wave
     // can get two tiles ahead of a reader because of the barrier above.
   }
 }
 
 // ------------------------------------------------------------------ launch
-constexpr size_t kXBudget = 80 * 1024;       // LDS bytes for staged x (chunked beyond this)
-constexpr size_t kXBudgetNorm = 128 * 1024;  // a fused norm needs whole rows
+constexpr size_t kXBudgetNorm = 144 * 1024;  // a fused norm needs whole rows
 
-size_t lin_lds_bytes(int M, int KC, bool direct) {
-  return (direct ? 0 : (size_t)(M + 1) * (KC + kXPad) * 2) + (size_t)2 * kLinWaves * 256 * 4;
+constexpr size_t kRedBytes = (size_t)2 * kLinWaves * 256 * 4;  // cross-wave sum buffer
+
+size_t lin_lds_bytes(int M, int KC, int norm) {
+  return (norm == NORM_NONE ? 0 : (size_t)(M + 1) * (KC + kXPad) * 2) + kRedBytes;
 }
 
-// Chooses the K-chunk (a whole number of 256-column segments); 0 if a fused
-// norm cannot hold x in LDS.
-int choose_kc(int M, int K, bool norm) {
+// K padded to whole 256-column segments if the rows of a fused norm fit in LDS, else 0.
+int choose_kc(int M, int K, int norm) {
   const int kpad = (K + 255) / 256 * 256;
   const size_t whole = (size_t)(M + 1) * (kpad + kXPad) * 2;
-  if (whole <= kXBudget) return kpad;
-  if (norm) return whole <= kXBudgetNorm ? kpad : 0;
-  const int kc_max = ((int)(kXBudget / ((size_t)(M + 1) * 2)) - kXPad) / 256 * 256;
-  const int n_chunks = (kpad + kc_max - 1) / kc_max;
-  return ((kpad / 256 + n_chunks - 1) / n_chunks) * 256;
+  // the norm weight (and LayerNorm bias) are staged in the sum buffer
+  const size_t params = (size_t)K * 2 * (norm == NORM_LAYER ? 2 : 1);
+  return whole <= kXBudgetNorm && params <= kRedBytes ? kpad : 0;
 }
 
 template <int EPI, int NORM, bool HALF>
 int launch_half(LinArgs& a, hipStream_t st) {
-  const size_t lds = lin_lds_bytes(a.M, a.KC, NORM == NORM_NONE);
+  const size_t lds = lin_lds_bytes(a.M, a.KC, NORM);
   static bool attr_set = false;  // once per instantiation and process
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM, HALF>),
@@ -424,9 +469,9 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
              "sd_linear: residual epilogue without residual pointer");
   SD_REQUIRE(norm == NORM_NONE || a.norm_w, SD_ERR_INVALID, "sd_linear: fused norm without weight");
   if (a.M == 0) return SD_OK;
-  a.KC = norm == NORM_NONE ? (a.K + 255) / 256 * 256 : choose_kc(a.M, a.K, true);
+  a.KC = norm == NORM_NONE ? (a.K + 255) / 256 * 256 : choose_kc(a.M, a.K, norm);
   SD_REQUIRE(a.KC > 0, SD_ERR_UNSUPPORTED,
-             "sd_linear: fused norm needs (M+1)*K*2 <= %zu bytes of LDS (M=%d K=%d)", kXBudgetNorm,
+             "sd_linear: fused norm needs (M+1)*K*2 <= %zu bytes of LDS and K <= 8192 (LayerNorm: 4096) (M=%d K=%d)", kXBudgetNorm,
              a.M, a.K);
   switch (norm) {
     case NORM_NONE: return launch_n<NORM_NONE>(a, epi, st);
@@ -580,6 +625,16 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t* __restrict__ 
 int tiles_for(int N, int epi) { return epi == SD_EPI_SILU_MUL ? (N + 7) / 8 : (N + 15) / 16; }
 
 }  // namespace
+
+bool sd_fused_norm_fits(int M, int K, bool layer_norm) {
+  return choose_kc(M, K, layer_norm ? NORM_LAYER : NORM_RMS) > 0;
+}
+
+#ifdef SD_LIN_STAMPS
+extern "C" int sd_debug_read_lin_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sd_lin_stamps), sizeof(sd_lin_stamps));
+}
+#endif
 
 extern "C" size_t sd_tiled_weight_elems(int N, int K, int mode) {
   if (N < 1 || K < 32 || K % 32) return 0;

@@ -168,7 +168,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
     void* vc = (char*)kv->v_cache + (size_t)li * kv->layer_stride_bytes;
-    const bool fuse = (size_t)(rows + 1) * (H + 264) * 2 <= 128 * 1024;
+    const bool fuse = sd_fused_norm_fits(rows, H, !llama);
     if (fuse) {
       SD_TRY(sd_norm_qkv_rope(l.qkv_w, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
                               l.qkv_b, qkv, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos,
@@ -200,7 +200,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     SD_TRY(sd_linear(l.down_w, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL, stream));
   }
   if (a->logits) {
-    if ((size_t)(rows + 1) * (H + 264) * 2 <= 128 * 1024) {
+    if (sd_fused_norm_fits(rows, H, !llama)) {
       SD_TRY(sd_norm_linear(d.lm_head, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
                             nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, stream));
     } else {
