@@ -135,7 +135,13 @@ size_t sd_paged_attention_workspace_bytes(int B, int q_len, int Hq, int D,
  *   max_ctx       host upper bound of seq_lens[b] + pos_offset + q_len
  *   split_tokens  keys per workgroup (multiple of 128); results for a given
  *                 query depend on split_tokens but not on B, q_len or max_ctx
- * Supported: D in {64, 128}, q_len * (Hq/Hkv) <= 64.                        */
+ * Supported: D in {64, 128}, q_len * (Hq/Hkv) <= 64.
+ * With more than one split (max_ctx > split_tokens) the workspace receives the
+ * per-split partials: [B, Hkv, n_splits, m_pad, D] f32 un-normalised outputs,
+ * then [B, Hkv, n_splits, m_pad, 2] f32 (row max in log2 units, row sum), with
+ * m_pad = 32 if q_len*(Hq/Hkv) <= 32 else 64 and row t*(Hq/Hkv)+g for query
+ * token t, head g of the KV group; a merge launch then writes `out`.  out ==
+ * NULL skips that launch and leaves the partials to sd_linear_attn_merge.    */
 int sd_paged_attention(const void* q, int64_t ldq, const void* k_cache,
                        const void* v_cache, const int32_t* block_tables,
                        int max_blocks_per_seq, const int32_t* seq_lens,
@@ -190,6 +196,20 @@ typedef enum {
 int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
               const void* residual, void* out, int64_t ldo, int M, int N, int K,
               int epilogue, sd_stream_t stream);
+
+/* Output projection straight from attention partials: sd_paged_attention with
+ * out == NULL (and more than one split) leaves its per-split partials in the
+ * workspace; this linear merges them while it stages its activations (same
+ * arithmetic as the stand-alone merge) and applies W [N, Hq*D] (PLAIN tiles).
+ * Same B, q_len, heads, max_ctx and split_tokens as the attention call; at most
+ * 8 splits, B*q_len <= 16; epilogue STORE or RESIDUAL.  Every workgroup redoes
+ * the merge, so it pays only for few rows and splits (decode, short verify).  */
+int sd_linear_attn_merge(const void* W, const void* workspace,
+                         size_t workspace_bytes, const int32_t* seq_lens,
+                         int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
+                         int max_ctx, int split_tokens, const void* bias,
+                         const void* residual, void* out, int64_t ldo, int N,
+                         int epilogue, sd_stream_t stream);
 
 /* The same with a norm fused in front: x is first normalised per row (RMSNorm,
  * or LayerNorm when layer_norm != 0; norm_b may be NULL) exactly as sd_rmsnorm /

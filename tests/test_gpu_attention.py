@@ -145,3 +145,35 @@ def test_attention_rejects_unsupported_shapes():
         ops.paged_attention(z, kc, kc, bt, sl, 0, 1, 8, 64, 4, 64, 1.0, 8, 128)
     with pytest.raises(SdError):     # max_ctx beyond the block table
         ops.paged_attention(z, kc, kc, bt, sl, 0, 1, 1, 4, 1, 64, 1.0, 100, 128)
+
+
+@pytest.mark.parametrize("B,ctx_lens,q_len,Hq,Hkv,D,split,N", [
+    (1, [1100], 1, 32, 8, 64, 256, 2048),      # draft decode: 5 splits, half-tile projection
+    (2, [700, 129], 2, 32, 8, 64, 256, 2048),  # draft first pass, ragged
+    (1, [300], 1, 32, 8, 128, 128, 4096),      # target decode
+    (1, [40], 2, 12, 12, 64, 128, 768),        # two splits bound, one live (MHA)
+])
+def test_projection_from_partials_equals_merge_then_linear(B, ctx_lens, q_len, Hq, Hkv, D, split, N):
+    """Bit-exact: output projection fed by the attention partials == merge launch + linear."""
+    ops = _ops()
+    kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed=11 + q_len)
+    max_ctx = max(max(ctx_lens) + q_len, split + 1)
+    pad = max(0, (max_ctx + 15) // 16 - bt.shape[1])
+    bt = torch.cat([bt, torch.zeros(B, pad, dtype=torch.int32)], dim=1).contiguous()
+    kc, vc, btc = kc.cuda(), vc.cuda(), bt.cuda()
+    q = torch.cat(qs).reshape(B * q_len, Hq * D).cuda()
+    seq_lens = torch.tensor(ctx_lens, dtype=torch.int32).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(N)
+    W = ops.tile_weights((torch.randn(N, Hq * D, generator=gen, device="cuda") * 0.05).to(torch.bfloat16))
+    res = torch.randn(B * q_len, N, generator=gen, device="cuda").to(torch.bfloat16)
+    ws = torch.zeros(ops.paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx, split),
+                     dtype=torch.uint8, device="cuda")
+    attn = ops.paged_attention(q, kc, vc, btc, seq_lens, 0, B, q_len, Hq, Hkv, D, D ** -0.5, max_ctx,
+                               split, workspace=ws)
+    ref = ops.linear(W, attn, None, res, ops.EPI_RESIDUAL)
+    ws.fill_(0xFF)    # stale partials of inactive splits must not matter (NaN bit patterns)
+    assert ops.paged_attention(q, kc, vc, btc, seq_lens, 0, B, q_len, Hq, Hkv, D, D ** -0.5, max_ctx,
+                               split, workspace=ws, partials_only=True) is None
+    got = ops.linear_attn_merge(W, ws, seq_lens, 0, B, q_len, Hq, Hkv, D, max_ctx, split, None, res,
+                                ops.EPI_RESIDUAL)
+    assert torch.equal(got, ref)

@@ -80,6 +80,8 @@ SIGNATURES = {
     "sd_store_proposal": (i32, [vp, vp, i32, i32, vp, vp, i64, C.c_float, C.c_uint32, i32, vp]),
     "sd_gather_proposals": (i32, [vp, vp, i32, i32, vp]),
     "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
+    "sd_linear_attn_merge": (i32, [vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+                                   vp, vp, vp, i64, i32, i32, vp]),
     "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i64, C.c_float,
                                        C.c_uint32, i32, vp]),

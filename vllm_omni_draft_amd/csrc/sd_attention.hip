@@ -410,7 +410,7 @@ int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
   hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>), dim3(a.Hkv, a.n_splits, B), dim3(256),
                      lds, stream, a);
   SD_CHECK_LAUNCH("sd_paged_attention");
-  if (a.n_splits > 1) {
+  if (a.n_splits > 1 && a.out) {
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(a.Hq, a.q_len, B), dim3(D), 0, stream, a,
                        MT * 32);
     SD_CHECK_LAUNCH("sd_paged_attention(merge)");
@@ -470,7 +470,7 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
                                   int Hq, int Hkv, int D, float scale, int max_ctx,
                                   int split_tokens, void* workspace, size_t workspace_bytes,
                                   sd_stream_t stream) {
-  SD_REQUIRE(q && k_cache && v_cache && block_tables && seq_lens && out, SD_ERR_INVALID,
+  SD_REQUIRE(q && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
              "sd_paged_attention: null pointer");
   SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, SD_ERR_INVALID,
              "sd_paged_attention: bad head counts (Hq=%d Hkv=%d)", Hq, Hkv);
@@ -486,7 +486,7 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
   SD_REQUIRE(max_ctx >= 1 && max_blocks_per_seq * 16 >= max_ctx, SD_ERR_INVALID,
              "sd_paged_attention: max_ctx %d exceeds block table (%d pages)", max_ctx,
              max_blocks_per_seq);
-  SD_REQUIRE(ldq % 8 == 0 && sd_aligned16(q) && ldo >= (int64_t)Hq * D, SD_ERR_INVALID,
+  SD_REQUIRE(ldq % 8 == 0 && sd_aligned16(q) && (!out || ldo >= (int64_t)Hq * D), SD_ERR_INVALID,
              "sd_paged_attention: q rows must be 16-byte aligned");
   if (B == 0) return SD_OK;
   AttnArgs a;
@@ -508,6 +508,8 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
   a.n_splits = n_splits_for(max_ctx, split_tokens);
   a.part_o = nullptr;
   a.part_ml = nullptr;
+  SD_REQUIRE(out || a.n_splits > 1, SD_ERR_INVALID,
+             "sd_paged_attention: out == NULL (partials only) needs more than one split");
   const int MT = q_len * G <= 32 ? 1 : 2;
   if (a.n_splits > 1) {
     const size_t rows = (size_t)B * Hkv * a.n_splits * (MT * 32);

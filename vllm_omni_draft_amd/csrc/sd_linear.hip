@@ -21,7 +21,10 @@
 
 namespace {
 
-enum { NORM_NONE = 0, NORM_RMS = 1, NORM_LAYER = 2 };
+// What a workgroup stages in LDS as its activations: nothing (lanes read x from global
+// memory), RMS- or LayerNorm-ed x, or the attention output merged from per-split partials.
+enum { NORM_NONE = 0, NORM_RMS = 1, NORM_LAYER = 2, STAGE_ATTN_MERGE = 3 };
+constexpr int kMergeMaxSplits = 8;
 constexpr int EPI_QKV_ROPE = 100;  // internal: sd_norm_qkv_rope
 constexpr int kLinThreads = 512;
 constexpr int kLinWaves = kLinThreads / SD_WAVE;
@@ -45,6 +48,15 @@ struct RopeArgs {
   int pos_offset, q_len, Hq, Hkv, D;
 };
 
+// Attention partials (the workspace layout of sd_paged_attention): per (sequence, KV
+// head, split) m_pad rows of D un-normalised outputs, and (row max, row sum) pairs.
+struct MergeArgs {
+  const float* part_o;
+  const float* part_ml;
+  const int32_t* seq_lens;
+  int pos_offset, q_len, G, Hkv, D, n_splits, split_tokens, m_pad;
+};
+
 struct LinArgs {
   const bf16_t* W;         // tiled [n_tiles][K/32][64][8]
   const bf16_t* x;
@@ -59,6 +71,7 @@ struct LinArgs {
   const bf16_t* norm_b;
   float eps;
   RopeArgs rope;
+  MergeArgs merge;
 };
 
 // HALF: a work unit is 8 of a tile's 16 rows (lanes of the other 8 rows load nothing and
@@ -134,7 +147,52 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   bf16_t* gs = reinterpret_cast<bf16_t*>(red);
   bf16_t* bs = gs + a.K;  // LayerNorm only
   float rs_m[2] = {0.f, 0.f}, mean_m[2] = {0.f, 0.f};  // rows wave, wave + 8
-  if (!DIRECT) {
+  if (NORM == STAGE_ATTN_MERGE) {
+    // x[m][c] = (sum_s f_s o_s) / (sum_s f_s l_s), f_s = exp2(m_s - max m), splits in index
+    // order: the arithmetic of the stand-alone merge kernel.  Every split's partial is
+    // requested at once (those past the sequence's length are read and ignored).
+    const MergeArgs& g = a.merge;
+    for (int it = tid; it < M * (a.K / 4); it += kLinThreads) {
+      const int m = it / (a.K / 4), c = (it - m * (a.K / 4)) * 4;
+      const int b = m / g.q_len, t = m - b * g.q_len;
+      const int head = c / g.D, d = c - head * g.D;
+      const int kvh = head / g.G, mrow = t * g.G + (head - kvh * g.G);
+      const size_t row0 = (size_t)(b * g.Hkv + kvh) * g.n_splits * g.m_pad + mrow;
+      f32x4 ov[kMergeMaxSplits];
+      float mv[kMergeMaxSplits], lv[kMergeMaxSplits];
+#pragma unroll
+      for (int sp = 0; sp < kMergeMaxSplits; ++sp) {
+        if (sp < g.n_splits) {
+          const size_t row = row0 + (size_t)sp * g.m_pad;
+          ov[sp] = *reinterpret_cast<const f32x4*>(g.part_o + row * g.D + d);
+          mv[sp] = g.part_ml[row * 2];
+          lv[sp] = g.part_ml[row * 2 + 1];
+        }
+      }
+      const int kv_len = g.seq_lens[b] + g.pos_offset + g.q_len;
+      const int n_valid = min((kv_len + g.split_tokens - 1) / g.split_tokens, g.n_splits);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < kMergeMaxSplits; ++sp)
+        if (sp < n_valid) mx = fmaxf(mx, mv[sp]);
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      float l = 0.f;
+      if (mx != -INFINITY) {
+#pragma unroll
+        for (int sp = 0; sp < kMergeMaxSplits; ++sp) {
+          if (sp < n_valid) {
+            const float f = __builtin_amdgcn_exp2f(mv[sp] - mx);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += f * ov[sp][j];
+            l += f * lv[sp];
+          }
+        }
+      }
+      bf16_t* xl = xs + (size_t)m * LDX + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xl[j] = (bf16_t)(l > 0.f ? o[j] / l : 0.f);
+    }
+  } else if (!DIRECT) {
     const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 g_pre[2], b_pre[2];
 #pragma unroll
@@ -204,7 +262,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int m = wave + rr * kLinWaves;
-      if (m < M) {
+      if (NORM != STAGE_ATTN_MERGE && m < M) {
         bf16_t* xl = xs + (size_t)m * LDX;
         const float rs = rs_m[rr], mean = mean_m[rr];
         for (int c = lane * 8; c < a.K; c += 512) {
@@ -393,7 +451,7 @@ constexpr size_t kXBudgetNorm = 144 * 1024;  // a fused norm needs whole rows
 constexpr size_t kRedBytes = (size_t)2 * kLinWaves * 256 * 4;  // cross-wave sum buffer
 
 size_t lin_lds_bytes(int M, int KC, int norm) {
-  return (norm == NORM_NONE ? 0 : (size_t)(M + 1) * (KC + kXPad) * 2) + kRedBytes;
+  return (norm == NORM_NONE ? 0 : (size_t)(M + 1) * (KC + kXPad) * 2) + kRedBytes;  // x + zero row
 }
 
 // K padded to whole 256-column segments if the rows of a fused norm fit in LDS, else 0.
@@ -401,7 +459,8 @@ int choose_kc(int M, int K, int norm) {
   const int kpad = (K + 255) / 256 * 256;
   const size_t whole = (size_t)(M + 1) * (kpad + kXPad) * 2;
   // the norm weight (and LayerNorm bias) are staged in the sum buffer
-  const size_t params = (size_t)K * 2 * (norm == NORM_LAYER ? 2 : 1);
+  const size_t params =
+      norm == STAGE_ATTN_MERGE ? 0 : (size_t)K * 2 * (norm == NORM_LAYER ? 2 : 1);
   return whole <= kXBudgetNorm && params <= kRedBytes ? kpad : 0;
 }
 
@@ -432,7 +491,8 @@ template <int EPI, int NORM>
 int launch_one(LinArgs& a, hipStream_t st) {
   // Row-half units where whole tiles would leave CUs idle (plain row-per-output tiles only:
   // gated and rotary tiles pair row r with row r + 8).
-  constexpr bool kCanHalve = NORM == NORM_NONE && EPI != SD_EPI_SILU_MUL && EPI != EPI_QKV_ROPE;
+  constexpr bool kCanHalve = (NORM == NORM_NONE || NORM == STAGE_ATTN_MERGE) &&
+                             EPI != SD_EPI_SILU_MUL && EPI != EPI_QKV_ROPE;
   if constexpr (kCanHalve) {
     if (a.n_tiles < 256) return launch_half<EPI, NORM, true>(a, st);
   }
@@ -441,6 +501,12 @@ int launch_one(LinArgs& a, hipStream_t st) {
 
 template <int NORM>
 int launch_n(LinArgs& a, int epi, hipStream_t st) {
+  if constexpr (NORM == STAGE_ATTN_MERGE) {
+    if (epi == SD_EPI_STORE) return launch_one<SD_EPI_STORE, NORM>(a, st);
+    if (epi == SD_EPI_RESIDUAL) return launch_one<SD_EPI_RESIDUAL, NORM>(a, st);
+    sd_set_error("sd_linear_attn_merge: epilogue %d not available", epi);
+    return SD_ERR_UNSUPPORTED;
+  }
   switch (epi) {
     case SD_EPI_STORE: return launch_one<SD_EPI_STORE, NORM>(a, st);
     case SD_EPI_SILU_MUL: return launch_one<SD_EPI_SILU_MUL, NORM>(a, st);
@@ -467,7 +533,8 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
              SD_ERR_INVALID, "sd_linear: rows must be 16-byte aligned (ldx=%lld)", (long long)a.ldx);
   SD_REQUIRE(epi != SD_EPI_RESIDUAL || a.residual, SD_ERR_INVALID,
              "sd_linear: residual epilogue without residual pointer");
-  SD_REQUIRE(norm == NORM_NONE || a.norm_w, SD_ERR_INVALID, "sd_linear: fused norm without weight");
+  SD_REQUIRE(norm == NORM_NONE || norm == STAGE_ATTN_MERGE || a.norm_w, SD_ERR_INVALID,
+             "sd_linear: fused norm without weight");
   if (a.M == 0) return SD_OK;
   a.KC = norm == NORM_NONE ? (a.K + 255) / 256 * 256 : choose_kc(a.M, a.K, norm);
   SD_REQUIRE(a.KC > 0, SD_ERR_UNSUPPORTED,
@@ -477,6 +544,7 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
     case NORM_NONE: return launch_n<NORM_NONE>(a, epi, st);
     case NORM_RMS: return launch_n<NORM_RMS>(a, epi, st);
     case NORM_LAYER: return launch_n<NORM_LAYER>(a, epi, st);
+    case STAGE_ATTN_MERGE: return launch_n<STAGE_ATTN_MERGE>(a, epi, st);
   }
   sd_set_error("sd_linear: unknown norm mode %d", norm);
   return SD_ERR_INVALID;
@@ -682,6 +750,36 @@ extern "C" int sd_linear(const void* W, const void* x, int64_t ldx, const void* 
   a.residual = (const bf16_t*)residual; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
   a.n_tiles = tiles_for(N, epilogue);
   return linear_common(a, epilogue, NORM_NONE, (hipStream_t)stream);
+}
+
+extern "C" int sd_linear_attn_merge(const void* W, const void* workspace, size_t workspace_bytes,
+                                    const int32_t* seq_lens, int pos_offset, int B, int q_len,
+                                    int Hq, int Hkv, int D, int max_ctx, int split_tokens,
+                                    const void* bias, const void* residual, void* out,
+                                    int64_t ldo, int N, int epilogue, sd_stream_t stream) {
+  SD_REQUIRE(W && workspace && seq_lens && out, SD_ERR_INVALID,
+             "sd_linear_attn_merge: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && (D == 64 || D == 128),
+             SD_ERR_INVALID, "sd_linear_attn_merge: bad shape");
+  SD_REQUIRE(split_tokens >= 128 && max_ctx >= 1, SD_ERR_INVALID,
+             "sd_linear_attn_merge: bad split_tokens / max_ctx");
+  SD_REQUIRE(ldo >= N, SD_ERR_INVALID, "sd_linear_attn_merge: ldo < N");
+  const int G = Hq / Hkv;
+  const int n_splits = (max_ctx + split_tokens - 1) / split_tokens;
+  SD_REQUIRE(q_len * G <= 64 && n_splits >= 1 && n_splits <= kMergeMaxSplits, SD_ERR_UNSUPPORTED,
+             "sd_linear_attn_merge: %d splits (at most %d)", n_splits, kMergeMaxSplits);
+  const int m_pad = q_len * G <= 32 ? 32 : 64;
+  const size_t rows = (size_t)B * Hkv * n_splits * m_pad;
+  SD_REQUIRE(workspace_bytes >= rows * (D + 2) * sizeof(float), SD_ERR_WORKSPACE,
+             "sd_linear_attn_merge: workspace smaller than the partials");
+  LinArgs a{};
+  a.W = (const bf16_t*)W; a.x = (const bf16_t*)workspace; a.ldx = (int64_t)Hq * D;
+  a.bias = (const bf16_t*)bias; a.residual = (const bf16_t*)residual; a.out = out; a.ldo = ldo;
+  a.M = B * q_len; a.N = N; a.K = Hq * D;
+  a.n_tiles = tiles_for(N, epilogue);
+  a.merge = MergeArgs{(const float*)workspace, (const float*)workspace + rows * D, seq_lens,
+                      pos_offset, q_len, G, Hkv, D, n_splits, split_tokens, m_pad};
+  return linear_common(a, epilogue, STAGE_ATTN_MERGE, (hipStream_t)stream);
 }
 
 extern "C" int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w,

@@ -182,12 +182,24 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                               kv->block_tables, kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
                               a->B, a->q_len, Hq, Hkv, D, H, stream));
     }
+    // With few rows and splits the output projection merges the attention partials itself
+    // (every workgroup redoes the small merge) and the merge launch is saved.
+    const int n_splits = (a->max_ctx + a->split_tokens - 1) / a->split_tokens;
+    const bool merge_in_proj = n_splits > 1 && n_splits <= 8 && rows * n_splits <= 16 &&
+                               sd_fused_norm_fits(rows, Hq * D, false);
     SD_TRY(sd_paged_attention(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
-                              kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
-                              (int64_t)Hq * D, a->B, a->q_len, Hq, Hkv, D, d.attn_scale, a->max_ctx,
-                              a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
-    SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, l.o_b, h, h, H, rows, H, Hq * D,
-                     SD_EPI_RESIDUAL, stream));
+                              kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
+                              merge_in_proj ? nullptr : attn, (int64_t)Hq * D, a->B, a->q_len, Hq,
+                              Hkv, D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
+                              w.attn_ws_bytes, stream));
+    if (merge_in_proj) {
+      SD_TRY(sd_linear_attn_merge(l.o_w, attn_ws, w.attn_ws_bytes, a->seq_lens, a->pos_offset,
+                                  a->B, a->q_len, Hq, Hkv, D, a->max_ctx, a->split_tokens, l.o_b,
+                                  h, h, H, H, SD_EPI_RESIDUAL, stream));
+    } else {
+      SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, l.o_b, h, h, H, rows, H, Hq * D,
+                       SD_EPI_RESIDUAL, stream));
+    }
     const int act_epi = llama ? SD_EPI_SILU_MUL : SD_EPI_RELU;
     if (fuse) {
       SD_TRY(sd_norm_linear(l.up_w, h, H, l.mlp_norm_w, l.mlp_norm_b, d.norm_eps, !llama, l.up_b,

@@ -153,14 +153,17 @@ def paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx, split_tokens) -> i
 
 
 def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D,
-                    scale, max_ctx, split_tokens=256, ldq=None, workspace=None) -> torch.Tensor:
-    """q: [B*q_len, >= Hq*D] bf16 rows (row stride ldq elements)."""
+                    scale, max_ctx, split_tokens=256, ldq=None, workspace=None,
+                    partials_only=False) -> Optional[torch.Tensor]:
+    """q: [B*q_len, >= Hq*D] bf16 rows (row stride ldq elements).  partials_only: leave the
+    per-split partials in `workspace` for linear_attn_merge and return None."""
     _need(q, torch.bfloat16, "q")
     _need(block_tables, torch.int32, "block_tables")
     _need(seq_lens, torch.int32, "seq_lens")
     if ldq is None:
         ldq = q.shape[-1] if q.dim() == 2 else Hq * D
-    out = torch.empty(B * q_len, Hq * D, dtype=torch.bfloat16, device=q.device)
+    out = None if partials_only else torch.empty(B * q_len, Hq * D, dtype=torch.bfloat16,
+                                                 device=q.device)
     need = paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx, split_tokens)
     if workspace is None:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
@@ -244,6 +247,20 @@ def layernorm(x, w, b, eps) -> torch.Tensor:
     out = torch.empty_like(x)
     _lib.check(_lib.load().sd_layernorm(_p(x), H, _p(w), _p(b), _p(out), H, rows, H, float(eps),
                                         _stream()), "sd_layernorm")
+    return out
+
+
+def linear_attn_merge(W, workspace, seq_lens, pos_offset, B, q_len, Hq, Hkv, D, max_ctx,
+                      split_tokens, bias=None, residual=None, epilogue=EPI_STORE,
+                      out=None) -> torch.Tensor:
+    """W @ merge(attention partials in `workspace`), see paged_attention(partials_only=True)."""
+    Wt = _tiled(W, epilogue)
+    if out is None:
+        out = torch.empty(B * q_len, Wt.N, dtype=torch.bfloat16, device=workspace.device)
+    _lib.check(_lib.load().sd_linear_attn_merge(
+        _p(Wt.data), _p(workspace), workspace.numel(), _p(seq_lens), pos_offset, B, q_len, Hq, Hkv,
+        D, max_ctx, split_tokens, _p(bias), _p(residual), _p(out), out.stride(0), Wt.N, epilogue,
+        _stream()), "sd_linear_attn_merge")
     return out
 
 
