@@ -14,7 +14,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 clean:
 	rm -f $(OBJS) $(LIB)

@@ -256,6 +256,12 @@ int sd_embed(const int32_t* ids, int64_t id_stride_seq, int64_t id_offset,
 
 typedef enum { SD_ARCH_LLAMA = 0, SD_ARCH_OPT = 1 } sd_arch;
 
+/* Sum of a bf16 buffer over the ranks of a tensor-parallel group, in place,
+ * enqueued on `stream`.  sd_tp_allreduce (RCCL, below) has this signature; a
+ * host may supply its own.                                                  */
+typedef int (*sd_allreduce_fn)(void* buf, size_t n_bf16, void* ctx,
+                               sd_stream_t stream);
+
 typedef struct {
   const void* attn_norm_w;  /* [H] */
   const void* attn_norm_b;  /* [H] or NULL (OPT) */
@@ -286,6 +292,15 @@ typedef struct {
   const void* final_norm_b; /* or NULL */
   const void* lm_head;     /* [vocab, H] bf16 tiled SD_TILE_PLAIN (== embed when tied) */
   const sd_layer_weights* layers; /* n_layers entries (copied) */
+  /* Tensor parallelism (allreduce == NULL: none).  n_heads, n_kv_heads and ffn
+   * are this rank's shares: qkv_w / up_w hold the rows of the rank's heads /
+   * ffn columns, o_w / down_w the matching input columns (hidden stays whole,
+   * embedding, norms and LM head are replicated).  The two row-parallel
+   * projections of a layer are summed over the ranks with `allreduce`; rank 0
+   * alone adds the residual and the biases.                                  */
+  int tp_rank;
+  sd_allreduce_fn allreduce;
+  void* allreduce_ctx;
 } sd_model_desc;
 
 typedef struct sd_model sd_model;
@@ -319,6 +334,21 @@ size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,
 int sd_model_forward(sd_model* m, const sd_kv_cache* kv,
                      const sd_forward_args* a, void* workspace,
                      size_t workspace_bytes, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Tensor-parallel group over RCCL (one process per GPU; xGMI inside a node).
+ * Replaces the NCCL tensor_model_parallel_all_reduce of the target model's
+ * row-parallel layers.  Rank 0 makes an id, the host spreads its
+ * SD_TP_ID_BYTES to the other ranks by any means, every rank then creates its
+ * communicator (collective call).
+ * ---------------------------------------------------------------------- */
+#define SD_TP_ID_BYTES 128
+typedef struct sd_tp_comm sd_tp_comm;
+int sd_tp_unique_id(void* id_out);
+sd_tp_comm* sd_tp_comm_create(const void* id, int rank, int world_size);
+void sd_tp_comm_destroy(sd_tp_comm* comm);
+/* An sd_allreduce_fn: ctx is the sd_tp_comm*.                                */
+int sd_tp_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Speculative step glue that must stay on the device (replaces the tensor

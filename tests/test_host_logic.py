@@ -140,6 +140,9 @@ def _dp_worker(rank, world, port, q):
     tokens = sum(len(s) for s in streams)
     total, secs = parallel.aggregate_throughput(tokens, 1.0 + rank)
     gathered = parallel.gather_streams(streams, w)
+    # the tensor-parallel id exchange: rank 0's 128 bytes reach every rank
+    uid = parallel._broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+    assert uid == bytes(range(128))
     dist.barrier()
     q.put((rank, total, secs, gathered))
     dist.destroy_process_group()
@@ -159,3 +162,45 @@ def test_data_parallel_helpers_world_size_2():
     for rank, total, secs, gathered in res:
         assert total == 15.0 and secs == 2.0                     # sum of tokens, max of time
         assert gathered == [[[0, 1, 2], [20, 21, 22], [40, 41, 42]], [[10, 11, 12], [30, 31, 32]]]
+
+
+@pytest.mark.parametrize("arch", ["llama", "opt"])
+def test_tensor_parallel_shards_reproduce_the_layer_math(arch):
+    """Column-parallel shards concatenate to the whole projection; row-parallel partial
+    products sum to it (checked on the oracle's weights, float64)."""
+    from oracle.models import OracleConfig, random_state
+    from vllm_omni_draft_amd import weights
+    oc = OracleConfig(arch=arch, n_layers=2, hidden=128, n_heads=4, n_kv_heads=4 if arch == "opt" else 2,
+                      head_dim=64, ffn=256, vocab=64, max_pos=64)
+    state = {k: v.double() for k, v in random_state(oc, seed=3, qkv_bias=(arch == "llama")).items()}
+    cfg = config.create_model_config(None, arch=arch, n_layers=2, hidden=128, n_heads=4,
+                                     n_kv_heads=oc.n_kv_heads, head_dim=64, ffn=256, vocab=64,
+                                     max_pos=64, qkv_bias=(arch == "llama"))
+    tp = 2
+    shards = [weights.shard_state_dict(cfg, state, tp, r) for r in range(tp)]
+    for local, _ in shards:
+        assert (local.n_heads, local.n_kv_heads, local.ffn, local.hidden) == (2, oc.n_kv_heads // 2, 128, 128)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 128, generator=g, dtype=torch.float64)
+    if arch == "llama":
+        lp, names = "model.layers.1.", ("self_attn.q_proj", "self_attn.o_proj", "mlp.gate_proj",
+                                        "mlp.up_proj", "mlp.down_proj")
+    else:
+        lp, names = "model.decoder.layers.1.", ("self_attn.q_proj", "self_attn.out_proj", "fc1", "fc1", "fc2")
+    qn, on, gn, un, dn = (lp + n + ".weight" for n in names)
+    q_full = x @ state[qn].T + state[qn.replace("weight", "bias")]
+    q_parts = [x @ st[qn].T + st[qn.replace("weight", "bias")] for _, st in shards]
+    torch.testing.assert_close(torch.cat(q_parts, dim=1), q_full)
+    # attention output stand-in: the q columns themselves; row-parallel o_proj partial sums
+    o_full = q_full @ state[on].T
+    o_sum = sum(qp @ st[on].T for qp, (_, st) in zip(q_parts, shards))
+    torch.testing.assert_close(o_sum, o_full)
+    act = lambda st: torch.nn.functional.silu(x @ st[gn].T) * (x @ st[un].T)
+    torch.testing.assert_close(sum(act(st) @ st[dn].T for _, st in shards), act(state) @ state[dn].T)
+    # replicated tensors are untouched; K/V shards follow the KV heads
+    kname = lp + "self_attn.k_proj.weight"
+    assert torch.equal(torch.cat([st[kname] for _, st in shards]), state[kname])
+    emb = "model.embed_tokens.weight" if arch == "llama" else "model.decoder.embed_tokens.weight"
+    assert all(torch.equal(st[emb], state[emb]) for _, st in shards)
+    with pytest.raises(ValueError):
+        cfg.tp_shard(3)

@@ -35,7 +35,12 @@ class ModelDesc(C.Structure):
         ("norm_eps", C.c_float), ("attn_scale", C.c_float),
         ("embed", vp), ("embed_tiled", i32), ("pos_table", vp), ("rope_cs", vp), ("final_norm_w", vp),
         ("final_norm_b", vp), ("lm_head", vp), ("layers", C.POINTER(LayerWeights)),
+        ("tp_rank", i32), ("allreduce", vp), ("allreduce_ctx", vp),
     ]
+
+
+# int (*sd_allreduce_fn)(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream)
+ALLREDUCE_FN = C.CFUNCTYPE(i32, vp, C.c_size_t, vp, vp)
 
 
 class KvCacheDesc(C.Structure):
@@ -82,6 +87,10 @@ SIGNATURES = {
     "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
     "sd_linear_attn_merge": (i32, [vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                    vp, vp, vp, i64, i32, i32, vp]),
+    "sd_tp_unique_id": (i32, [vp]),
+    "sd_tp_comm_create": (vp, [vp, i32, i32]),
+    "sd_tp_comm_destroy": (None, [vp]),
+    "sd_tp_allreduce": (i32, [vp, C.c_size_t, vp, vp]),
     "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i64, C.c_float,
                                        C.c_uint32, i32, vp]),

@@ -9,6 +9,7 @@ from __future__ import annotations
 import json
 import math
 import os
+import dataclasses
 from dataclasses import dataclass, field, fields
 from typing import Optional
 
@@ -58,6 +59,18 @@ class ModelConfig:
 
     def kv_bytes_per_token(self) -> int:
         return 2 * self.n_layers * self.n_kv_heads * self.head_dim * 2
+
+    def tp_shard(self, tp_size: int) -> "ModelConfig":
+        """The per-rank view under tensor parallelism: heads and ffn columns divided,
+        hidden size, vocabulary and layer count unchanged."""
+        if tp_size < 1 or self.n_heads % tp_size or self.n_kv_heads % tp_size:
+            raise ValueError(f"tp_size {tp_size} must divide n_heads={self.n_heads} and "
+                             f"n_kv_heads={self.n_kv_heads}")
+        if self.ffn % (32 * tp_size):
+            raise ValueError(f"ffn {self.ffn} must be a multiple of 32 * tp_size")
+        return dataclasses.replace(self, n_heads=self.n_heads // tp_size,
+                                   n_kv_heads=self.n_kv_heads // tp_size,
+                                   ffn=self.ffn // tp_size, name=f"{self.name}/tp{tp_size}")
 
 
 def create_model_config(base: Optional[ModelConfig] = None, **overrides) -> ModelConfig:

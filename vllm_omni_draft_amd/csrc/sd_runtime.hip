@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "sd_common.h"
+#include <rccl/rccl.h>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -192,14 +193,19 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                               merge_in_proj ? nullptr : attn, (int64_t)Hq * D, a->B, a->q_len, Hq,
                               Hkv, D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
                               w.attn_ws_bytes, stream));
+    // Row-parallel projections under tensor parallelism: rank 0 adds the residual and the
+    // bias, the others store their partial product, and the sum over ranks lands in h.
+    const bool lead = !d.allreduce || d.tp_rank == 0;
+    const int proj_epi = lead ? SD_EPI_RESIDUAL : SD_EPI_STORE;
     if (merge_in_proj) {
       SD_TRY(sd_linear_attn_merge(l.o_w, attn_ws, w.attn_ws_bytes, a->seq_lens, a->pos_offset,
-                                  a->B, a->q_len, Hq, Hkv, D, a->max_ctx, a->split_tokens, l.o_b,
-                                  h, h, H, H, SD_EPI_RESIDUAL, stream));
+                                  a->B, a->q_len, Hq, Hkv, D, a->max_ctx, a->split_tokens,
+                                  lead ? l.o_b : nullptr, h, h, H, H, proj_epi, stream));
     } else {
-      SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, l.o_b, h, h, H, rows, H, Hq * D,
-                       SD_EPI_RESIDUAL, stream));
+      SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
+                       Hq * D, proj_epi, stream));
     }
+    if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
     const int act_epi = llama ? SD_EPI_SILU_MUL : SD_EPI_RELU;
     if (fuse) {
       SD_TRY(sd_norm_linear(l.up_w, h, H, l.mlp_norm_w, l.mlp_norm_b, d.norm_eps, !llama, l.up_b,
@@ -209,7 +215,9 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
       SD_TRY(sd_linear(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H, act_epi, stream));
     }
-    SD_TRY(sd_linear(l.down_w, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL, stream));
+    SD_TRY(sd_linear(l.down_w, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F, proj_epi,
+                     stream));
+    if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
   }
   if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {
@@ -273,4 +281,53 @@ extern "C" void sd_graph_destroy(sd_graph* g) {
   hipGraphExecDestroy(g->exec);
   hipGraphDestroy(g->graph);
   delete g;
+}
+
+// ------------------------------------------------------------------ tensor-parallel group
+struct sd_tp_comm {
+  ncclComm_t comm;
+  int rank, world;
+};
+
+static_assert(sizeof(ncclUniqueId) <= SD_TP_ID_BYTES, "RCCL unique id does not fit");
+
+extern "C" int sd_tp_unique_id(void* id_out) {
+  SD_REQUIRE(id_out, SD_ERR_INVALID, "sd_tp_unique_id: null pointer");
+  ncclUniqueId id;
+  const ncclResult_t r = ncclGetUniqueId(&id);
+  SD_REQUIRE(r == ncclSuccess, SD_ERR_HIP, "sd_tp_unique_id: %s", ncclGetErrorString(r));
+  memset(id_out, 0, SD_TP_ID_BYTES);
+  memcpy(id_out, &id, sizeof(id));
+  return SD_OK;
+}
+
+extern "C" sd_tp_comm* sd_tp_comm_create(const void* id, int rank, int world_size) {
+  if (!id || world_size < 1 || rank < 0 || rank >= world_size) {
+    sd_set_error("sd_tp_comm_create: bad arguments (rank %d of %d)", rank, world_size);
+    return nullptr;
+  }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  ncclComm_t comm;
+  const ncclResult_t r = ncclCommInitRank(&comm, world_size, uid, rank);
+  if (r != ncclSuccess) {
+    sd_set_error("sd_tp_comm_create: ncclCommInitRank: %s", ncclGetErrorString(r));
+    return nullptr;
+  }
+  return new sd_tp_comm{comm, rank, world_size};
+}
+
+extern "C" void sd_tp_comm_destroy(sd_tp_comm* c) {
+  if (!c) return;
+  ncclCommDestroy(c->comm);
+  delete c;
+}
+
+extern "C" int sd_tp_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream) {
+  SD_REQUIRE(buf && ctx, SD_ERR_INVALID, "sd_tp_allreduce: null pointer");
+  sd_tp_comm* c = static_cast<sd_tp_comm*>(ctx);
+  const ncclResult_t r = ncclAllReduce(buf, buf, n_bf16, ncclBfloat16, ncclSum, c->comm,
+                                       (hipStream_t)stream);
+  SD_REQUIRE(r == ncclSuccess, SD_ERR_HIP, "sd_tp_allreduce: %s", ncclGetErrorString(r));
+  return SD_OK;
 }

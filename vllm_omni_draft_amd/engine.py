@@ -44,7 +44,11 @@ class EngineConfig:
 
 
 class SpecEngine:
-    def __init__(self, target: ModelWeights, draft: Optional[ModelWeights], cfg: EngineConfig):
+    def __init__(self, target: ModelWeights, draft: Optional[ModelWeights], cfg: EngineConfig,
+                 tp_group=None):
+        """tp_group: the target is this rank's tensor-parallel shard (its two row-parallel
+        projections per layer are summed over the group inside the native forward); the
+        draft is whole.  Every rank runs the same steps on the same inputs."""
         if cfg.k < 0 or cfg.k > 7:
             raise ValueError("k must be in 0..7")
         if cfg.k > 0 and draft is None:
@@ -58,7 +62,7 @@ class SpecEngine:
         self.device = dev
         B, k = cfg.max_batch, cfg.k
         self.max_ctx = cfg.max_seq_len + k + 2
-        self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens)
+        self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group)
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens)
                       if k > 0 else None)
         self.V = target.cfg.vocab

@@ -25,8 +25,12 @@ def _ptr(t):
 
 
 class DecoderModel:
-    def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256):
+    def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
+                 tp_group=None):
+        """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
+        ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
+        self.tp_group = tp_group  # keeps the communicator / callback alive
         self.cfg: ModelConfig = weights.cfg
         cfg = self.cfg
         if max_ctx > cfg.max_pos:
@@ -46,7 +50,10 @@ class DecoderModel:
             embed=_ptr(weights.embed), embed_tiled=int(weights.embed_tiled),
             pos_table=_ptr(weights.pos_table),
             rope_cs=_ptr(weights.rope_cs), final_norm_w=_ptr(weights.final_norm_w),
-            final_norm_b=_ptr(weights.final_norm_b), lm_head=_ptr(weights.lm_head), layers=layers)
+            final_norm_b=_ptr(weights.final_norm_b), lm_head=_ptr(weights.lm_head), layers=layers,
+            tp_rank=tp_group.rank if tp_group else 0,
+            allreduce=tp_group.allreduce_ptr if tp_group else None,
+            allreduce_ctx=tp_group.ctx_ptr if tp_group else None)
         self._handle = lib.sd_model_create(C.byref(desc))
         if not self._handle:
             raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")

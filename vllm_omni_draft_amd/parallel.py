@@ -5,11 +5,18 @@ Data-parallel replicas: requests are dealt round-robin to N single-GPU engines,
 each with its own target, draft and KV cache.  Nothing is exchanged on the data
 path; only throughput accounting crosses ranks.  (The reference runs a single
 uni-process executor, /root/reference/src/qwen_image_gen/executor.py:11.)
+
+Tensor-parallel target (a 70B target over the 8 GPUs of a node): every rank holds
+its shard of the target (weights.shard_state_dict) and a whole draft; the native
+forward sums the two row-parallel projections of each layer over the ranks with
+RCCL (TensorParallelGroup).  Ranks run the same step on the same inputs, so
+proposals, acceptance and state are identical everywhere with no further exchange.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
-from typing import List, Sequence, Tuple, TypeVar
+from typing import Callable, List, Optional, Sequence, Tuple, TypeVar
 
 import torch
 import torch.distributed as dist
@@ -63,3 +70,64 @@ def gather_streams(local: List[List[int]], world: int) -> List[List[List[int]]]:
     out: List = [None] * world
     dist.all_gather_object(out, local)
     return out
+
+
+class TensorParallelGroup:
+    """An RCCL communicator owned by the native library (sd_tp_comm_create).
+
+    broadcast_id(id_bytes_or_None) -> bytes spreads rank 0's 128-byte id to every rank;
+    by default it goes through torch.distributed (any backend)."""
+
+    def __init__(self, rank: int, world_size: int,
+                 broadcast_id: Optional[Callable[[Optional[bytes]], bytes]] = None):
+        from . import _lib
+        lib = _lib.load()
+        self.rank, self.world_size = rank, world_size
+        n = 128  # SD_TP_ID_BYTES
+        mine = None
+        if rank == 0:
+            buf = (C.c_ubyte * n)()
+            _lib.check(lib.sd_tp_unique_id(buf), "sd_tp_unique_id")
+            mine = bytes(buf)
+        uid = (broadcast_id or _broadcast_bytes)(mine) if world_size > 1 else mine
+        if uid is None or len(uid) != n:
+            raise RuntimeError("tensor-parallel id exchange failed")
+        self._comm = lib.sd_tp_comm_create((C.c_ubyte * n).from_buffer_copy(uid), rank, world_size)
+        if not self._comm:
+            raise _lib.SdError(f"sd_tp_comm_create failed: {_lib.last_error()}")
+        self.allreduce_ptr = C.cast(lib.sd_tp_allreduce, C.c_void_p).value
+        self.ctx_ptr = self._comm
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        """In-place sum of a bf16 device tensor over the group (current stream)."""
+        from . import _lib
+        if t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous():
+            raise _lib.SdError("all_reduce: contiguous bf16 device tensor expected")
+        _lib.check(_lib.load().sd_tp_allreduce(t.data_ptr(), t.numel(), self._comm,
+                                               torch.cuda.current_stream().cuda_stream),
+                   "sd_tp_allreduce")
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None):
+            from . import _lib
+            _lib.load().sd_tp_comm_destroy(self._comm)
+            self._comm = None
+
+
+def _broadcast_bytes(payload: Optional[bytes]) -> bytes:
+    """Rank 0's payload on every rank of the default process group."""
+    box = [payload]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
+class CallbackAllReduce:
+    """A tensor-parallel 'group' whose all-reduce is a host callback
+    fn(ptr, n_bf16, stream) -> int: for tests and for hosts with their own collective."""
+
+    def __init__(self, rank: int, fn: Callable[[int, int, int], int]):
+        from . import _lib
+        self.rank = rank
+        self._cb = _lib.ALLREDUCE_FN(lambda buf, n, ctx, stream: fn(buf, n, stream or 0))
+        self.allreduce_ptr = C.cast(self._cb, C.c_void_p).value
+        self.ctx_ptr = None

@@ -222,6 +222,10 @@ class SpecDecodeConfig:
     seed: int = 0
     split_tokens: int = 256
     use_graph: bool = True
+    # Tensor-parallel verify: the target is sharded over this many ranks (one process per
+    # GPU), the draft stays whole on each.  `target` is then either this rank's shard or a
+    # (ModelConfig, state_dict) pair that load_model shards itself.
+    tensor_parallel_size: int = 1
 
 
 class SpecDecodeWorker:
@@ -254,13 +258,29 @@ class SpecDecodeWorker:
         if not torch.cuda.is_available():
             raise RuntimeError("SpecDecodeWorker needs a GPU: there is no CPU path")
         torch.cuda.set_device(self.local_rank)
+        tp = self.config.tensor_parallel_size
+        if tp > 1:
+            from . import parallel
+            if not torch.distributed.is_initialized():
+                raise RuntimeError("tensor_parallel_size > 1 needs an initialised torch.distributed "
+                                   "group (parallel.init_from_env) to exchange the RCCL id")
+            if torch.distributed.get_world_size() != tp:
+                raise ValueError("tensor_parallel_size must equal the world size")
+            self.tp_group = parallel.TensorParallelGroup(self.rank, tp)
 
     def load_model(self) -> None:
         c = self.config
-        self.engine = SpecEngine(c.target, c.draft, EngineConfig(
+        target, tp = c.target, c.tensor_parallel_size
+        if isinstance(target, tuple):
+            from . import weights as W
+            cfg, state = target
+            if tp > 1:
+                cfg, state = W.shard_state_dict(cfg, state, tp, self.rank)
+            target = W.from_state_dict(cfg, state, torch.device("cuda", self.local_rank))
+        self.engine = SpecEngine(target, c.draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
-            use_graph=c.use_graph))
+            use_graph=c.use_graph), tp_group=getattr(self, "tp_group", None))
         self._wire()
 
     def _wire(self) -> None:

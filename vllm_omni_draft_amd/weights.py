@@ -135,6 +135,38 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
                         lm_head=lm_head, layers=layers)
 
 
+def shard_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], tp_size: int,
+                     tp_rank: int):
+    """(per-rank config, per-rank state dict) for tensor parallelism over `tp_size` GPUs.
+
+    Column-parallel: q/k/v projections by head and gate/up (fc1) by ffn column keep the
+    rows of the rank's share; row-parallel: o_proj and down_proj (fc2) keep the matching
+    input columns, their partial products are summed over the ranks.  Norms, embeddings,
+    LM head and the biases of the row-parallel layers stay whole (rank 0 applies them)."""
+    if not 0 <= tp_rank < tp_size:
+        raise ValueError(f"tp_rank {tp_rank} outside 0..{tp_size - 1}")
+    local = cfg.tp_shard(tp_size)
+    D = cfg.head_dim
+    q0, q1 = tp_rank * local.n_heads * D, (tp_rank + 1) * local.n_heads * D
+    k0, k1 = tp_rank * local.n_kv_heads * D, (tp_rank + 1) * local.n_kv_heads * D
+    f0, f1 = tp_rank * local.ffn, (tp_rank + 1) * local.ffn
+    rows = {"q_proj": (q0, q1), "k_proj": (k0, k1), "v_proj": (k0, k1), "gate_proj": (f0, f1),
+            "up_proj": (f0, f1), "fc1": (f0, f1)}
+    cols = {"o_proj": (q0, q1), "out_proj": (q0, q1), "down_proj": (f0, f1), "fc2": (f0, f1)}
+    out: Dict[str, torch.Tensor] = {}
+    for name, t in state.items():
+        parts = name.split(".")
+        mod, kind = (parts[-2], parts[-1]) if len(parts) >= 2 else ("", "")
+        if "layers" in parts and mod in rows:
+            a, b = rows[mod]
+            t = t[a:b]
+        elif "layers" in parts and mod in cols and kind == "weight":
+            a, b = cols[mod]
+            t = t[:, a:b]
+        out[name] = t.contiguous()
+    return local, out
+
+
 def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02) -> ModelWeights:
     """Seeded random weights generated directly on the device in the fused
     layout (no host copy: an 8B model is 16 GB)."""
