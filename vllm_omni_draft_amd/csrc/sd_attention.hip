@@ -53,8 +53,11 @@ __device__ unsigned long long sd_stamps[16];
 #define STAMP(i)
 #endif
 
+// NBUF == 1 (one 32-row query tile) keeps the kernel within 256 registers, so that two workgroups share a CU and one's
+// prologue and merge overlap the other's stream (large batches); deeper rings run one
+// workgroup per CU.
 template <int D, int MT, int NBUF, int BT_PER_THREAD, bool RELOAD>
-__global__ __launch_bounds__(256, 1) void paged_attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_kernel(AttnArgs a) {
   STAMP(0);
   constexpr int KS = D / 16;  // k-steps of the K.Q^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
@@ -421,16 +424,23 @@ int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
 template <int D, int MT>
 int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
   // Ring depth: as many 32-key tiles in flight per wave as the register file allows.
-  constexpr int NBUF = D == 64 ? 4 : (MT == 1 ? 3 : 2);
+  constexpr int NBUF = D == 64 ? (MT == 1 ? 4 : 2) : (MT == 1 ? 3 : 1);
   // A split of at most NBUF tiles per wave is loaded whole, with no ring to keep turning.
   const int tiles_per_wave = a.split_tokens / 128;
   if (tiles_per_wave == 1) return launch_attn_bt<D, MT, 1, 1, false>(a, B, stream);
-  if (tiles_per_wave == 2) return launch_attn_bt<D, MT, 2, 1, false>(a, B, stream);
+  if constexpr (NBUF >= 2) {
+    if (tiles_per_wave == 2) return launch_attn_bt<D, MT, 2, 1, false>(a, B, stream);
+  }
   if constexpr (NBUF >= 3) {
     if (tiles_per_wave == 3) return launch_attn_bt<D, MT, 3, 1, false>(a, B, stream);
   }
   if constexpr (NBUF >= 4) {
     if (tiles_per_wave == 4) return launch_attn_bt<D, MT, 4, 1, false>(a, B, stream);
+  }
+  // Enough workgroups for two per CU: the one-tile ring, two workgroups per CU.
+  if (MT == 1 && (long)B * a.Hkv * a.n_splits >= 512) {
+    if (a.split_tokens / 16 + 8 <= 256) return launch_attn_bt<D, MT, 1, 1, true>(a, B, stream);
+    return launch_attn_bt<D, MT, 1, 4, true>(a, B, stream);
   }
   // block-table entries staged per thread: 1 covers splits up to ~3.5k keys
   const int n_bt = a.split_tokens / 16 + 8 * NBUF;

@@ -352,9 +352,11 @@ class SpecEngine:
             need = self.host_lens[b] + k + 2
             if need > self.max_ctx:
                 raise RuntimeError(f"sequence {b} would exceed max_seq_len")
-            self.t_kv.ensure_capacity(b, need)
+            # pages are taken a few at a time, so most steps upload no block-table entries
+            ahead = min(need + 4 * 16, self.max_ctx)
+            self.t_kv.ensure_capacity(b, need, ahead)
             if self.d_kv is not None:
-                self.d_kv.ensure_capacity(b, need)
+                self.d_kv.ensure_capacity(b, need, ahead)
         # Attention launches one workgroup per `split_tokens` keys up to the context bound it
         # is given; a bound that follows the live lengths in powers of two keeps short
         # contexts on the single-split path (no partials, no merge kernel).  The split

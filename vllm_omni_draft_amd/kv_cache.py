@@ -61,8 +61,10 @@ class PagedKVCache:
     def pages_of(self, slot: int) -> List[int]:
         return self._host_tables[slot]
 
-    def ensure_capacity(self, slot: int, n_tokens: int) -> None:
-        """Makes sure batch slot `slot` owns pages for positions 0..n_tokens-1."""
+    def ensure_capacity(self, slot: int, n_tokens: int, grow_to: int = 0) -> None:
+        """Makes sure batch slot `slot` owns pages for positions 0..n_tokens-1.  When pages
+        must be added anyway, grow_to > n_tokens takes pages for that many tokens at once
+        (as far as free pages allow)."""
         need = (n_tokens + PAGE - 1) // PAGE
         if need > self.max_blocks_per_seq:
             raise OutOfPages(f"sequence of {n_tokens} tokens exceeds max_seq_len")
@@ -72,6 +74,10 @@ class PagedKVCache:
         first_new = len(tbl)
         while len(tbl) < need:
             tbl.append(self.allocator.alloc())
+        want = min((grow_to + PAGE - 1) // PAGE, self.max_blocks_per_seq)
+        while len(tbl) < want and self.allocator.num_free > 0:
+            tbl.append(self.allocator.alloc())
+        need = len(tbl)
         new = torch.tensor(tbl[first_new:], dtype=torch.int32)
         self.block_tables[slot, first_new:need].copy_(new, non_blocking=True)
 

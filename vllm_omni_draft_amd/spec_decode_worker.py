@@ -280,7 +280,8 @@ class SpecDecodeWorker:
         self.engine = SpecEngine(target, c.draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
-            use_graph=c.use_graph), tp_group=getattr(self, "tp_group", None))
+            # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
+            use_graph=c.use_graph and tp == 1), tp_group=getattr(self, "tp_group", None))
         self._wire()
 
     def _wire(self) -> None:
