@@ -39,6 +39,22 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch (read + write) of a kernel from the committed counter summary
+    (profiles/r1_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE passes of rocprofv3 over
+    experiments/pmc_*.py, FETCH_SIZE doubled as gfx950 requires), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm.json")
+    try:
+        with open(path) as f:
+            ks = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, e in ks.items():
+        if kernel_substr in name and "hbm_read_bytes_per_launch" in e:
+            return e["hbm_read_bytes_per_launch"] + e.get("hbm_write_bytes_per_launch", 0)
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +145,8 @@ def kernel_roofline(eng, tw, rows, reps=3):
     n_rows = 2 * w.N if cfg.arch == "llama" else w.N
     return {"kernel": f"linear_kernel<norm+gate_up+silu_mul>, M={rows} [{n_rows}x{w.K}] bf16",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic("linear_kernel<2, 1, false>") if rows == 6 else None,
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
@@ -163,8 +180,8 @@ def attention_roofline(device, k):
     gbs = kv_bytes / us * 1e-3
     return {"kernel": "paged_attn_kernel<D=128> + merge, B=32 ctx=4096 q_len=%d, 1024 keys per workgroup" % q_len,
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": kv_bytes,
-            "avg_us": round(us, 2)}
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("paged_attn_kernel<128, 1"),
+            "bytes_per_launch": kv_bytes, "avg_us": round(us, 2)}
 
 
 def cpu_baseline(args, tokens_per_step, budget_s=30.0):
