@@ -97,6 +97,34 @@ int sd_softmax_rows(const float* logits, int64_t ld, float temperature,
 int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
                    int64_t* ids, int R, int V, sd_stream_t stream);
 
+/* Split forms of the three vocabulary-wide steps of the sampling path: each row
+ * is cut into 64 slices worked on by one workgroup each (a handful of rows
+ * otherwise occupies a handful of CUs), a per-row step finishes.  Same results
+ * as the one-workgroup forms up to the rounding of the f32 softmax sum and, for
+ * draws, of an f64 sum taken in a different order.  `scratch` holds
+ * sd_sampling_scratch_bytes(R) bytes (R = rows, or sequences for the rejection
+ * form); contents need not survive the call.                                */
+size_t sd_sampling_scratch_bytes(int R);
+int sd_softmax_rows_split(const float* logits, int64_t ld, float temperature,
+                          float* probs, int64_t ld_probs, int R, int V,
+                          void* scratch, sd_stream_t stream);
+int sd_sample_rows_split(const float* probs, int64_t ld, const float* uniforms,
+                         int64_t* ids, int R, int V, void* scratch,
+                         sd_stream_t stream);
+int sd_rejection_sample_split(const float* target_probs, const int64_t* bonus_ids,
+                              const float* draft_probs, const int64_t* draft_ids,
+                              const float* u_accept, const float* u_recover,
+                              const int32_t* proposal_lens, int64_t* out_ids,
+                              int64_t* counters, int B, int k, int V,
+                              void* scratch, sd_stream_t stream);
+
+/* out[i] = uniform in [0, 1) (24 bits) from a counter-based hash of (seed,
+ * *counter, i); then *counter += 1.  Lets a captured step draw fresh uniforms
+ * on every replay without host work.  (The acceptance entry points take their
+ * uniforms as inputs; this is one way to fill them.)                         */
+int sd_fill_uniforms(float* out, int n, uint64_t seed, uint64_t* counter,
+                     sd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Paged KV cache and attention (replaces vLLM's paged_attention_v1/v2 as used
  * by spec_decode.batch_expansion's scorer, with k+1 query tokens per sequence

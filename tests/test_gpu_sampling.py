@@ -28,7 +28,13 @@ def test_library_loads_on_gpu():
     assert cus > 0 and "gfx" in name
 
 
-def test_rejection_golden():
+def _scratch(ops, split, rows):
+    """None (one workgroup per row) or scratch for the split forms."""
+    return ops.sampling_scratch(rows) if split else None
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_rejection_golden(split):
     ops = _ops()
     g = np.load(os.path.join(GOLDEN, "rejection_cases.npz"))
     for i in range(int(g["n_cases"])):
@@ -37,28 +43,33 @@ def test_rejection_golden():
         out = ops.rejection_sample(
             cu(g[f"c{i}_target_probs"]), cu(g[f"c{i}_bonus_ids"]), cu(g[f"c{i}_draft_probs"]),
             cu(g[f"c{i}_draft_ids"]), cu(g[f"c{i}_u_accept"]), cu(g[f"c{i}_u_recover"]),
-            None if pl.size == 0 else cu(pl), counters)
+            None if pl.size == 0 else cu(pl), counters,
+            scratch=_scratch(ops, split, g[f"c{i}_target_probs"].shape[0]))
         np.testing.assert_array_equal(out.cpu().numpy(), g[f"c{i}_out_ids"], err_msg=f"case {i}")
         np.testing.assert_array_equal(counters.cpu().numpy(), g[f"c{i}_counters"])
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("B,k,V", [(1, 5, 128256), (4, 3, 50272), (32, 5, 151936), (3, 1, 64)])
-def test_rejection_random_full_vocab(B, k, V):
+def test_rejection_random_full_vocab(B, k, V, split):
     ops = _ops()
     gen = torch.Generator(device="cuda").manual_seed(B * 1000 + k)
     tl = torch.randn(B * (k + 1), V, generator=gen, device="cuda") * 3
     dl = tl.view(B, k + 1, V)[:, :k].reshape(B * k, V) + torch.randn(B * k, V, generator=gen, device="cuda")
-    p = ops.softmax_rows(tl).view(B, k + 1, V)
-    q = ops.softmax_rows(dl.contiguous()).view(B, k, V)
+    sc = _scratch(ops, split, B * (k + 1))
+    p = ops.softmax_rows(tl, scratch=sc).view(B, k + 1, V)
+    q = ops.softmax_rows(dl.contiguous(), scratch=sc).view(B, k, V)
     ud = torch.rand(B * k, generator=gen, device="cuda")
-    ids = ops.sample_rows(q.view(B * k, V), ud).view(B, k)
+    ids = ops.sample_rows(q.view(B * k, V), ud, scratch=sc).view(B, k)
+    ref_ids = sampling.sample_rows(q.view(B * k, V).cpu().numpy(), ud.cpu().numpy())
+    np.testing.assert_array_equal(ids.view(-1).cpu().numpy(), ref_ids)
     ua = torch.rand(B, k, generator=gen, device="cuda")
     ur = torch.rand(B, k + 1, generator=gen, device="cuda")
     bonus = torch.randint(0, V, (B,), generator=gen, device="cuda")
     lens = torch.randint(0, k + 1, (B,), generator=gen, device="cuda").to(torch.int32)
     for pl in (None, lens):
         counters = torch.zeros(3, dtype=torch.int64, device="cuda")
-        out = ops.rejection_sample(p, bonus, q, ids, ua, ur, pl, counters)
+        out = ops.rejection_sample(p, bonus, q, ids, ua, ur, pl, counters, scratch=sc)
         ref, cnt = sampling.rejection_sample(p.cpu().numpy(), bonus.cpu().numpy(), q.cpu().numpy(),
                                              ids.cpu().numpy(), ua.cpu().numpy(), ur.cpu().numpy(),
                                              None if pl is None else pl.cpu().numpy())
@@ -95,20 +106,23 @@ def test_greedy_ragged_and_ties():
     assert ops.argmax_rows(x).tolist() == [123, 128255]
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("V", [64, 50272, 128256])
-def test_softmax_and_sample_rows(V):
+def test_softmax_and_sample_rows(V, split):
     ops = _ops()
     gen = torch.Generator(device="cuda").manual_seed(V)
     x = torch.randn(6, V, generator=gen, device="cuda") * 4
+    sc = _scratch(ops, split, 6)
     for T in (1.0, 0.7):
-        p = ops.softmax_rows(x, T)
+        p = ops.softmax_rows(x, T, scratch=sc)
         ref = sampling.softmax_rows(x.cpu().numpy(), T)
         np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=2e-5, atol=1e-9)
     u = torch.rand(6, generator=gen, device="cuda")
-    ids = ops.sample_rows(p, u)
+    ids = ops.sample_rows(p, u, scratch=sc)
     np.testing.assert_array_equal(ids.cpu().numpy(), sampling.sample_rows(p.cpu().numpy(), u.cpu().numpy()))
     # strided rows (every other row) and the extreme uniforms
-    ids2 = ops.sample_rows(p, torch.tensor([0.0, 0.99999994, 0.5], device="cuda"), row_offset=1, row_step=2)
+    ids2 = ops.sample_rows(p, torch.tensor([0.0, 0.99999994, 0.5], device="cuda"), row_offset=1, row_step=2,
+                           scratch=sc)
     ref2 = sampling.sample_rows(p.cpu().numpy()[1::2], [0.0, 0.99999994, 0.5])
     np.testing.assert_array_equal(ids2.cpu().numpy(), ref2)
 
@@ -218,3 +232,21 @@ def test_store_proposal_forcing_is_the_same_in_both_paths():
         assert torch.equal(a, b)
         forced += (a[:, 2 + step] == truth[rows, (seq_lens + step).long()]).sum().item()
     assert 8 <= forced <= 32     # 40 draws at probability 0.5
+
+
+def test_fill_uniforms_is_uniform_and_advances():
+    ops = _ops()
+    u = torch.zeros(20000, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.fill_uniforms(u, 7, counter)
+    a = u.clone()
+    ops.fill_uniforms(u, 7, counter)
+    assert counter.item() == 2 and not torch.equal(a, u)
+    for t in (a, u):
+        assert 0.0 <= t.min().item() and t.max().item() < 1.0
+        assert abs(t.mean().item() - 0.5) < 0.01
+        hist = torch.histc(t, bins=10, min=0, max=1)
+        assert (hist - 2000).abs().max().item() < 250
+    counter.zero_()
+    ops.fill_uniforms(u, 7, counter)          # same (seed, counter) -> same numbers
+    assert torch.equal(a, u)

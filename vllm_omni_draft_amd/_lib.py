@@ -91,6 +91,11 @@ SIGNATURES = {
     "sd_tp_comm_create": (vp, [vp, i32, i32]),
     "sd_tp_comm_destroy": (None, [vp]),
     "sd_tp_allreduce": (i32, [vp, C.c_size_t, vp, vp]),
+    "sd_sampling_scratch_bytes": (C.c_size_t, [i32]),
+    "sd_softmax_rows_split": (i32, [vp, i64, C.c_float, vp, i64, i32, i32, vp, vp]),
+    "sd_sample_rows_split": (i32, [vp, i64, vp, vp, i32, i32, vp, vp]),
+    "sd_rejection_sample_split": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "sd_fill_uniforms": (i32, [vp, i32, C.c_uint64, vp, vp]),
     "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i64, C.c_float,
                                        C.c_uint32, i32, vp]),

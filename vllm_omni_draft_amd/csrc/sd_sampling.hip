@@ -267,6 +267,334 @@ __global__ __launch_bounds__(kSampleThreads) void softmax_rows_kernel(
   for (int i = tid; i < V; i += blockDim.x) out[i] = expf(row[i] * inv_t - mx) * inv;
 }
 
+// ---------------------------------------------------------------------------------------
+// Split forms: a vocabulary row is cut into kRowParts slices, one workgroup each, so that a
+// handful of rows still spreads over the chip; a per-row finishing step combines the slices.
+// Scratch per row: kRowParts x {f64 mass, i32 last index with mass, f32 max, f32 sum}.
+constexpr int kRowParts = 64;
+constexpr int kPartThreads = 256;
+
+struct RowScratch {
+  double* mass;   // [R][kRowParts]
+  int32_t* last;  // [R][kRowParts]
+  float* pmax;    // [R][kRowParts]
+  float* psum;    // [R][kRowParts]
+};
+
+__host__ __device__ inline size_t row_scratch_bytes(int R) {
+  return (size_t)R * kRowParts * (sizeof(double) + sizeof(int32_t) + 2 * sizeof(float));
+}
+
+__host__ __device__ inline RowScratch row_scratch(void* base, int R) {
+  RowScratch r;
+  r.mass = reinterpret_cast<double*>(base);
+  r.last = reinterpret_cast<int32_t*>(r.mass + (size_t)R * kRowParts);
+  r.pmax = reinterpret_cast<float*>(r.last + (size_t)R * kRowParts);
+  r.psum = r.pmax + (size_t)R * kRowParts;
+  return r;
+}
+
+__device__ __forceinline__ void part_range(int part, int V, int& lo, int& hi) {
+  const int chunk = ((V + kRowParts - 1) / kRowParts + 3) & ~3;
+  lo = min(part * chunk, V);
+  hi = min(lo + chunk, V);
+}
+
+// Block-wide sum of doubles / max of floats / max of ints for kPartThreads threads.
+__device__ __forceinline__ double part_block_sum(double v, double* smem) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < kPartThreads / 64; ++w) t += smem[w];
+  return t;
+}
+
+__global__ __launch_bounds__(kPartThreads) void softmax_partial_kernel(
+    const float* __restrict__ logits, int64_t ld, float inv_t, RowScratch sc, int V) {
+  __shared__ float s_f[kPartThreads / 64];
+  __shared__ double s_d[kPartThreads / 64];
+  const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  int lo, hi;
+  part_range(part, V, lo, hi);
+  const float* row = logits + (size_t)r * ld;
+  float mx = -INFINITY;
+  for (int i = lo + tid; i < hi; i += kPartThreads) mx = fmaxf(mx, row[i] * inv_t);
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) s_f[tid >> 6] = mx;
+  __syncthreads();
+  mx = s_f[0];
+  for (int w = 1; w < kPartThreads / 64; ++w) mx = fmaxf(mx, s_f[w]);
+  double sum = 0.0;
+  if (mx != -INFINITY)
+    for (int i = lo + tid; i < hi; i += kPartThreads) sum += (double)expf(row[i] * inv_t - mx);
+  const double total = part_block_sum(sum, s_d);
+  if (tid == 0) {
+    sc.pmax[(size_t)r * kRowParts + part] = mx;
+    sc.psum[(size_t)r * kRowParts + part] = (float)total;
+  }
+}
+
+__global__ __launch_bounds__(kPartThreads) void softmax_finish_kernel(
+    const float* __restrict__ logits, int64_t ld, float inv_t, RowScratch sc,
+    float* __restrict__ probs, int64_t ld_probs, int V) {
+  const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  // every thread folds the row's 64 slice statistics the same way
+  float mx = -INFINITY;
+  for (int p = 0; p < kRowParts; ++p) mx = fmaxf(mx, sc.pmax[(size_t)r * kRowParts + p]);
+  double total = 0.0;
+  for (int p = 0; p < kRowParts; ++p) {
+    const float pm = sc.pmax[(size_t)r * kRowParts + p];
+    if (pm != -INFINITY) total += (double)sc.psum[(size_t)r * kRowParts + p] * (double)expf(pm - mx);
+  }
+  const float inv = (float)(1.0 / total);
+  int lo, hi;
+  part_range(part, V, lo, hi);
+  const float* row = logits + (size_t)r * ld;
+  float* out = probs + (size_t)r * ld_probs;
+  for (int i = lo + tid; i < hi; i += kPartThreads) out[i] = expf(row[i] * inv_t - mx) * inv;
+}
+
+// First rejected position of sequence b (or L when every proposal is accepted).
+__device__ __forceinline__ int first_reject(const float* __restrict__ pb, const float* __restrict__ qb,
+                                            const int64_t* __restrict__ draft_ids,
+                                            const float* __restrict__ u_accept, int b, int k, int L,
+                                            int V) {
+  int j = L;
+  for (int i = L - 1; i >= 0; --i) {
+    const int64_t x = draft_ids[(size_t)b * k + i];
+    bool ok = false;
+    if (x >= 0 && x < V) {
+      const float uq = __fmul_rn(u_accept[(size_t)b * k + i], qb[(size_t)i * V + x]);
+      ok = uq < pb[(size_t)i * V + x];
+    }
+    if (!ok) j = i;
+  }
+  return j;
+}
+
+struct ResidualRows {  // which rows the residual max(p - q, 0) of "row r" is taken from
+  const float* p;      // p row r at p + r * ld_p
+  int64_t ld_p;
+  // rejection sampling (draft_ids != nullptr): r is a sequence; the rows are the target / draft
+  // rows of its first rejected position
+  const float* q;
+  const int64_t* draft_ids;
+  const float* u_accept;
+  const int32_t* proposal_lens;
+  int k;
+};
+
+__device__ __forceinline__ bool residual_rows(const ResidualRows& a, int r, int V, const float*& p,
+                                              const float*& q, int& j, int& L) {
+  if (!a.draft_ids) {
+    p = a.p + (size_t)r * a.ld_p;
+    q = nullptr;
+    j = 0;
+    L = 0;
+    return true;
+  }
+  L = a.proposal_lens ? a.proposal_lens[r] : a.k;
+  L = min(max(L, 0), a.k);
+  const float* pb = a.p + (size_t)r * (a.k + 1) * V;
+  const float* qb = a.q + (size_t)r * a.k * V;
+  j = first_reject(pb, qb, a.draft_ids, a.u_accept, r, a.k, L, V);
+  p = pb + (size_t)j * V;
+  q = j < L ? qb + (size_t)j * V : nullptr;
+  return !(j == L && L == a.k);  // all accepted: the bonus token, no residual draw
+}
+
+__global__ __launch_bounds__(kPartThreads) void residual_mass_kernel(ResidualRows a, RowScratch sc,
+                                                                    int V) {
+  __shared__ double s_d[kPartThreads / 64];
+  __shared__ int s_i[kPartThreads / 64];
+  const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  const float *p, *q;
+  int j, L;
+  if (!residual_rows(a, r, V, p, q, j, L)) return;
+  int lo, hi;
+  part_range(part, V, lo, hi);
+  double local = 0.0;
+  int last_pos = -1;
+  for (int i = lo + tid * 4; i < hi; i += kPartThreads * 4) {
+    const float4 pv = *reinterpret_cast<const float4*>(p + i);
+    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q) qv = *reinterpret_cast<const float4*>(q + i);
+    const float e[4] = {fmaxf(pv.x - qv.x, 0.f), fmaxf(pv.y - qv.y, 0.f), fmaxf(pv.z - qv.z, 0.f),
+                        fmaxf(pv.w - qv.w, 0.f)};
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      local += (double)e[jj];
+      if (e[jj] > 0.f) last_pos = i + jj;
+    }
+  }
+  const double total = part_block_sum(local, s_d);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) last_pos = max(last_pos, __shfl_xor(last_pos, o, 64));
+  if ((tid & 63) == 0) s_i[tid >> 6] = last_pos;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < kPartThreads / 64; ++w) last_pos = max(last_pos, s_i[w]);
+    sc.mass[(size_t)r * kRowParts + part] = total;
+    sc.last[(size_t)r * kRowParts + part] = last_pos;
+  }
+}
+
+// Inverse-CDF pick for row r from the slice masses: the slice whose running sum first exceeds
+// u * total, then a scan inside it (same rule as block_sample_residual).  Whole block.
+__device__ int pick_from_parts(const float* __restrict__ p, const float* __restrict__ q, int V,
+                               float u, const RowScratch& sc, int r) {
+  __shared__ double s_prefix[kRowParts + 1];
+  __shared__ double s_w[kPartThreads / 64];
+  __shared__ int s_found, s_part;
+  __shared__ float s_f[kPartThreads / 64];
+  __shared__ int s_i[kPartThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    double c = 0.0;
+    for (int pp = 0; pp < kRowParts; ++pp) {
+      s_prefix[pp] = c;
+      c += sc.mass[(size_t)r * kRowParts + pp];
+    }
+    s_prefix[kRowParts] = c;
+    s_found = 0x7fffffff;
+  }
+  __syncthreads();
+  const double total = s_prefix[kRowParts];
+  if (!(total > 0.0)) {  // no mass: argmax(p), whole row
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += kPartThreads)
+      if (p[i] > best) { best = p[i]; bi = i; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { s_f[wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    best = s_f[0];
+    bi = s_i[0];
+    for (int w = 1; w < kPartThreads / 64; ++w)
+      if (s_f[w] > best || (s_f[w] == best && s_i[w] < bi)) { best = s_f[w]; bi = s_i[w]; }
+    return bi == 0x7fffffff ? 0 : bi;
+  }
+  const double thr = (double)u * total;
+  if (tid == 0) {
+    int part = -1;
+    for (int pp = 0; pp < kRowParts; ++pp)
+      if (s_prefix[pp] <= thr && s_prefix[pp + 1] > thr) { part = pp; break; }
+    s_part = part;
+  }
+  __syncthreads();
+  const int part = s_part;
+  if (part >= 0) {
+    int lo, hi;
+    part_range(part, V, lo, hi);
+    double carry = s_prefix[part];
+    for (int base = lo; base < hi; base += kPartThreads * 4) {
+      const int i = base + tid * 4;
+      float e[4] = {0.f, 0.f, 0.f, 0.f};
+      if (i < hi) {
+        const float4 pv = *reinterpret_cast<const float4*>(p + i);
+        float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q) qv = *reinterpret_cast<const float4*>(q + i);
+        e[0] = fmaxf(pv.x - qv.x, 0.f);
+        e[1] = fmaxf(pv.y - qv.y, 0.f);
+        e[2] = fmaxf(pv.z - qv.z, 0.f);
+        e[3] = fmaxf(pv.w - qv.w, 0.f);
+      }
+      const double s4 = (double)e[0] + (double)e[1] + (double)e[2] + (double)e[3];
+      double inc = s4;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+      }
+      __syncthreads();
+      if (lane == 63) s_w[wave] = inc;
+      __syncthreads();
+      double wave_prefix = 0.0, tile_total = 0.0;
+      for (int w = 0; w < kPartThreads / 64; ++w) {
+        if (w < wave) wave_prefix += s_w[w];
+        tile_total += s_w[w];
+      }
+      const double excl = carry + wave_prefix + (inc - s4);
+      if (i < hi && excl <= thr && excl + s4 > thr) {
+        double c = excl;
+        int idx = i + 3;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          c += (double)e[jj];
+          if (c > thr) { idx = i + jj; break; }
+        }
+        atomicMin(&s_found, idx);
+      }
+      carry += tile_total;
+      __syncthreads();
+      if (s_found != 0x7fffffff) break;
+    }
+  }
+  const int found = s_found;
+  if (found != 0x7fffffff) return found;
+  int last_pos = -1;  // rounding left no index: the last one with mass
+  for (int pp = 0; pp < kRowParts; ++pp) last_pos = max(last_pos, sc.last[(size_t)r * kRowParts + pp]);
+  return max(last_pos, 0);
+}
+
+__global__ __launch_bounds__(kPartThreads) void sample_finish_kernel(
+    ResidualRows a, RowScratch sc, const float* __restrict__ uniforms, int64_t* __restrict__ ids,
+    int V) {
+  const int r = blockIdx.x;
+  const int idx = pick_from_parts(a.p + (size_t)r * a.ld_p, nullptr, V, uniforms[r], sc, r);
+  if (threadIdx.x == 0) ids[r] = idx;
+}
+
+__global__ __launch_bounds__(kPartThreads) void rejection_finish_kernel(
+    ResidualRows a, RowScratch sc, const int64_t* __restrict__ bonus_ids,
+    const float* __restrict__ u_recover, int64_t* __restrict__ out_ids,
+    unsigned long long* __restrict__ counters, int V) {
+  const int b = blockIdx.x, tid = threadIdx.x, k = a.k;
+  const float *p, *q;
+  int j, L;
+  int64_t tok;
+  if (residual_rows(a, b, V, p, q, j, L))
+    tok = pick_from_parts(p, q, V, u_recover[(size_t)b * (k + 1) + j], sc, b);
+  else
+    tok = bonus_ids[b];
+  if (tid <= k) {
+    int64_t v = -1;
+    if (tid < j) v = a.draft_ids[(size_t)b * k + tid];
+    else if (tid == j) v = tok;
+    out_ids[(size_t)b * (k + 1) + tid] = v;
+  }
+  if (tid == 0 && counters) {
+    atomicAdd(&counters[0], (unsigned long long)j);
+    atomicAdd(&counters[1], (unsigned long long)(j + 1));
+    atomicAdd(&counters[2], (unsigned long long)L);
+  }
+}
+
+// u[i] = 24-bit uniform in [0, 1) from (seed, *counter, i); one workgroup, which then advances
+// the counter, so a replayed graph draws fresh numbers every time.
+__global__ __launch_bounds__(1024) void fill_uniforms_kernel(float* __restrict__ out, int n,
+                                                            unsigned long long seed,
+                                                            unsigned long long* __restrict__ counter) {
+  const unsigned long long c = *counter;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    unsigned long long z = seed ^ (c * 0x9e3779b97f4a7c15ull) ^ ((unsigned long long)i << 32 | (unsigned)i);
+    z += 0x9e3779b97f4a7c15ull;   // splitmix64 finaliser
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    z ^= z >> 31;
+    out[i] = (float)(z >> 40) * (1.0f / 16777216.0f);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = c + 1;
+}
+
 __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     const float* __restrict__ probs, int64_t ld, const float* __restrict__ uniforms,
     int64_t* __restrict__ ids, int V) {
@@ -550,6 +878,83 @@ extern "C" int sd_sample_rows(const float* probs, int64_t ld, const float* unifo
   hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(kSampleThreads), 0,
                      (hipStream_t)stream, probs, ld, uniforms, ids, V);
   SD_CHECK_LAUNCH("sd_sample_rows");
+  return SD_OK;
+}
+
+extern "C" size_t sd_sampling_scratch_bytes(int R) {
+  return R > 0 ? (row_scratch_bytes(R) + 255) & ~(size_t)255 : 0;
+}
+
+extern "C" int sd_softmax_rows_split(const float* logits, int64_t ld, float temperature,
+                                     float* probs, int64_t ld_probs, int R, int V, void* scratch,
+                                     sd_stream_t stream) {
+  SD_REQUIRE(R >= 0 && V >= 1 && ld >= V && ld_probs >= V && logits && probs && scratch &&
+                 temperature > 0.f,
+             SD_ERR_INVALID, "sd_softmax_rows_split: bad arguments (R=%d V=%d T=%g)", R, V,
+             (double)temperature);
+  if (R == 0) return SD_OK;
+  const RowScratch sc = row_scratch(scratch, R);
+  hipLaunchKernelGGL(softmax_partial_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
+                     (hipStream_t)stream, logits, ld, 1.0f / temperature, sc, V);
+  SD_CHECK_LAUNCH("sd_softmax_rows_split");
+  hipLaunchKernelGGL(softmax_finish_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
+                     (hipStream_t)stream, logits, ld, 1.0f / temperature, sc, probs, ld_probs, V);
+  SD_CHECK_LAUNCH("sd_softmax_rows_split");
+  return SD_OK;
+}
+
+extern "C" int sd_sample_rows_split(const float* probs, int64_t ld, const float* uniforms,
+                                    int64_t* ids, int R, int V, void* scratch,
+                                    sd_stream_t stream) {
+  SD_REQUIRE(R >= 0 && V >= 4 && ld >= V && probs && uniforms && ids && scratch, SD_ERR_INVALID,
+             "sd_sample_rows_split: bad arguments (R=%d V=%d)", R, V);
+  SD_REQUIRE(V % 4 == 0 && ld % 4 == 0 && sd_aligned16(probs), SD_ERR_UNSUPPORTED,
+             "sd_sample_rows_split: V and ld must be multiples of 4, rows 16-byte aligned");
+  if (R == 0) return SD_OK;
+  const RowScratch sc = row_scratch(scratch, R);
+  const ResidualRows a{probs, ld, nullptr, nullptr, nullptr, nullptr, 0};
+  hipLaunchKernelGGL(residual_mass_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
+                     (hipStream_t)stream, a, sc, V);
+  SD_CHECK_LAUNCH("sd_sample_rows_split");
+  hipLaunchKernelGGL(sample_finish_kernel, dim3(R), dim3(kPartThreads), 0, (hipStream_t)stream, a,
+                     sc, uniforms, ids, V);
+  SD_CHECK_LAUNCH("sd_sample_rows_split");
+  return SD_OK;
+}
+
+extern "C" int sd_rejection_sample_split(const float* target_probs, const int64_t* bonus_ids,
+                                         const float* draft_probs, const int64_t* draft_ids,
+                                         const float* u_accept, const float* u_recover,
+                                         const int32_t* proposal_lens, int64_t* out_ids,
+                                         int64_t* counters, int B, int k, int V, void* scratch,
+                                         sd_stream_t stream) {
+  SD_REQUIRE(B >= 0 && k >= 1 && k <= 63 && V >= 4, SD_ERR_INVALID,
+             "sd_rejection_sample_split: need B>=0, 1<=k<=63, V>=4 (B=%d k=%d V=%d)", B, k, V);
+  SD_REQUIRE(V % 4 == 0, SD_ERR_UNSUPPORTED, "sd_rejection_sample_split: V %% 4 != 0 (V=%d)", V);
+  SD_REQUIRE(target_probs && bonus_ids && draft_probs && draft_ids && u_accept && u_recover &&
+                 out_ids && scratch, SD_ERR_INVALID, "sd_rejection_sample_split: null pointer");
+  SD_REQUIRE(sd_aligned16(target_probs) && sd_aligned16(draft_probs), SD_ERR_INVALID,
+             "sd_rejection_sample_split: probability rows must be 16-byte aligned");
+  if (B == 0) return SD_OK;
+  const RowScratch sc = row_scratch(scratch, B);
+  const ResidualRows a{target_probs, 0, draft_probs, draft_ids, u_accept, proposal_lens, k};
+  hipLaunchKernelGGL(residual_mass_kernel, dim3(kRowParts, B), dim3(kPartThreads), 0,
+                     (hipStream_t)stream, a, sc, V);
+  SD_CHECK_LAUNCH("sd_rejection_sample_split");
+  hipLaunchKernelGGL(rejection_finish_kernel, dim3(B), dim3(kPartThreads), 0, (hipStream_t)stream,
+                     a, sc, bonus_ids, u_recover, out_ids,
+                     reinterpret_cast<unsigned long long*>(counters), V);
+  SD_CHECK_LAUNCH("sd_rejection_sample_split");
+  return SD_OK;
+}
+
+extern "C" int sd_fill_uniforms(float* out, int n, uint64_t seed, uint64_t* counter,
+                                sd_stream_t stream) {
+  SD_REQUIRE(out && counter && n >= 0, SD_ERR_INVALID, "sd_fill_uniforms: bad arguments");
+  if (n == 0) return SD_OK;
+  hipLaunchKernelGGL(fill_uniforms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, out, n,
+                     (unsigned long long)seed, reinterpret_cast<unsigned long long*>(counter));
+  SD_CHECK_LAUNCH("sd_fill_uniforms");
   return SD_OK;
 }
 

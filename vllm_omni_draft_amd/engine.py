@@ -98,12 +98,19 @@ class SpecEngine:
             f32 = dict(dtype=torch.float32, device=dev)
             self.t_probs = torch.empty(B, k + 1, self.V, **f32)
             self.d_probs = torch.empty(B, max(k, 1), self.V, **f32)
-            self.u_draft = torch.zeros(max(k, 1), B, **f32)
-            self.u_accept = torch.zeros(B, max(k, 1), **f32)
-            self.u_recover = torch.zeros(B, k + 1, **f32)
-            self.u_bonus = torch.zeros(B, **f32)
+            # one flat buffer of uniforms, refilled on the device at the start of every step
+            kk = max(k, 1)
+            sizes = [kk * B, B * kk, B * (k + 1), B]
+            self.u_all = torch.zeros(sum(sizes), **f32)
+            parts = torch.split(self.u_all, sizes)
+            self.u_draft = parts[0].view(kk, B)
+            self.u_accept = parts[1].view(B, kk)
+            self.u_recover = parts[2].view(B, k + 1)
+            self.u_bonus = parts[3]
+            self.u_counter = torch.zeros(1, dtype=torch.int64, device=dev)
             self.bonus_ids = torch.zeros(B, dtype=torch.int64, device=dev)
-            self.rng = torch.Generator(device=dev).manual_seed(cfg.seed)
+            self.rng = torch.Generator(device=dev).manual_seed(cfg.seed)  # first-token draw
+            self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * (k + 1)), dev)
         # synthetic acceptance control (benchmarks with random weights)
         self.truth: Optional[torch.Tensor] = None
         self.accept_prob = 0.0
@@ -227,8 +234,10 @@ class SpecEngine:
         self._forward(self.target, self.t_kv, self.tok_buf, 2, 1, self.seq_lens, -1, B, 1,
                       self.t_logits)
         if self.sampling:
-            ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V))
-            ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp)
+            ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V),
+                             scratch=self.samp_scratch)
+            ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
+                            scratch=self.samp_scratch)
             ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf,
                               self.gen_tokens, self.gen_counts, 0, self.step_out)
         else:
@@ -261,9 +270,10 @@ class SpecEngine:
                 continue
             if self.sampling:
                 ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
-                                 out_ptr=self.d_probs.data_ptr() + i * self.V * 4, out_ld=k * self.V)
+                                 out_ptr=self.d_probs.data_ptr() + i * self.V * 4, out_ld=k * self.V,
+                                 scratch=self.samp_scratch)
                 ops.sample_rows(self.d_probs.view(-1, self.V)[:B * k], self.u_draft[i],
-                                out=self.ids_tmp, row_offset=i, row_step=k)
+                                out=self.ids_tmp, row_offset=i, row_step=k, scratch=self.samp_scratch)
             else:
                 ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
             ops.store_proposal(self.ids_tmp, self.tok_buf, k, i, self.seq_lens, self.truth,
@@ -281,9 +291,11 @@ class SpecEngine:
         if fused:
             ops.argmax_partial(rows, self.part_val, self.part_idx)
         elif self.sampling:
-            ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V))
+            ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V),
+                             scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
-                            out=self.bonus_ids, row_offset=k, row_step=k + 1)
+                            out=self.bonus_ids, row_offset=k, row_step=k + 1,
+                            scratch=self.samp_scratch)
         else:
             ops.argmax_rows(rows, out=self.target_ids.view(-1))
 
@@ -296,11 +308,9 @@ class SpecEngine:
                                      self.gen_counts, k, self.step_out)
             return
         if self.sampling:
-            _lib.check(_lib.load().sd_rejection_sample(
-                self.t_probs.data_ptr(), self.bonus_ids.data_ptr(), self.d_probs.data_ptr(),
-                self.draft_ids.data_ptr(), self.u_accept.data_ptr(), self.u_recover.data_ptr(),
-                None, self.out_ids.data_ptr(), self.counters.data_ptr(), B, k, self.V,
-                torch.cuda.current_stream().cuda_stream), "sd_rejection_sample")
+            ops.rejection_sample(self.t_probs[:B], self.bonus_ids[:B], self.d_probs[:B],
+                                 self.draft_ids[:B], self.u_accept[:B], self.u_recover[:B], None,
+                                 self.counters, scratch=self.samp_scratch, out=self.out_ids[:B])
         else:
             ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], None, self.counters,
                               out=self.out_ids)
@@ -330,8 +340,8 @@ class SpecEngine:
 
     # ------------------------------------------------------------------ stepping
     def _refresh_uniforms(self) -> None:
-        for t in (self.u_draft, self.u_accept, self.u_recover, self.u_bonus):
-            t.copy_(torch.rand(t.shape, generator=self.rng, device=self.device))
+        """Fresh uniforms for the coming step, drawn on the device (no host work, no sync)."""
+        ops.fill_uniforms(self.u_all, self.cfg.seed, self.u_counter)
 
     def step(self, sync: bool = True) -> Optional[List[List[int]]]:
         """Runs one step for every active sequence.  With sync=True returns the

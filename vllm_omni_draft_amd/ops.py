@@ -40,8 +40,21 @@ def device_info():
 
 
 # ---------------------------------------------------------------- acceptance
+def sampling_scratch(rows: int, device="cuda") -> torch.Tensor:
+    """Scratch for the split (many-workgroups-per-row) forms of softmax_rows, sample_rows and
+    rejection_sample over up to `rows` rows / sequences."""
+    return torch.empty(max(int(_lib.load().sd_sampling_scratch_bytes(rows)), 16),
+                       dtype=torch.uint8, device=device)
+
+
+def _scratch_ok(scratch, rows, what):
+    if scratch.numel() < _lib.load().sd_sampling_scratch_bytes(rows):
+        raise _lib.SdError(f"{what}: scratch too small for {rows} rows")
+
+
 def rejection_sample(target_probs, bonus_ids, draft_probs, draft_ids, u_accept, u_recover,
-                     proposal_lens=None, counters=None) -> torch.Tensor:
+                     proposal_lens=None, counters=None, scratch=None, out=None) -> torch.Tensor:
+    """scratch (sampling_scratch(B)): use the split form."""
     B, k1, V = target_probs.shape
     k = k1 - 1
     _need(target_probs, torch.float32, "target_probs")
@@ -59,7 +72,15 @@ def rejection_sample(target_probs, bonus_ids, draft_probs, draft_ids, u_accept, 
         _need(proposal_lens, torch.int32, "proposal_lens")
     if counters is not None:
         _need(counters, torch.int64, "counters")
-    out = torch.empty(B, k + 1, dtype=torch.int64, device=target_probs.device)
+    if out is None:
+        out = torch.empty(B, k + 1, dtype=torch.int64, device=target_probs.device)
+    if scratch is not None:
+        _scratch_ok(scratch, B, "rejection_sample")
+        _lib.check(_lib.load().sd_rejection_sample_split(
+            _p(target_probs), _p(bonus), _p(draft_probs), _p(draft_ids), _p(u_accept),
+            _p(u_recover), _p(proposal_lens), _p(out), _p(counters), B, k, V, _p(scratch),
+            _stream()), "sd_rejection_sample_split")
+        return out
     _lib.check(_lib.load().sd_rejection_sample(
         _p(target_probs), _p(bonus), _p(draft_probs), _p(draft_ids), _p(u_accept), _p(u_recover),
         _p(proposal_lens), _p(out), _p(counters), B, k, V, _stream()), "sd_rejection_sample")
@@ -97,7 +118,7 @@ def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None, *, row
 
 
 def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out=None, *, row_offset=0,
-                 row_step=1, out_ptr=None, out_ld=None) -> torch.Tensor:
+                 row_step=1, out_ptr=None, out_ld=None, scratch=None) -> torch.Tensor:
     """softmax(logits / T) of rows row_offset, row_offset+row_step, ...; the
     result goes to `out` ([R, V]) or to raw address out_ptr with row stride out_ld."""
     _need(logits, torch.float32, "logits")
@@ -106,6 +127,12 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out=None, *, ro
     if out is None and out_ptr is None:
         out = torch.empty(R, V, dtype=torch.float32, device=logits.device)
     dst = out_ptr if out_ptr is not None else out.data_ptr()
+    if scratch is not None:
+        _scratch_ok(scratch, R, "softmax_rows")
+        _lib.check(_lib.load().sd_softmax_rows_split(
+            logits.data_ptr() + row_offset * V * 4, V * row_step, float(temperature), dst,
+            out_ld or V, R, V, _p(scratch), _stream()), "sd_softmax_rows_split")
+        return out
     _lib.check(_lib.load().sd_softmax_rows(logits.data_ptr() + row_offset * V * 4, V * row_step,
                                            float(temperature), dst, out_ld or V, R, V, _stream()),
                "sd_softmax_rows")
@@ -113,7 +140,7 @@ def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out=None, *, ro
 
 
 def sample_rows(probs: torch.Tensor, uniforms: torch.Tensor, out=None, *, row_offset=0,
-                row_step=1) -> torch.Tensor:
+                row_step=1, scratch=None) -> torch.Tensor:
     """Inverse-CDF draw from rows row_offset, row_offset+row_step, ... of probs [*, V]."""
     _need(probs, torch.float32, "probs")
     _need(uniforms, torch.float32, "uniforms")
@@ -123,6 +150,12 @@ def sample_rows(probs: torch.Tensor, uniforms: torch.Tensor, out=None, *, row_of
         raise _lib.SdError("sample_rows: need one uniform per row")
     if out is None:
         out = torch.empty(R, dtype=torch.int64, device=probs.device)
+    if scratch is not None:
+        _scratch_ok(scratch, R, "sample_rows")
+        _lib.check(_lib.load().sd_sample_rows_split(
+            probs.data_ptr() + row_offset * V * 4, V * row_step, _p(uniforms), _p(out), R, V,
+            _p(scratch), _stream()), "sd_sample_rows_split")
+        return out
     _lib.check(_lib.load().sd_sample_rows(probs.data_ptr() + row_offset * V * 4, V * row_step,
                                           _p(uniforms), _p(out), R, V, _stream()),
                "sd_sample_rows")
@@ -262,6 +295,14 @@ def linear_attn_merge(W, workspace, seq_lens, pos_offset, B, q_len, Hq, Hkv, D, 
         D, max_ctx, split_tokens, _p(bias), _p(residual), _p(out), out.stride(0), Wt.N, epilogue,
         _stream()), "sd_linear_attn_merge")
     return out
+
+
+def fill_uniforms(out: torch.Tensor, seed: int, counter: torch.Tensor) -> None:
+    """out (f32, contiguous) <- uniforms in [0, 1) from (seed, counter[0]); counter[0] += 1."""
+    _need(out, torch.float32, "out")
+    _need(counter, torch.int64, "counter")
+    _lib.check(_lib.load().sd_fill_uniforms(_p(out), out.numel(), int(seed) & (2 ** 64 - 1),
+                                            _p(counter), _stream()), "sd_fill_uniforms")
 
 
 # ---------------------------------------------------------------- step glue
