@@ -225,6 +225,30 @@ int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
               const void* residual, void* out, int64_t ldo, int M, int N, int K,
               int epilogue, sd_stream_t stream);
 
+/* The same linear layers at up to 256 token rows (batched draft passes, batched
+ * verify; replaces the batch-expanded target pass of
+ * spec_decode.batch_expansion at batch > 2), over the same tiled weights.
+ * Activations pass through LDS shared by the waves of a workgroup; matrices
+ * with few rows split K over workgroups, partial sums are added in a fixed
+ * order by a second launch that applies the epilogue.  A token row's result
+ * depends on (N, K) only, not on M; it differs in rounding from sd_linear's
+ * (another summation order), so a caller uses one family for all its passes.
+ * No fused norm: normalise first (sd_rmsnorm / sd_layernorm).
+ * workspace: sd_linear_wide_workspace_bytes(M, N, K, epilogue) bytes; for
+ * sd_qkv_rope_wide pass N = (Hq + 2*Hkv) * D and SD_EPI_STORE.              */
+size_t sd_linear_wide_workspace_bytes(int M, int N, int K, int epilogue);
+int sd_linear_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+                   const void* residual, void* out, int64_t ldo, int M, int N,
+                   int K, int epilogue, void* workspace, size_t workspace_bytes,
+                   sd_stream_t stream);
+int sd_qkv_rope_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+                     void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
+                     void* k_cache, void* v_cache, const int32_t* block_tables,
+                     int max_blocks_per_seq, const int32_t* seq_lens,
+                     int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
+                     int K, void* workspace, size_t workspace_bytes,
+                     sd_stream_t stream);
+
 /* Output projection straight from attention partials: sd_paged_attention with
  * out == NULL (and more than one split) leaves its per-split partials in the
  * workspace; this linear merges them while it stages its activations (same
@@ -345,7 +369,7 @@ typedef struct {
 } sd_kv_cache;
 
 typedef struct {
-  int B, q_len;              /* q_len tokens per sequence, B*q_len <= 16 */
+  int B, q_len;              /* q_len tokens per sequence, B*q_len <= 16 (256 if wide) */
   const int32_t* token_ids;  /* token t of seq b at [b*tok_stride + tok_offset + t] */
   int64_t tok_stride, tok_offset;
   const int32_t* seq_lens;   /* [B] device; first new position = seq_lens[b] + pos_offset */
@@ -353,6 +377,10 @@ typedef struct {
   int max_ctx;               /* host bound on seq_lens[b] + pos_offset + q_len */
   int split_tokens;          /* attention keys per workgroup */
   float* logits;             /* [B*q_len, vocab] f32 out, or NULL to skip the head */
+  int wide;                  /* 0: B*q_len <= 16 (sd_linear family); 1: up to 256 rows
+                                through sd_linear_wide / sd_qkv_rope_wide.  The two families
+                                round differently: a caller keeps one for all its passes.
+                                sd_model_workspace_bytes plans for it when max_rows > 16. */
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

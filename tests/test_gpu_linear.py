@@ -171,3 +171,74 @@ def test_fused_qkv_rope_append_matches_unfused(Hq, Hkv, D, H, rope):
     for a, b in zip(*caches):
         torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2)
     assert caches[1][1].abs().sum() > 0 and caches[1][2].abs().sum() > 0
+
+
+# ------------------------------------------------------------------ 17..256 token rows
+@pytest.mark.parametrize("M", [17, 32, 50, 192, 256])
+@pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (257, 896), (96, 14336)])
+def test_wide_linear_epilogues(M, N, K):
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=gen, device="cuda")).to(torch.bfloat16)
+    bias = (torch.randn(2 * N, generator=gen, device="cuda") * 0.1).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=gen, device="cuda").to(torch.bfloat16)
+    W2 = (torch.randn(2 * N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    W = W2[:N].contiguous()
+    for epi in (ops.EPI_STORE, ops.EPI_RESIDUAL, ops.EPI_RELU, ops.EPI_F32, ops.EPI_GELU_TANH):
+        for b in (None, bias[:N].contiguous()):
+            got = ops.linear_wide(W, x, b, res if epi == ops.EPI_RESIDUAL else None, epi).float()
+            ref = _ref_linear(W, x, b, res, epi, ops)
+            torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+    for b in (None, bias):
+        got = ops.linear_wide(W2, x, b, None, ops.EPI_SILU_MUL).float()
+        ref = _ref_linear(W2, x, b, None, ops.EPI_SILU_MUL, ops)
+        torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
+
+
+def test_wide_linear_f32_accuracy_and_row_independence():
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    W = (torch.randn(512, 4096, generator=gen, device="cuda") * 0.02).to(torch.bfloat16)
+    x = torch.randn(192, 4096, generator=gen, device="cuda").to(torch.bfloat16)
+    Wt = ops.tile_weights(W)
+    full = ops.linear_wide(Wt, x, None, None, ops.EPI_F32)
+    ref = x.double() @ W.double().t()
+    assert (full.double() - ref).abs().max().item() < 2e-5 * 4096 ** 0.5
+    # a row's bits do not depend on how many rows share the pass (the K split is a
+    # function of the matrix alone)
+    for M, m0 in ((1, 0), (6, 100), (32, 160), (100, 92)):
+        part = ops.linear_wide(Wt, x[m0:m0 + M].contiguous(), None, None, ops.EPI_F32)
+        assert torch.equal(part, full[m0:m0 + M]), (M, m0)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,H,rope", [(32, 8, 128, 4096, True), (12, 12, 64, 768, False),
+                                              (14, 2, 64, 896, True)])
+def test_wide_qkv_rope_append_matches_narrow_ops(Hq, Hkv, D, H, rope):
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    gen = torch.Generator(device="cuda").manual_seed(Hq * D)
+    B, q_len = 8, 6
+    M = B * q_len
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=128)
+    cs = rope_table(cfg).cuda() if rope else None
+    x = torch.randn(M, H, generator=gen, device="cuda").to(torch.bfloat16)
+    W = (torch.randn((Hq + 2 * Hkv) * D, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    bias = (0.1 * torch.randn((Hq + 2 * Hkv) * D, generator=gen, device="cuda")).to(torch.bfloat16)
+    bt = torch.randperm(B * 3, generator=gen, device="cuda").to(torch.int32).view(B, 3).contiguous()
+    seq_lens = torch.randint(1, 30, (B,), generator=gen, device="cuda").to(torch.int32)
+    caches = []
+    for wide in (False, True):
+        kc = torch.zeros(B * 3, Hkv, D * 16, dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        if wide:
+            q = ops.qkv_rope_wide(ops.tile_weights(W, ops.TILE_ROTARY, D), x, bias, cs, kc, vc, bt,
+                                  seq_lens, -1, B, q_len, Hq, Hkv, D)
+        else:
+            qkv = torch.cat([ops.linear(W, x[i:i + 16].contiguous(), bias, None, ops.EPI_STORE)
+                             for i in range(0, M, 16)])
+            ops.rope_append(qkv, cs, kc, vc, bt, seq_lens, -1, B, q_len, Hq, Hkv, D)
+            q = qkv[:, :Hq * D].contiguous()
+        caches.append((q.float(), kc.float(), vc.float()))
+    for a, b in zip(*caches):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2)
+    assert caches[1][1].abs().sum() > 0 and caches[1][2].abs().sum() > 0

@@ -29,12 +29,12 @@ def _bf(state):
     return {k: v.to(torch.bfloat16).float() for k, v in state.items()}
 
 
-def _logits_via_engine(w, tokens, chunks):
+def _logits_via_engine(w, tokens, chunks, wide=False):
     """Feeds `tokens` through the native forward in the given chunk sizes."""
     from vllm_omni_draft_amd.kv_cache import PagedKVCache
     from vllm_omni_draft_amd.model_runner import DecoderModel
     cfg = w.cfg
-    model = DecoderModel(w, max_ctx=128, split_tokens=128)
+    model = DecoderModel(w, max_ctx=128, split_tokens=128, wide=wide)
     kv = PagedKVCache(cfg, 16, 1, 128, "cuda")
     kv.ensure_capacity(0, len(tokens))
     tok = torch.tensor(tokens, dtype=torch.int32, device="cuda")
@@ -80,6 +80,27 @@ def test_forward_logits_match_oracle(name):
     assert (got - ref).abs().max().item() < 0.03 * scale, (got - ref).abs().max().item() / scale
     agree = (got.argmax(-1) == ref.argmax(-1)).float().mean().item()
     assert agree > 0.9
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_wide_forward_logits_match_oracle_and_are_chunk_invariant(name):
+    """The 17..256-row kernel family: same oracle bar, and a token's logits do not depend on
+    the number of rows in its pass (within the family)."""
+    ocfg = MODELS[name]
+    state = _bf(random_state(ocfg, seed=11, qkv_bias=(name == "qwen2")))
+    w = _product(ocfg, state, qkv_bias=(name == "qwen2"))
+    toks = torch.randint(0, ocfg.vocab, (37,), generator=torch.Generator().manual_seed(4)).tolist()
+    G = ocfg.n_heads // ocfg.n_kv_heads
+    big = min(64 // G, 37)                      # attention bound: q_len * G <= 64
+    chunks = [big] * (37 // big) + ([37 % big] if 37 % big else [])
+    got = _logits_via_engine(w, toks, chunks, wide=True)
+    lm = OracleLM(ocfg, state, bf16_acts=True)
+    ref = lm.forward(toks, 0, lm.new_cache())
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 0.03 * scale, (got - ref).abs().max().item() / scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
+    again = _logits_via_engine(w, toks, [1] * 5 + [8, 8, 8, 6, 2], wide=True)
+    assert torch.equal(got, again)
 
 
 def test_chunking_is_bit_invariant():
@@ -137,6 +158,31 @@ def test_draft_equals_target_accepts_all_and_batches():
     assert m["accepted"] == m["draft"]
     # batched AR equals single AR too
     assert _generate(_engine(tw, None, 0, max_batch=3), prompts, 40) == ar
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_wide_batch_spec_equals_ar(use_graph):
+    """8 sequences x (k+1 = 6) rows = 48 rows per verify pass: the wide kernel family.  The
+    speculative stream equals the autoregressive one of an engine on the same family."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    g = torch.Generator().manual_seed(9)
+    prompts = [torch.randint(0, tcfg.vocab, (int(n),), generator=g).tolist()
+               for n in torch.randint(3, 40, (8,), generator=g)]
+    ar_eng = _engine(tw, None, 0, max_batch=8, rows="wide", use_graph=use_graph)
+    assert ar_eng.wide
+    ar = _generate(ar_eng, prompts, 40)
+    eng = _engine(tw, dw, 5, max_batch=8, use_graph=use_graph)
+    assert eng.wide and eng.max_rows == 256
+    got = _generate(eng, prompts, 40)
+    assert got == ar
+    # draft == target on the wide family: every proposal accepted
+    eng2 = _engine(tw, tw, 3, max_batch=8, rows="wide", use_graph=use_graph)
+    assert _generate(eng2, prompts, 40) == ar
+    m = eng2.metrics()
+    assert m["accepted"] == m["draft"]
 
 
 def test_synthetic_acceptance_control():

@@ -51,7 +51,7 @@ class KvCacheDesc(C.Structure):
 class ForwardArgs(C.Structure):
     _fields_ = [("B", i32), ("q_len", i32), ("token_ids", vp), ("tok_stride", i64),
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
-                ("split_tokens", i32), ("logits", vp)]
+                ("split_tokens", i32), ("logits", vp), ("wide", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/sd_amd.h declares.
@@ -85,6 +85,10 @@ SIGNATURES = {
     "sd_store_proposal": (i32, [vp, vp, i32, i32, vp, vp, i64, C.c_float, C.c_uint32, i32, vp]),
     "sd_gather_proposals": (i32, [vp, vp, i32, i32, vp]),
     "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
+    "sd_linear_wide_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32]),
+    "sd_linear_wide": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
+    "sd_qkv_rope_wide": (i32, [vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
+                               i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "sd_linear_attn_merge": (i32, [vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                    vp, vp, vp, i64, i32, i32, vp]),
     "sd_tp_unique_id": (i32, [vp]),

@@ -1,0 +1,403 @@
+// Linear layers at 17..256 token rows (batched draft passes, batched verify) over the same
+// pre-tiled weights as the <= 16-row kernel.
+//
+// wide_gemm_kernel: a workgroup of 8 waves owns 16 weight tiles (256 weight rows; wave w the
+// tiles 2w, 2w+1) and one K range.  The activations of the K range pass through LDS in
+// 128-column chunks (double buffered), shared by the 8 waves; the weights go HBM -> VGPR ->
+// MFMA as in the narrow kernel, each A fragment feeding one MFMA per 16-row token tile.  With
+// M = 192 rows an A fragment is used 12 times, so the kernel sits at the MFMA / LDS / HBM
+// balance point rather than being a pure stream.
+//
+// Matrices with few tiles split K over several workgroups.  Partial sums go to a workspace
+// as f32 [split][row][tile row] and wide_epilogue_kernel adds the splits in index order and
+// applies the epilogue, so a row's arithmetic depends on (N, K) only: never on how many rows
+// share the pass.
+#include "sd_common.h"
+
+namespace {
+
+constexpr int kWideThreads = 512;
+constexpr int kWideWaves = kWideThreads / SD_WAVE;
+constexpr int kTilesPerWave = 2;
+constexpr int kTilesPerGroup = kWideWaves * kTilesPerWave;  // 16 tiles = 256 weight rows
+constexpr int kChunkSteps = 4;                              // k-steps (32 columns) per LDS chunk
+constexpr int kChunkCols = kChunkSteps * 32;
+constexpr int kXLD = kChunkCols + 8;                        // padded LDS row (elements)
+constexpr int EPI_QKV_ROPE = 100;
+
+struct WideArgs {
+  const bf16_t* W;  // tiled [n_tiles][K/32][64][8]
+  const bf16_t* x;
+  int64_t ldx;
+  float* part;      // [S][M][NR]
+  int M, K, n_tiles, ks_per_split;
+};
+
+template <int MT>  // token tiles of 16 rows
+__global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [2][MT*16][kXLD]
+  constexpr int kRows = MT * 16;
+  constexpr int kPieces = kRows * (kChunkCols / 8) / kWideThreads;  // 16-byte pieces per thread
+  static_assert(kRows * (kChunkCols / 8) % kWideThreads == 0, "MT must be even");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = a.K / 32;
+  const int NR = a.n_tiles * 16;
+  const int ks_lo = blockIdx.y * a.ks_per_split;
+  const int ks_hi = min(ks_lo + a.ks_per_split, KS);
+  const int n_chunks = (ks_hi - ks_lo + kChunkSteps - 1) / kChunkSteps;
+  const int tile0 = (blockIdx.x * kWideWaves + wave) * kTilesPerWave;
+
+  bf16x8 x_stage[kPieces];
+  auto load_x = [&](int chunk) {
+    const int col0 = (ks_lo + chunk * kChunkSteps) * 32;
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const int p = tid + i * kWideThreads;
+      const int row = p / (kChunkCols / 8), col = col0 + (p % (kChunkCols / 8)) * 8;
+      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < a.M && col < ks_hi * 32) v = *reinterpret_cast<const bf16x8*>(a.x + (size_t)row * a.ldx + col);
+      x_stage[i] = v;
+    }
+  };
+  auto store_x = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const int p = tid + i * kWideThreads;
+      const int row = p / (kChunkCols / 8), c8 = p % (kChunkCols / 8);
+      *reinterpret_cast<bf16x8*>(xs + ((size_t)buf * kRows + row) * kXLD + c8 * 8) = x_stage[i];
+    }
+  };
+  bf16x8 a_nxt[kTilesPerWave][kChunkSteps];
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t)
+#pragma unroll
+      for (int j = 0; j < kChunkSteps; ++j) {
+        const int ks = ks_lo + chunk * kChunkSteps + j;
+        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (tile0 + t < a.n_tiles && ks < ks_hi)
+          v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
+              a.W + ((size_t)(tile0 + t) * KS + ks) * 512 + lane * 8));
+        a_nxt[t][j] = v;
+      }
+  };
+
+  f32x4 acc[kTilesPerWave][MT];
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_x(0);
+  load_a(0);
+  store_x(0);
+  __syncthreads();
+  const int xc = lane & 15, xq = lane >> 4;
+  for (int c = 0; c < n_chunks; ++c) {
+    bf16x8 a_cur[kTilesPerWave][kChunkSteps];
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t)
+#pragma unroll
+      for (int j = 0; j < kChunkSteps; ++j) a_cur[t][j] = a_nxt[t][j];
+    if (c + 1 < n_chunks) {
+      load_x(c + 1);
+      load_a(c + 1);
+    }
+    const bf16_t* xb = xs + (size_t)(c & 1) * kRows * kXLD + (size_t)xc * kXLD + 8 * xq;
+#pragma unroll
+    for (int j = 0; j < kChunkSteps; ++j) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * kXLD + j * 32);
+#pragma unroll
+        for (int t = 0; t < kTilesPerWave; ++t)
+          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[t][j], b, acc[t][mt], 0, 0, 0);
+      }
+    }
+    if (c + 1 < n_chunks) store_x((c + 1) & 1);
+    __syncthreads();
+  }
+
+  // acc[t][mt][reg] = partial of (tile row 4*(lane>>4)+reg of tile tile0+t, token 16*mt + lane&15)
+  float* part = a.part + (size_t)blockIdx.y * a.M * NR;
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t) {
+    if (tile0 + t >= a.n_tiles) continue;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + xc;
+      if (m < a.M)
+        *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)(tile0 + t) * 16 + 4 * xq) = acc[t][mt];
+    }
+  }
+}
+
+__device__ __forceinline__ float silu_w(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_tanh_w(float v) {
+  const float c = 0.7978845608028654f;
+  return 0.5f * v * (1.0f + tanhf(c * (v + 0.044715f * v * v * v)));
+}
+
+struct WideRope {
+  const float* cs;
+  int max_pos;
+  bf16_t* kc;
+  bf16_t* vc;
+  const int32_t* block_tables;
+  int max_blocks;
+  const int32_t* seq_lens;
+  int pos_offset, q_len, Hq, Hkv, D;
+};
+
+struct WideEpiArgs {
+  const float* part;  // [S][M][NR]
+  int S, M, NR, N;
+  const bf16_t* bias;
+  const bf16_t* residual;
+  void* out;
+  int64_t ldo;
+  WideRope rope;
+};
+
+// One thread = 4 consecutive tile rows of one token row (paired modes: rows r..r+3 and their
+// partners r+8..r+11 of a tile).  Splits are added in index order.
+template <int EPI>
+__global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
+  constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
+  const int units_per_row = PAIRED ? a.NR / 8 : a.NR / 4;  // paired: 2 units per tile
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)a.M * units_per_row) return;
+  const int m = (int)(gid / units_per_row), u = (int)(gid % units_per_row);
+  const int tr = PAIRED ? (u >> 1) * 16 + (u & 1) * 4 : u * 4;  // first tile row of the unit
+  f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.S; ++s) {
+    const float* p = a.part + ((size_t)s * a.M + m) * a.NR + tr;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] += v[j];
+    if (PAIRED) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(p + 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] += w[j];
+    }
+  }
+  if (EPI == EPI_QKV_ROPE) {
+    const WideRope& rp = a.rope;
+    const int D = rp.D, half = D / 2, tiles_per_head = D / 16;
+    const int tile = u >> 1, head = tile / tiles_per_head;
+    const int i0 = (tile % tiles_per_head) * 8 + (u & 1) * 4;
+    const int b = m / rp.q_len, t = m - b * rp.q_len;
+    const int pos = rp.seq_lens[b] + rp.pos_offset + t;
+    if (pos < 0) return;
+    const float* cs = rp.cs ? rp.cs + (size_t)min(pos, rp.max_pos - 1) * D : nullptr;
+    const int page = head >= rp.Hq ? rp.block_tables[(size_t)b * rp.max_blocks + (pos >> 4)] : 0;
+    const int slot = pos & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = i0 + j;
+      float l = lo[j], h = hi[j];
+      if (a.bias) {
+        l += (float)a.bias[head * D + i];
+        h += (float)a.bias[head * D + i + half];
+      }
+      l = round_bf16(l);
+      h = round_bf16(h);
+      if (head < rp.Hq + rp.Hkv && cs) {
+        const float c = cs[i], sn = cs[half + i];
+        const float nl = l * c - h * sn, nh = h * c + l * sn;
+        l = nl;
+        h = nh;
+      }
+      if (head < rp.Hq) {
+        bf16_t* q = reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + (size_t)head * D;
+        q[i] = (bf16_t)l;
+        q[i + half] = (bf16_t)h;
+      } else if (head < rp.Hq + rp.Hkv) {
+        bf16_t* kp = rp.kc + ((size_t)page * rp.Hkv + (head - rp.Hq)) * D * 16;
+        const int i2 = i + half;
+        kp[((i >> 3) * 16 + slot) * 8 + (i & 7)] = (bf16_t)l;
+        kp[((i2 >> 3) * 16 + slot) * 8 + (i2 & 7)] = (bf16_t)h;
+      } else {
+        bf16_t* vp = rp.vc + ((size_t)page * rp.Hkv + (head - rp.Hq - rp.Hkv)) * D * 16;
+        const int sl = sd_v_slot(slot);
+        vp[i * 16 + sl] = (bf16_t)l;
+        vp[(i + half) * 16 + sl] = (bf16_t)h;
+      }
+    }
+  } else if (EPI == SD_EPI_SILU_MUL) {
+    const int n0 = (u >> 1) * 8 + (u & 1) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j;
+      if (n >= a.N) break;
+      float g = lo[j], up = hi[j];
+      if (a.bias) {
+        g += (float)a.bias[n];
+        up += (float)a.bias[a.N + n];
+      }
+      g = round_bf16(silu_w(round_bf16(g)));
+      reinterpret_cast<bf16_t*>(a.out)[(size_t)m * a.ldo + n] = (bf16_t)(g * round_bf16(up));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = tr + j;
+      if (n >= a.N) break;
+      float y = lo[j];
+      if (a.bias) y += (float)a.bias[n];
+      const size_t o = (size_t)m * a.ldo + n;
+      if (EPI == SD_EPI_F32) {
+        reinterpret_cast<float*>(a.out)[o] = y;
+      } else {
+        bf16_t* ob = reinterpret_cast<bf16_t*>(a.out);
+        if (EPI == SD_EPI_STORE) ob[o] = (bf16_t)y;
+        else if (EPI == SD_EPI_RESIDUAL) ob[o] = (bf16_t)(round_bf16(y) + (float)a.residual[o]);
+        else if (EPI == SD_EPI_RELU) ob[o] = (bf16_t)fmaxf(round_bf16(y), 0.f);
+        else ob[o] = (bf16_t)gelu_tanh_w(round_bf16(y));
+      }
+    }
+  }
+}
+
+// K split: a function of the matrix alone (never of M), so results do not depend on the
+// number of rows in the pass.
+void plan_split(int n_tiles, int K, int& S, int& ks_per_split) {
+  const int KS = K / 32;
+  const int groups = (n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
+  int want = (256 + groups - 1) / groups;           // enough workgroups for every CU
+  const int max_s = (KS + 7) / 8;                   // at least 8 k-steps (256 columns) per split
+  want = want < 1 ? 1 : (want > max_s ? max_s : want);
+  ks_per_split = ((KS + want - 1) / want + kChunkSteps - 1) / kChunkSteps * kChunkSteps;
+  S = (KS + ks_per_split - 1) / ks_per_split;
+}
+
+int tiles_of(int N, int epi) { return epi == SD_EPI_SILU_MUL ? (N + 7) / 8 : (N + 15) / 16; }
+
+size_t wide_ws_bytes(int M, int n_tiles, int K) {
+  int S, ksp;
+  plan_split(n_tiles, K, S, ksp);
+  return (size_t)S * M * n_tiles * 16 * sizeof(float);
+}
+
+template <int MT>
+int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
+  const size_t lds = (size_t)2 * MT * 16 * kXLD * sizeof(bf16_t);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+      sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return SD_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  const int groups = (a.n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
+  hipLaunchKernelGGL((wide_gemm_kernel<MT>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
+  SD_CHECK_LAUNCH("sd_linear_wide");
+  return SD_OK;
+}
+
+template <int EPI>
+int launch_epi(const WideEpiArgs& e, hipStream_t st) {
+  constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
+  const size_t units = (size_t)e.M * (PAIRED ? e.NR / 8 : e.NR / 4);
+  hipLaunchKernelGGL((wide_epilogue_kernel<EPI>), dim3((unsigned)((units + 255) / 256)), dim3(256),
+                     0, st, e);
+  SD_CHECK_LAUNCH("sd_linear_wide(epilogue)");
+  return SD_OK;
+}
+
+int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_tiles, int epi,
+                WideEpiArgs& e, void* workspace, size_t ws_bytes, hipStream_t st) {
+  SD_REQUIRE(W && x && e.out && workspace, SD_ERR_INVALID, "sd_linear_wide: null pointer");
+  SD_REQUIRE(M >= 0 && M <= 256, SD_ERR_UNSUPPORTED, "sd_linear_wide: M=%d outside 0..256", M);
+  SD_REQUIRE(K >= 32 && K % 32 == 0 && n_tiles >= 1, SD_ERR_INVALID,
+             "sd_linear_wide: K must be a positive multiple of 32 (K=%d)", K);
+  SD_REQUIRE(ldx % 8 == 0 && ldx >= K && sd_aligned16(W) && sd_aligned16(x) &&
+                 sd_aligned16(workspace), SD_ERR_INVALID,
+             "sd_linear_wide: rows must be 16-byte aligned (ldx=%lld)", (long long)ldx);
+  if (M == 0) return SD_OK;
+  int S, ksp;
+  plan_split(n_tiles, K, S, ksp);
+  const size_t need = (size_t)S * M * n_tiles * 16 * sizeof(float);
+  SD_REQUIRE(ws_bytes >= need, SD_ERR_WORKSPACE, "sd_linear_wide: workspace %zu < %zu bytes",
+             ws_bytes, need);
+  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp};
+  const int mt = (M + 15) / 16;
+  int rc;
+  if (mt <= 2) rc = launch_gemm<2>(a, S, st);
+  else if (mt <= 4) rc = launch_gemm<4>(a, S, st);
+  else if (mt <= 8) rc = launch_gemm<8>(a, S, st);
+  else if (mt <= 12) rc = launch_gemm<12>(a, S, st);
+  else rc = launch_gemm<16>(a, S, st);
+  if (rc != SD_OK) return rc;
+  e.part = (const float*)workspace;
+  e.S = S;
+  e.M = M;
+  e.NR = n_tiles * 16;
+  switch (epi) {
+    case SD_EPI_STORE: return launch_epi<SD_EPI_STORE>(e, st);
+    case SD_EPI_RESIDUAL: return launch_epi<SD_EPI_RESIDUAL>(e, st);
+    case SD_EPI_SILU_MUL: return launch_epi<SD_EPI_SILU_MUL>(e, st);
+    case SD_EPI_RELU: return launch_epi<SD_EPI_RELU>(e, st);
+    case SD_EPI_F32: return launch_epi<SD_EPI_F32>(e, st);
+    case SD_EPI_GELU_TANH: return launch_epi<SD_EPI_GELU_TANH>(e, st);
+    case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(e, st);
+  }
+  sd_set_error("sd_linear_wide: unknown epilogue %d", epi);
+  return SD_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" size_t sd_linear_wide_workspace_bytes(int M, int N, int K, int epilogue) {
+  if (M < 1 || N < 1 || K < 32 || K % 32) return 0;
+  return wide_ws_bytes(M, tiles_of(N, epilogue), K);
+}
+
+extern "C" int sd_linear_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+                              const void* residual, void* out, int64_t ldo, int M, int N, int K,
+                              int epilogue, void* workspace, size_t workspace_bytes,
+                              sd_stream_t stream) {
+  SD_REQUIRE(epilogue >= SD_EPI_STORE && epilogue <= SD_EPI_GELU_TANH, SD_ERR_INVALID,
+             "sd_linear_wide: unknown epilogue %d", epilogue);
+  SD_REQUIRE(N >= 1 && ldo >= N, SD_ERR_INVALID, "sd_linear_wide: need N >= 1 and ldo >= N");
+  SD_REQUIRE(epilogue != SD_EPI_RESIDUAL || residual, SD_ERR_INVALID,
+             "sd_linear_wide: residual epilogue without residual pointer");
+  WideEpiArgs e{};
+  e.N = N;
+  e.bias = (const bf16_t*)bias;
+  e.residual = (const bf16_t*)residual;
+  e.out = out;
+  e.ldo = ldo;
+  return wide_common(W, x, ldx, M, K, tiles_of(N, epilogue), epilogue, e, workspace,
+                     workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int sd_qkv_rope_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+                                void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
+                                void* k_cache, void* v_cache, const int32_t* block_tables,
+                                int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
+                                int B, int q_len, int Hq, int Hkv, int D, int K, void* workspace,
+                                size_t workspace_bytes, sd_stream_t stream) {
+  SD_REQUIRE(q_out && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
+             "sd_qkv_rope_wide: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && D % 16 == 0 && D >= 16,
+             SD_ERR_INVALID, "sd_qkv_rope_wide: bad shape (D=%d)", D);
+  SD_REQUIRE(!rope_cs || max_pos >= 1, SD_ERR_INVALID, "sd_qkv_rope_wide: max_pos < 1");
+  SD_REQUIRE(ldq >= (int64_t)Hq * D, SD_ERR_INVALID, "sd_qkv_rope_wide: ldq too small");
+  const int N = (Hq + 2 * Hkv) * D;
+  WideEpiArgs e{};
+  e.N = N;
+  e.bias = (const bf16_t*)bias;
+  e.out = q_out;
+  e.ldo = ldq;
+  e.rope = WideRope{rope_cs, max_pos, (bf16_t*)k_cache, (bf16_t*)v_cache, block_tables,
+                    max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D};
+  return wide_common(W, x, ldx, B * q_len, K, N / 16, EPI_QKV_ROPE, e, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+}

@@ -102,10 +102,12 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, total;
+  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, wide_ws, wide_ws_bytes, total;
 };
 
-Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int split_tokens) {
+// wide: the pass uses the 17..256-row linear kernels (and their partial-sum scratch).
+Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int split_tokens,
+                         bool wide) {
   Workspace w;
   const size_t qkv_cols = (size_t)(d.n_heads + 2 * d.n_kv_heads) * d.head_dim;
   size_t off = 0;
@@ -114,10 +116,24 @@ Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int spli
   w.qkv = off;  off += align256((size_t)rows * qkv_cols * 2);
   w.attn = off; off += align256((size_t)rows * d.n_heads * d.head_dim * 2);
   w.act = off;  off += align256((size_t)rows * d.ffn * 2);
-  // rows bounds B and q_len separately; B*q_len rows in total
-  w.attn_ws_bytes = sd_paged_attention_workspace_bytes(rows, rows, d.n_heads, d.head_dim,
-                                                       max_ctx, split_tokens);
+  // rows bounds the number of sequences; partials are 64 rows per (sequence, KV head, split)
+  const size_t n_splits = (size_t)(max_ctx + split_tokens - 1) / split_tokens;
+  w.attn_ws_bytes = n_splits <= 1 ? 256 : (size_t)rows * d.n_kv_heads * n_splits * 64 *
+                                              (d.head_dim + 2) * sizeof(float) + 256;
   w.attn_ws = off; off += align256(w.attn_ws_bytes);
+  w.wide_ws_bytes = 0;
+  if (wide) {
+    const int H = d.hidden, F = d.ffn, QD = d.n_heads * d.head_dim;
+    const int up_epi = d.arch == SD_ARCH_LLAMA ? SD_EPI_SILU_MUL : SD_EPI_RELU;
+    const size_t need[5] = {
+        sd_linear_wide_workspace_bytes(rows, (int)qkv_cols, H, SD_EPI_STORE),
+        sd_linear_wide_workspace_bytes(rows, H, QD, SD_EPI_RESIDUAL),
+        sd_linear_wide_workspace_bytes(rows, F, H, up_epi),
+        sd_linear_wide_workspace_bytes(rows, H, F, SD_EPI_RESIDUAL),
+        sd_linear_wide_workspace_bytes(rows, d.vocab, H, SD_EPI_F32)};
+    for (size_t n : need) w.wide_ws_bytes = n > w.wide_ws_bytes ? n : w.wide_ws_bytes;
+  }
+  w.wide_ws = off; off += align256(w.wide_ws_bytes);
   w.total = off;
   return w;
 }
@@ -127,7 +143,7 @@ Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int spli
 extern "C" size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,
                                            int split_tokens) {
   if (!m || max_rows < 1) return 0;
-  return plan_workspace(m->d, max_rows, max_ctx, split_tokens).total;
+  return plan_workspace(m->d, max_rows, max_ctx, split_tokens, max_rows > 16).total;
 }
 
 #define SD_TRY(expr)            \
@@ -141,13 +157,14 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   SD_REQUIRE(m && kv && a && workspace, SD_ERR_INVALID, "sd_model_forward: null argument");
   const sd_model_desc& d = m->d;
   const int rows = a->B * a->q_len;
-  SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= 16, SD_ERR_UNSUPPORTED,
-             "sd_model_forward: B*q_len = %d outside 1..16", rows);
+  const bool wide = a->wide != 0;
+  SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= (wide ? 256 : 16), SD_ERR_UNSUPPORTED,
+             "sd_model_forward: B*q_len = %d outside 1..%d", rows, wide ? 256 : 16);
   SD_REQUIRE(a->token_ids && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
              SD_ERR_INVALID, "sd_model_forward: null buffer");
   SD_REQUIRE(a->max_ctx >= 1 && a->max_ctx <= d.max_pos, SD_ERR_INVALID,
              "sd_model_forward: max_ctx %d outside 1..max_pos %d", a->max_ctx, d.max_pos);
-  const Workspace w = plan_workspace(d, rows, a->max_ctx, a->split_tokens);
+  const Workspace w = plan_workspace(d, rows, a->max_ctx, a->split_tokens, wide);
   SD_REQUIRE(workspace_bytes >= w.total, SD_ERR_WORKSPACE,
              "sd_model_forward: workspace %zu < %zu bytes", workspace_bytes, w.total);
   SD_REQUIRE(sd_aligned16(workspace), SD_ERR_INVALID, "sd_model_forward: workspace unaligned");
@@ -169,6 +186,34 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
     void* vc = (char*)kv->v_cache + (size_t)li * kv->layer_stride_bytes;
+    if (wide) {
+      // 17..256 token rows: stand-alone norms, activations shared through LDS by the wide
+      // linear kernels; same layer otherwise.
+      void* wws = base + w.wide_ws;
+      const bool lead = !d.allreduce || d.tp_rank == 0;
+      const int proj_epi = lead ? SD_EPI_RESIDUAL : SD_EPI_STORE;
+      if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
+      else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
+      SD_TRY(sd_qkv_rope_wide(l.qkv_w, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
+                              llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
+                              kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
+                              Hq, Hkv, D, H, wws, w.wide_ws_bytes, stream));
+      SD_TRY(sd_paged_attention(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                                kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
+                                (int64_t)Hq * D, a->B, a->q_len, Hq, Hkv, D, d.attn_scale,
+                                a->max_ctx, a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
+      SD_TRY(sd_linear_wide(l.o_w, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
+                            Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
+      if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
+      if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
+      else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
+      SD_TRY(sd_linear_wide(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H,
+                            llama ? SD_EPI_SILU_MUL : SD_EPI_RELU, wws, w.wide_ws_bytes, stream));
+      SD_TRY(sd_linear_wide(l.down_w, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F,
+                            proj_epi, wws, w.wide_ws_bytes, stream));
+      if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
+      continue;
+    }
     const bool fuse = sd_fused_norm_fits(rows, H, !llama);
     if (fuse) {
       SD_TRY(sd_norm_qkv_rope(l.qkv_w, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
@@ -219,7 +264,12 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                      stream));
     if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
   }
-  if (a->logits) {
+  if (a->logits && wide) {
+    if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
+    else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
+    SD_TRY(sd_linear_wide(d.lm_head, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
+                          SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
+  } else if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {
       SD_TRY(sd_norm_linear(d.lm_head, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
                             nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, stream));

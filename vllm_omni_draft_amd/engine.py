@@ -41,6 +41,11 @@ class EngineConfig:
     seed: int = 0
     use_graph: bool = True
     gen_capacity: int = 4096       # generated tokens kept on the device per sequence
+    # Kernel family of the linear layers: "narrow" (<= 16 token rows per pass, larger batches
+    # run as sub-batches), "wide" (<= 256 rows per pass) or "auto" (wide when a verify pass of
+    # the whole batch exceeds 16 rows).  The families round differently, so an autoregressive
+    # engine that is to reproduce a speculative engine's stream must be given the same one.
+    rows: str = "auto"
 
 
 class SpecEngine:
@@ -62,9 +67,14 @@ class SpecEngine:
         self.device = dev
         B, k = cfg.max_batch, cfg.k
         self.max_ctx = cfg.max_seq_len + k + 2
-        self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group)
-        self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens)
-                      if k > 0 else None)
+        if cfg.rows not in ("auto", "narrow", "wide"):
+            raise ValueError("rows must be 'auto', 'narrow' or 'wide'")
+        self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS)
+        self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
+                                   wide=self.wide)
+        self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
+                                   wide=self.wide) if k > 0 else None)
+        self.max_rows = self.target.max_rows
         self.V = target.cfg.vocab
         pages = PagedKVCache.pages_for(target.cfg, B, self.max_ctx)
         self.t_kv = PagedKVCache(target.cfg, pages, B, self.max_ctx, dev)
@@ -207,8 +217,8 @@ class SpecEngine:
     def _forward(self, model: DecoderModel, kv: PagedKVCache, tokens, tok_stride, tok_offset,
                  seq_lens, pos_offset, B, q_len, logits, slot0: int = 0) -> None:
         """One model pass over B sequences x q_len tokens, in sub-batches of at
-        most MAX_ROWS token rows."""
-        per = max(1, MAX_ROWS // q_len)
+        most max_rows token rows."""
+        per = max(1, self.max_rows // q_len)
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
             sub_logits = None

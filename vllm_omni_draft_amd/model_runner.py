@@ -15,7 +15,8 @@ from .config import ModelConfig
 from .kv_cache import PagedKVCache
 from .weights import ModelWeights
 
-MAX_ROWS = 16  # token rows one forward pass may carry (B * q_len)
+MAX_ROWS = 16        # token rows one forward pass may carry (B * q_len), narrow kernel family
+MAX_ROWS_WIDE = 256  # the same for the wide family (batched draft passes / verify)
 
 
 def _ptr(t):
@@ -26,11 +27,15 @@ def _ptr(t):
 
 class DecoderModel:
     def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
-                 tp_group=None):
+                 tp_group=None, wide: bool = False):
         """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
         self.tp_group = tp_group  # keeps the communicator / callback alive
+        # wide: every pass of this model goes through the 17..256-row linear kernels (one
+        # kernel family per model, because the two round differently)
+        self.wide = bool(wide)
+        self.max_rows = MAX_ROWS_WIDE if wide else MAX_ROWS
         self.cfg: ModelConfig = weights.cfg
         cfg = self.cfg
         if max_ctx > cfg.max_pos:
@@ -57,7 +62,7 @@ class DecoderModel:
         self._handle = lib.sd_model_create(C.byref(desc))
         if not self._handle:
             raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")
-        nbytes = lib.sd_model_workspace_bytes(self._handle, MAX_ROWS, max_ctx, split_tokens)
+        nbytes = lib.sd_model_workspace_bytes(self._handle, self.max_rows, max_ctx, split_tokens)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=weights.embed.device)
 
     def __del__(self):
@@ -89,7 +94,7 @@ class DecoderModel:
                                 tok_stride=tok_stride, tok_offset=tok_offset,
                                 seq_lens=seq_lens.data_ptr(), pos_offset=pos_offset,
                                 max_ctx=max_ctx or self.max_ctx, split_tokens=self.split_tokens,
-                                logits=_ptr(logits))
+                                logits=_ptr(logits), wide=int(self.wide))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           self.workspace.data_ptr(), self.workspace.numel(),
                                           torch.cuda.current_stream().cuda_stream)

@@ -222,6 +222,7 @@ class SpecDecodeConfig:
     seed: int = 0
     split_tokens: int = 256
     use_graph: bool = True
+    rows: str = "auto"             # kernel family, see EngineConfig.rows
     # Tensor-parallel verify: the target is sharded over this many ranks (one process per
     # GPU), the draft stays whole on each.  `target` is then either this rank's shard or a
     # (ModelConfig, state_dict) pair that load_model shards itself.
@@ -281,7 +282,8 @@ class SpecDecodeWorker:
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
             # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
-            use_graph=c.use_graph and tp == 1), tp_group=getattr(self, "tp_group", None))
+            use_graph=c.use_graph and tp == 1, rows=c.rows),
+            tp_group=getattr(self, "tp_group", None))
         self._wire()
 
     def _wire(self) -> None:
