@@ -1,0 +1,65 @@
+"""Batched speculative decoding (the wide kernel family): Qwen2.5-7B target + Qwen2.5-0.5B draft,
+k = 5, B sequences, synthetic weights and teacher-forced acceptance, next to the batched
+autoregressive baseline on the same kernels.
+    python experiments/bench_batch.py [B] [prompt_len]
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_omni_draft_amd import config, weights  # noqa: E402
+from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+k, steps, warm, alpha = 5, 24, 4, 0.8
+tcfg = config.preset("qwen2.5-7b")
+dcfg = config.preset("qwen2.5-0.5b", vocab=tcfg.vocab)  # draft vocabulary padded to the target's
+tw = weights.random_init(tcfg, seed=0)
+dw = weights.random_init(dcfg, seed=1)
+V = min(tcfg.vocab, dcfg.vocab)
+g = torch.Generator().manual_seed(7)
+prompts = [torch.randint(0, V, (P,), generator=g).tolist() for _ in range(B)]
+n_new = (steps + warm) * (k + 1) + 8
+max_seq = P + n_new + 16
+rows = "wide" if B * (k + 1) > 16 else "narrow"
+
+
+def run(eng, n_steps, n_warm):
+    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    for _ in range(n_warm):
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    torch.cuda.synchronize()
+    n0 = sum(len(o) for o in outs)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return outs, sum(len(o) for o in outs) - n0, dt
+
+
+ar = SpecEngine(tw, None, EngineConfig(k=0, max_batch=B, max_seq_len=max_seq, rows=rows,
+                                       gen_capacity=n_new + 64))
+ar_out, ar_n, ar_dt = run(ar, n_new - 8 - warm, warm)
+print(f"AR   B={B}: {ar_dt / (n_new - 8 - warm) * 1e3:.3f} ms/step, {ar_n / ar_dt:.1f} tok/s", flush=True)
+truth = torch.zeros(B, max_seq, dtype=torch.int32)
+for b in range(B):
+    truth[b, :P] = torch.tensor(prompts[b])
+    truth[b, P:P + len(ar_out[b])] = torch.tensor(ar_out[b])
+del ar
+torch.cuda.empty_cache()
+eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=B, max_seq_len=max_seq, rows=rows,
+                                      gen_capacity=n_new + 64))
+eng.set_synthetic_acceptance(truth.cuda(), alpha, seed=3)
+out, n, dt = run(eng, steps, warm)
+exact = all(o[:min(len(o), len(a))] == a[:min(len(o), len(a))] for o, a in zip(out, ar_out))
+m = eng.metrics()
+print(f"spec B={B}: {dt / steps * 1e3:.3f} ms/step, {n / dt:.1f} tok/s, "
+      f"{n / steps / B:.2f} tokens/step/seq, speedup {n / dt / (ar_n / ar_dt):.3f}, "
+      f"spec == AR: {exact}, family {rows}", flush=True)

@@ -25,15 +25,45 @@ constexpr int kChunkCols = kChunkSteps * 32;
 constexpr int kXLD = kChunkCols + 8;                        // padded LDS row (elements)
 constexpr int EPI_QKV_ROPE = 100;
 
+__device__ __forceinline__ float silu_w(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_tanh_w(float v) {
+  const float c = 0.7978845608028654f;
+  return 0.5f * v * (1.0f + tanhf(c * (v + 0.044715f * v * v * v)));
+}
+
+struct WideRope {
+  const float* cs;
+  int max_pos;
+  bf16_t* kc;
+  bf16_t* vc;
+  const int32_t* block_tables;
+  int max_blocks;
+  const int32_t* seq_lens;
+  int pos_offset, q_len, Hq, Hkv, D;
+};
+
+struct WideEpiArgs {
+  const float* part;  // [S][M][NR]
+  int S, M, NR, N;
+  const bf16_t* bias;
+  const bf16_t* residual;
+  void* out;
+  int64_t ldo;
+  WideRope rope;
+};
+
 struct WideArgs {
   const bf16_t* W;  // tiled [n_tiles][K/32][64][8]
   const bf16_t* x;
   int64_t ldx;
   float* part;      // [S][M][NR]
   int M, K, n_tiles, ks_per_split;
+  WideEpiArgs epi;  // direct epilogue (one split): EPI >= 0
 };
 
-template <int MT>  // token tiles of 16 rows
+constexpr int EPI_PARTIAL = -1;  // several K splits: partial sums to the workspace
+
+template <int MT, int EPI>  // MT token tiles of 16 rows
 __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [2][MT*16][kXLD]
@@ -121,74 +151,50 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
     __syncthreads();
   }
 
-  // acc[t][mt][reg] = partial of (tile row 4*(lane>>4)+reg of tile tile0+t, token 16*mt + lane&15)
-  float* part = a.part + (size_t)blockIdx.y * a.M * NR;
+  // acc[t][mt][reg] = sum of (tile row 4*(lane>>4)+reg of tile tile0+t, token 16*mt + lane&15)
+  if (EPI == EPI_PARTIAL) {
+    float* part = a.part + (size_t)blockIdx.y * a.M * NR;
 #pragma unroll
-  for (int t = 0; t < kTilesPerWave; ++t) {
-    if (tile0 + t >= a.n_tiles) continue;
+    for (int t = 0; t < kTilesPerWave; ++t) {
+      if (tile0 + t >= a.n_tiles) continue;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = mt * 16 + xc;
-      if (m < a.M)
-        *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)(tile0 + t) * 16 + 4 * xq) = acc[t][mt];
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + xc;
+        if (m < a.M)
+          *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)(tile0 + t) * 16 + 4 * xq) = acc[t][mt];
+      }
+    }
+  } else {
+    constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+      const bool tile_ok = tile0 + t < a.n_tiles;  // wave-uniform
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + xc;
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+        if (PAIRED) {  // rows r+8 sit 32 lanes up
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hi[j] = __shfl(acc[t][mt][j], (lane + 32) & 63, 64);
+        }
+        if (tile_ok && m < a.M && (!PAIRED || xq < 2))
+          emit_unit<EPI == EPI_PARTIAL ? 0 : EPI>(a.epi, m, tile0 + t, 4 * xq, acc[t][mt], hi);
+      }
     }
   }
 }
 
-__device__ __forceinline__ float silu_w(float v) { return v / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float gelu_tanh_w(float v) {
-  const float c = 0.7978845608028654f;
-  return 0.5f * v * (1.0f + tanhf(c * (v + 0.044715f * v * v * v)));
-}
-
-struct WideRope {
-  const float* cs;
-  int max_pos;
-  bf16_t* kc;
-  bf16_t* vc;
-  const int32_t* block_tables;
-  int max_blocks;
-  const int32_t* seq_lens;
-  int pos_offset, q_len, Hq, Hkv, D;
-};
-
-struct WideEpiArgs {
-  const float* part;  // [S][M][NR]
-  int S, M, NR, N;
-  const bf16_t* bias;
-  const bf16_t* residual;
-  void* out;
-  int64_t ldo;
-  WideRope rope;
-};
-
-// One thread = 4 consecutive tile rows of one token row (paired modes: rows r..r+3 and their
-// partners r+8..r+11 of a tile).  Splits are added in index order.
+// The epilogue of 4 consecutive tile rows r0..r0+3 of tile `tile` for token row m: lo holds
+// their sums; in the paired modes hi holds the sums of rows r0+8..r0+11 (the up rows of a
+// gated tile, the rotation partners of a rotary tile) and r0 is 0 or 4.
 template <int EPI>
-__global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
-  constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
-  const int units_per_row = PAIRED ? a.NR / 8 : a.NR / 4;  // paired: 2 units per tile
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (size_t)a.M * units_per_row) return;
-  const int m = (int)(gid / units_per_row), u = (int)(gid % units_per_row);
-  const int tr = PAIRED ? (u >> 1) * 16 + (u & 1) * 4 : u * 4;  // first tile row of the unit
-  f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < a.S; ++s) {
-    const float* p = a.part + ((size_t)s * a.M + m) * a.NR + tr;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) lo[j] += v[j];
-    if (PAIRED) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(p + 8);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) hi[j] += w[j];
-    }
-  }
+__device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile, int r0, f32x4 lo,
+                                          f32x4 hi) {
   if (EPI == EPI_QKV_ROPE) {
     const WideRope& rp = a.rope;
     const int D = rp.D, half = D / 2, tiles_per_head = D / 16;
-    const int tile = u >> 1, head = tile / tiles_per_head;
-    const int i0 = (tile % tiles_per_head) * 8 + (u & 1) * 4;
+    const int head = tile / tiles_per_head;
+    const int i0 = (tile % tiles_per_head) * 8 + r0;
     const int b = m / rp.q_len, t = m - b * rp.q_len;
     const int pos = rp.seq_lens[b] + rp.pos_offset + t;
     if (pos < 0) return;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
       }
     }
   } else if (EPI == SD_EPI_SILU_MUL) {
-    const int n0 = (u >> 1) * 8 + (u & 1) * 4;
+    const int n0 = tile * 8 + r0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + j;
@@ -242,9 +248,35 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
       reinterpret_cast<bf16_t*>(a.out)[(size_t)m * a.ldo + n] = (bf16_t)(g * round_bf16(up));
     }
   } else {
+    const int n0 = tile * 16 + r0;
+    if (n0 + 3 < a.N && (a.ldo & 3) == 0) {  // four outputs in one store
+      f32x4 y = lo;
+      if (a.bias) {
+        const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] += (float)bv[j];
+      }
+      const size_t o = (size_t)m * a.ldo + n0;
+      if (EPI == SD_EPI_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + o) = y;
+        return;
+      }
+      bf16x4 r;
+      bf16x4 res = {0, 0, 0, 0};
+      if (EPI == SD_EPI_RESIDUAL) res = *reinterpret_cast<const bf16x4*>(a.residual + o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (EPI == SD_EPI_STORE) r[j] = (bf16_t)y[j];
+        else if (EPI == SD_EPI_RESIDUAL) r[j] = (bf16_t)(round_bf16(y[j]) + (float)res[j]);
+        else if (EPI == SD_EPI_RELU) r[j] = (bf16_t)fmaxf(round_bf16(y[j]), 0.f);
+        else r[j] = (bf16_t)gelu_tanh_w(round_bf16(y[j]));
+      }
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + o) = r;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = tr + j;
+      const int n = n0 + j;
       if (n >= a.N) break;
       float y = lo[j];
       if (a.bias) y += (float)a.bias[n];
@@ -262,12 +294,38 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
   }
 }
 
+// One thread = one unit (see emit_unit) of one token row.  Splits are added in index order.
+template <int EPI>
+__global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
+  constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
+  const int units_per_row = PAIRED ? a.NR / 8 : a.NR / 4;  // paired: 2 units per tile
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)a.M * units_per_row) return;
+  const int m = (int)(gid / units_per_row), u = (int)(gid % units_per_row);
+  const int tile = PAIRED ? u >> 1 : u >> 2, r0 = PAIRED ? (u & 1) * 4 : (u & 3) * 4;
+  f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < a.S; ++s) {
+    const float* p = a.part + ((size_t)s * a.M + m) * a.NR + tile * 16 + r0;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] += v[j];
+    if (PAIRED) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(p + 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hi[j] += w[j];
+    }
+  }
+  emit_unit<EPI>(a, m, tile, r0, lo, hi);
+}
+
 // K split: a function of the matrix alone (never of M), so results do not depend on the
 // number of rows in the pass.
 void plan_split(int n_tiles, int K, int& S, int& ks_per_split) {
   const int KS = K / 32;
   const int groups = (n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
-  int want = (256 + groups - 1) / groups;           // enough workgroups for every CU
+  // one split (epilogue inside the kernel, no partial sums) once half the CUs have a
+  // workgroup; otherwise enough splits for every CU
+  int want = groups >= 128 ? 1 : (256 + groups - 1) / groups;
   const int max_s = (KS + 7) / 8;                   // at least 8 k-steps (256 columns) per split
   want = want < 1 ? 1 : (want > max_s ? max_s : want);
   ks_per_split = ((KS + want - 1) / want + kChunkSteps - 1) / kChunkSteps * kChunkSteps;
@@ -282,12 +340,12 @@ size_t wide_ws_bytes(int M, int n_tiles, int K) {
   return (size_t)S * M * n_tiles * 16 * sizeof(float);
 }
 
-template <int MT>
+template <int MT, int EPI>
 int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
   const size_t lds = (size_t)2 * MT * 16 * kXLD * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -296,7 +354,7 @@ int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
     attr_set = true;
   }
   const int groups = (a.n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
-  hipLaunchKernelGGL((wide_gemm_kernel<MT>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
+  hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
   SD_CHECK_LAUNCH("sd_linear_wide");
   return SD_OK;
 }
@@ -309,6 +367,45 @@ int launch_epi(const WideEpiArgs& e, hipStream_t st) {
                      0, st, e);
   SD_CHECK_LAUNCH("sd_linear_wide(epilogue)");
   return SD_OK;
+}
+
+int epilogue_by_kind(const WideEpiArgs& e, int epi, hipStream_t st) {
+  switch (epi) {
+    case SD_EPI_STORE: return launch_epi<SD_EPI_STORE>(e, st);
+    case SD_EPI_RESIDUAL: return launch_epi<SD_EPI_RESIDUAL>(e, st);
+    case SD_EPI_SILU_MUL: return launch_epi<SD_EPI_SILU_MUL>(e, st);
+    case SD_EPI_RELU: return launch_epi<SD_EPI_RELU>(e, st);
+    case SD_EPI_F32: return launch_epi<SD_EPI_F32>(e, st);
+    case SD_EPI_GELU_TANH: return launch_epi<SD_EPI_GELU_TANH>(e, st);
+    case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(e, st);
+  }
+  sd_set_error("sd_linear_wide: unknown epilogue %d", epi);
+  return SD_ERR_INVALID;
+}
+
+template <int MT, bool DIRECT>
+int gemm_by_kind(const WideArgs& a, int epi, int S, hipStream_t st) {
+  if (!DIRECT) return launch_gemm<MT, EPI_PARTIAL>(a, S, st);
+  switch (epi) {
+    case SD_EPI_STORE: return launch_gemm<MT, SD_EPI_STORE>(a, S, st);
+    case SD_EPI_RESIDUAL: return launch_gemm<MT, SD_EPI_RESIDUAL>(a, S, st);
+    case SD_EPI_SILU_MUL: return launch_gemm<MT, SD_EPI_SILU_MUL>(a, S, st);
+    case SD_EPI_RELU: return launch_gemm<MT, SD_EPI_RELU>(a, S, st);
+    case SD_EPI_F32: return launch_gemm<MT, SD_EPI_F32>(a, S, st);
+    case SD_EPI_GELU_TANH: return launch_gemm<MT, SD_EPI_GELU_TANH>(a, S, st);
+    case EPI_QKV_ROPE: return launch_gemm<MT, EPI_QKV_ROPE>(a, S, st);
+  }
+  sd_set_error("sd_linear_wide: unknown epilogue %d", epi);
+  return SD_ERR_INVALID;
+}
+
+template <bool DIRECT>
+int gemm_by_rows(const WideArgs& a, int mt, int epi, int S, hipStream_t st) {
+  if (mt <= 2) return gemm_by_kind<2, DIRECT>(a, epi, S, st);
+  if (mt <= 4) return gemm_by_kind<4, DIRECT>(a, epi, S, st);
+  if (mt <= 8) return gemm_by_kind<8, DIRECT>(a, epi, S, st);
+  if (mt <= 12) return gemm_by_kind<12, DIRECT>(a, epi, S, st);
+  return gemm_by_kind<16, DIRECT>(a, epi, S, st);
 }
 
 int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_tiles, int epi,
@@ -326,30 +423,17 @@ int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_t
   const size_t need = (size_t)S * M * n_tiles * 16 * sizeof(float);
   SD_REQUIRE(ws_bytes >= need, SD_ERR_WORKSPACE, "sd_linear_wide: workspace %zu < %zu bytes",
              ws_bytes, need);
-  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp};
-  const int mt = (M + 15) / 16;
-  int rc;
-  if (mt <= 2) rc = launch_gemm<2>(a, S, st);
-  else if (mt <= 4) rc = launch_gemm<4>(a, S, st);
-  else if (mt <= 8) rc = launch_gemm<8>(a, S, st);
-  else if (mt <= 12) rc = launch_gemm<12>(a, S, st);
-  else rc = launch_gemm<16>(a, S, st);
-  if (rc != SD_OK) return rc;
+  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp, e};
   e.part = (const float*)workspace;
   e.S = S;
   e.M = M;
   e.NR = n_tiles * 16;
-  switch (epi) {
-    case SD_EPI_STORE: return launch_epi<SD_EPI_STORE>(e, st);
-    case SD_EPI_RESIDUAL: return launch_epi<SD_EPI_RESIDUAL>(e, st);
-    case SD_EPI_SILU_MUL: return launch_epi<SD_EPI_SILU_MUL>(e, st);
-    case SD_EPI_RELU: return launch_epi<SD_EPI_RELU>(e, st);
-    case SD_EPI_F32: return launch_epi<SD_EPI_F32>(e, st);
-    case SD_EPI_GELU_TANH: return launch_epi<SD_EPI_GELU_TANH>(e, st);
-    case EPI_QKV_ROPE: return launch_epi<EPI_QKV_ROPE>(e, st);
-  }
-  sd_set_error("sd_linear_wide: unknown epilogue %d", epi);
-  return SD_ERR_INVALID;
+  a.epi = e;
+  const int mt = (M + 15) / 16;
+  if (S == 1) return gemm_by_rows<true>(a, mt, epi, S, st);
+  const int rc = gemm_by_rows<false>(a, mt, epi, S, st);
+  if (rc != SD_OK) return rc;
+  return epilogue_by_kind(e, epi, st);
 }
 
 }  // namespace

@@ -88,7 +88,7 @@ class SpecEngine:
         self.counters = torch.zeros(3, dtype=torch.int64, device=dev)
         self.zero_lens = torch.zeros(B, **i32)
         self.prompt_buf = torch.zeros(max(cfg.max_seq_len, 8), **i32)
-        self.t_logits = torch.empty(MAX_ROWS if k == 0 else max(MAX_ROWS, B * (k + 1)), self.V,
+        self.t_logits = torch.empty(max(MAX_ROWS, B * (k + 1)), self.V,
                                     dtype=torch.float32, device=dev)
         self.d_logits = torch.empty(max(MAX_ROWS, 2 * B), self.V, dtype=torch.float32, device=dev)
         self.ids_tmp = torch.zeros(max(B, 1), dtype=torch.int64, device=dev)
