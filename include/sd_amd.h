@@ -424,6 +424,12 @@ int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, int step,
                       int64_t truth_stride, float accept_prob, uint32_t seed,
                       int B, sd_stream_t stream);
 
+/* Writes externally made proposals [B, k] i32 (an n-gram / prompt-lookup
+ * proposer, which needs no draft model) into tok_buf[:, 2:2+k]; entries past a
+ * sequence's proposal length are ignored by the verification (proposal_lens). */
+int sd_set_proposals(const int32_t* proposals, int32_t* tok_buf, int B, int k,
+                     sd_stream_t stream);
+
 /* Gathers tok_buf[:, 2:2+k] as i64 draft_ids [B, k].                        */
 int sd_gather_proposals(const int32_t* tok_buf, int64_t* draft_ids, int B,
                         int k, sd_stream_t stream);

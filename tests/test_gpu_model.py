@@ -256,3 +256,24 @@ def test_sampling_mode_runs_and_preserves_first_token_distribution():
             counts[toks[1]] += 1            # second token: first one produced by a step
         hist[name] = counts / counts.sum()
     assert np.abs(hist["ar"] - hist["spec"]).sum() < 0.7
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_prompt_lookup_proposer_equals_ar_and_accepts_repeats(use_graph):
+    """No draft model: n-gram proposals from the sequence's own history.  Greedy stream ==
+    autoregressive stream; on a sequence that repeats, proposals are accepted."""
+    tcfg = MODELS["llama"]
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    prompts = [[5, 9, 200, 31, 7, 5, 9, 200], list(range(40, 60)) * 2]
+    ar = [_generate(_engine(tw, None, 0, use_graph=use_graph), [p], 60)[0] for p in prompts]
+    eng = _engine(tw, None, 4, max_batch=2, ngram_max=3, ngram_min=1, use_graph=use_graph)
+    assert eng.ngram and eng.draft is None
+    got = _generate(eng, prompts, 60)
+    assert got == ar
+    m = eng.metrics()
+    # a tiny random model falls into a loop quickly: the lookup then predicts it
+    assert m["draft"] > 0 and m["accepted"] > 0
+    # sampling mode runs with the one-hot draft distribution of the lookup
+    eng = _engine(tw, None, 4, max_batch=2, ngram_max=3, temperature=1.0, seed=1, use_graph=use_graph)
+    out = _generate(eng, prompts, 30)
+    assert all(0 <= t < tcfg.vocab for o in out for t in o)

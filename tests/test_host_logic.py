@@ -204,3 +204,20 @@ def test_tensor_parallel_shards_reproduce_the_layer_math(arch):
     assert all(torch.equal(st[emb], state[emb]) for _, st in shards)
     with pytest.raises(ValueError):
         cfg.tp_shard(3)
+
+
+def test_prompt_lookup_matches_longest_most_recent_ngram():
+    """The host side of the n-gram proposer (no GPU needed: only the lookup is exercised)."""
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    eng = SpecEngine.__new__(SpecEngine)
+    eng.k, eng.cfg = 3, EngineConfig(k=3, ngram_max=3, ngram_min=1)
+    look = eng._lookup
+    #        0  1  2  3  4  5  6  7  8  9
+    hist = [5, 6, 7, 8, 1, 2, 6, 7, 9, 4, 6, 7]
+    assert look(hist) == [9, 4, 6]                  # "6 7": the later of two earlier matches
+    assert look([1, 2, 3, 9, 1, 2, 3]) == [9, 1, 2]  # 3-gram wins over shorter ones
+    assert look([1, 2, 3, 4]) == []                 # nothing repeats
+    assert look([7]) == []
+    assert look([4, 4]) == [4]                      # continuation shorter than k
+    eng.cfg = EngineConfig(k=3, ngram_max=3, ngram_min=2)
+    assert look([1, 9, 2, 9]) == []                 # only a 1-gram matches: below ngram_min

@@ -84,6 +84,7 @@ SIGNATURES = {
                                C.c_size_t, vp]),
     "sd_store_proposal": (i32, [vp, vp, i32, i32, vp, vp, i64, C.c_float, C.c_uint32, i32, vp]),
     "sd_gather_proposals": (i32, [vp, vp, i32, i32, vp]),
+    "sd_set_proposals": (i32, [vp, vp, i32, i32, vp]),
     "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
     "sd_linear_wide_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32]),
     "sd_linear_wide": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),

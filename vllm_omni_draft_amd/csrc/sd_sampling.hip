@@ -667,6 +667,14 @@ __device__ __forceinline__ void apply_emitted(const int64_t* o, int b,
   tb[1] = last;
 }
 
+__global__ void set_proposals_kernel(const int32_t* __restrict__ props,
+                                     int32_t* __restrict__ tok_buf, int B, int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * k) return;
+  const int b = i / k, j = i % k;
+  tok_buf[(size_t)b * (k + 2) + 2 + j] = props[i];
+}
+
 __global__ void gather_proposals_kernel(const int32_t* __restrict__ tok_buf,
                                         int64_t* __restrict__ draft_ids, int B, int k) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -969,6 +977,17 @@ extern "C" int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, in
                      (hipStream_t)stream, ids, tok_buf, k, step, seq_lens, truth,
                      truth_stride, accept_prob, seed, B);
   SD_CHECK_LAUNCH("sd_store_proposal");
+  return SD_OK;
+}
+
+extern "C" int sd_set_proposals(const int32_t* proposals, int32_t* tok_buf, int B, int k,
+                                sd_stream_t stream) {
+  SD_REQUIRE(proposals && tok_buf && B >= 0 && k >= 1, SD_ERR_INVALID,
+             "sd_set_proposals: bad arguments");
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(set_proposals_kernel, dim3((B * k + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, proposals, tok_buf, B, k);
+  SD_CHECK_LAUNCH("sd_set_proposals");
   return SD_OK;
 }
 

@@ -46,6 +46,11 @@ class EngineConfig:
     # the whole batch exceeds 16 rows).  The families round differently, so an autoregressive
     # engine that is to reproduce a speculative engine's stream must be given the same one.
     rows: str = "auto"
+    # Prompt-lookup proposals instead of a draft model (k > 0, draft = None): the last
+    # ngram_max..ngram_min tokens of a sequence are searched in its own history and the k
+    # tokens after the most recent match are proposed (none if nothing matches).
+    ngram_max: int = 0
+    ngram_min: int = 1
 
 
 class SpecEngine:
@@ -56,8 +61,11 @@ class SpecEngine:
         draft is whole.  Every rank runs the same steps on the same inputs."""
         if cfg.k < 0 or cfg.k > 7:
             raise ValueError("k must be in 0..7")
-        if cfg.k > 0 and draft is None:
-            raise ValueError("k > 0 needs a draft model")
+        self.ngram = cfg.k > 0 and draft is None and cfg.ngram_max > 0
+        if cfg.k > 0 and draft is None and not self.ngram:
+            raise ValueError("k > 0 needs a draft model (or ngram_max > 0 for prompt lookup)")
+        if self.ngram and not 1 <= cfg.ngram_min <= cfg.ngram_max:
+            raise ValueError("need 1 <= ngram_min <= ngram_max")
         if draft is not None and draft.cfg.vocab != target.cfg.vocab:
             raise ValueError("draft and target must share a vocabulary "
                              f"({draft.cfg.vocab} vs {target.cfg.vocab})")
@@ -73,12 +81,19 @@ class SpecEngine:
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
                                    wide=self.wide)
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
-                                   wide=self.wide) if k > 0 else None)
+                                   wide=self.wide) if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self.V = target.cfg.vocab
         pages = PagedKVCache.pages_for(target.cfg, B, self.max_ctx)
         self.t_kv = PagedKVCache(target.cfg, pages, B, self.max_ctx, dev)
-        self.d_kv = PagedKVCache(draft.cfg, pages, B, self.max_ctx, dev) if k > 0 else None
+        self.d_kv = (PagedKVCache(draft.cfg, pages, B, self.max_ctx, dev)
+                     if self.draft is not None else None)
+        if self.ngram:
+            self.history: List[List[int]] = [[] for _ in range(B)]   # prompt + emitted tokens
+            self.ext_props = torch.zeros(B, k, **dict(dtype=torch.int32, device=dev))
+            self.prop_lens = torch.zeros(B, **dict(dtype=torch.int32, device=dev))
+            self._props_host = torch.zeros(B, k, dtype=torch.int32).pin_memory()
+            self._lens_host = torch.zeros(B, dtype=torch.int32).pin_memory()
 
         i32 = dict(dtype=torch.int32, device=dev)
         self.seq_lens = torch.zeros(B, **i32)
@@ -146,6 +161,8 @@ class SpecEngine:
                 self.d_kv.release(b)
             self.host_lens[b] = 0
             self.host_gen[b] = 0
+            if self.ngram:
+                self.history[b] = []
         self.seq_lens.zero_()
         self.gen_counts.zero_()
         self.counters.zero_()
@@ -209,6 +226,8 @@ class SpecEngine:
         self.gen_tokens[slot, 0] = first_tok
         self.gen_counts[slot] = 1
         self.host_lens[slot] = n + 1
+        if self.ngram:
+            self.history[slot] = list(prompt) + [first_tok]
         self.host_gen[slot] = 1
         self.active += 1
         return first_tok
@@ -235,7 +254,10 @@ class SpecEngine:
         if self.k == 0:
             self._enqueue_ar_step()
             return
-        self._enqueue_propose(fused)
+        if self.ngram:
+            self._enqueue_lookup_proposals()
+        else:
+            self._enqueue_propose(fused)
         self._enqueue_score(fused)
         self._enqueue_accept(fused)
 
@@ -291,6 +313,32 @@ class SpecEngine:
         if not fused:
             ops.gather_proposals(self.tok_buf, self.draft_ids, k)
 
+    def _enqueue_lookup_proposals(self) -> None:
+        """Prompt-lookup proposals (uploaded by _prepare_step) into the token window; in
+        sampling mode their one-hot 'draft distribution' into d_probs."""
+        B, k = self.active, self.k
+        ops.set_proposals(self.ext_props, self.tok_buf, k)
+        ops.gather_proposals(self.tok_buf, self.draft_ids, k)
+        if self.sampling:
+            self.d_probs.zero_()
+            self.d_probs.scatter_(2, self.draft_ids.unsqueeze(-1), 1.0)
+
+    def _lookup(self, hist: List[int]) -> List[int]:
+        """The k tokens that followed the most recent earlier occurrence of the sequence's
+        last n tokens, longest n first (ngram_max .. ngram_min); [] if nothing matches."""
+        import numpy as np
+        k, arr = self.k, np.asarray(hist, dtype=np.int64)
+        n_hist = arr.size
+        if n_hist < 2:
+            return []
+        ends = np.nonzero(arr[:-1] == arr[-1])[0][::-1]   # candidate match ends, latest first
+        for n in range(min(self.cfg.ngram_max, n_hist - 1), self.cfg.ngram_min - 1, -1):
+            pat = arr[n_hist - n:]
+            for e in ends:
+                if e + 1 >= n and np.array_equal(arr[e + 1 - n:e + 1], pat):
+                    return arr[e + 1:e + 1 + k].tolist()
+        return []
+
     def _enqueue_score(self, fused: bool = False) -> None:
         """One target pass over {last token, k proposals} of every sequence:
         t_logits [B*(k+1), V], plus target_ids (greedy) or t_probs / bonus_ids."""
@@ -312,17 +360,18 @@ class SpecEngine:
     def _enqueue_accept(self, fused: bool = False) -> None:
         """Acceptance (rejection sampling or greedy match) and the state update."""
         B, k = self.active, self.k
+        lens = self.prop_lens[:B] if self.ngram else None
         if fused:
             ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf, self.out_ids,
                                      self.counters, self.seq_lens, self.gen_tokens,
-                                     self.gen_counts, k, self.step_out)
+                                     self.gen_counts, k, self.step_out, proposal_lens=lens)
             return
         if self.sampling:
             ops.rejection_sample(self.t_probs[:B], self.bonus_ids[:B], self.d_probs[:B],
-                                 self.draft_ids[:B], self.u_accept[:B], self.u_recover[:B], None,
+                                 self.draft_ids[:B], self.u_accept[:B], self.u_recover[:B], lens,
                                  self.counters, scratch=self.samp_scratch, out=self.out_ids[:B])
         else:
-            ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], None, self.counters,
+            ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], lens, self.counters,
                               out=self.out_ids)
         ops.advance_state(self.out_ids, self.seq_lens, self.tok_buf, self.gen_tokens,
                           self.gen_counts, k, self.step_out)
@@ -344,6 +393,8 @@ class SpecEngine:
                 for t in (self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts):
                     t[slot].copy_(t[last])
                 self.host_lens[slot], self.host_gen[slot] = self.host_lens[last], self.host_gen[last]
+                if self.ngram:
+                    self.history[slot] = self.history[last]
             self.host_lens[last] = self.host_gen[last] = 0
             self.active = last
             torch.cuda.synchronize(self.device)
@@ -382,6 +433,14 @@ class SpecEngine:
         # contexts on the single-split path (no partials, no merge kernel).  The split
         # boundaries stay at fixed absolute positions, so results do not depend on the bound.
         self._ctx = self._ctx_bucket()
+        if self.ngram:
+            for b in range(B):
+                cont = self._lookup(self.history[b])
+                self._lens_host[b] = len(cont)
+                for j in range(k):
+                    self._props_host[b, j] = cont[j] if j < len(cont) else 0
+            self.ext_props.copy_(self._props_host, non_blocking=True)
+            self.prop_lens.copy_(self._lens_host, non_blocking=True)
         if self.sampling:
             self._refresh_uniforms()
 
@@ -459,6 +518,8 @@ class SpecEngine:
                 out.append(rec[b][2:2 + n])
                 self.host_gen[b] += n
                 self.host_lens[b] = rec[b][1]
+                if self.ngram:
+                    self.history[b].extend(out[-1])
             return out
         counts = self.gen_counts[:B].tolist()
         lens = self.seq_lens[:B].tolist()
@@ -469,6 +530,8 @@ class SpecEngine:
             out.append(toks)
             self.host_gen[b] = hi
             self.host_lens[b] = lens[b]
+            if self.ngram:
+                self.history[b].extend(toks)
         return out
 
     def metrics(self) -> dict:

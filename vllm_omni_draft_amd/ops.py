@@ -352,6 +352,13 @@ def store_proposal(ids, tok_buf, k, step, seq_lens, truth=None, accept_prob=0.0,
         _stream()), "sd_store_proposal")
 
 
+def set_proposals(proposals, tok_buf, k) -> None:
+    """proposals [B, k] int32 -> tok_buf[:, 2:2+k]."""
+    _need(proposals, torch.int32, "proposals")
+    _lib.check(_lib.load().sd_set_proposals(_p(proposals), _p(tok_buf), tok_buf.shape[0], k,
+                                            _stream()), "sd_set_proposals")
+
+
 def gather_proposals(tok_buf, draft_ids, k) -> None:
     _lib.check(_lib.load().sd_gather_proposals(_p(tok_buf), _p(draft_ids), tok_buf.shape[0], k,
                                                _stream()), "sd_gather_proposals")

@@ -134,6 +134,27 @@ class Top1Proposer(SpeculativeProposer):
             proposal_lens=lens, no_proposals=(B == 0))
 
 
+class NGramProposer(SpeculativeProposer):
+    """Prompt-lookup proposals: no draft model; the continuation of the most recent earlier
+    occurrence of a sequence's last n tokens (upstream's NGramWorker role).  The engine
+    computes them on the host in prepare_step; sequences without a match propose nothing
+    (proposal_lens 0) and get one token from the target as in plain decoding."""
+
+    def __init__(self, engine: SpecEngine):
+        self.engine = engine
+
+    def get_spec_proposals(self, execute_model_req=None,
+                           seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
+        eng = self.engine
+        B = eng.active
+        with torch.cuda.stream(eng.stream):
+            eng._enqueue_lookup_proposals()
+        return SpeculativeProposals(
+            proposal_token_ids=eng.draft_ids[:B],
+            proposal_probs=eng.d_probs[:B] if eng.sampling else None,
+            proposal_lens=eng.prop_lens[:B], no_proposals=(B == 0))
+
+
 class MQAScorer(SpeculativeScorer):
     """Scores all k+1 positions of every sequence in ONE target pass: the k+1
     query tokens of a sequence share each KV page read (no batch expansion)."""
@@ -214,8 +235,11 @@ class RejectionSampler(nn.Module):
 @dataclass
 class SpecDecodeConfig:
     target: ModelWeights
-    draft: ModelWeights
+    draft: Optional[ModelWeights] = None
     num_speculative_tokens: int = 5
+    # without a draft model: prompt-lookup proposals from n-grams of these sizes
+    ngram_prompt_lookup_max: int = 0
+    ngram_prompt_lookup_min: int = 1
     max_num_seqs: int = 1
     max_model_len: int = 2048
     temperature: float = 0.0
@@ -282,13 +306,18 @@ class SpecDecodeWorker:
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
             # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
-            use_graph=c.use_graph and tp == 1, rows=c.rows),
+            use_graph=c.use_graph and tp == 1, rows=c.rows,
+            ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min),
             tp_group=getattr(self, "tp_group", None))
         self._wire()
 
     def _wire(self) -> None:
-        self.proposer_worker = MultiStepWorker(self.engine)
-        self.proposer = Top1Proposer(self.proposer_worker)
+        if getattr(self.engine, "ngram", False):
+            self.proposer_worker = None
+            self.proposer = NGramProposer(self.engine)
+        else:
+            self.proposer_worker = MultiStepWorker(self.engine)
+            self.proposer = Top1Proposer(self.proposer_worker)
         self.scorer = MQAScorer(self.engine)
         self.metrics = AsyncMetricsCollector(self.engine)
 
