@@ -160,6 +160,9 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const bool wide = a->wide != 0;
   SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= (wide ? 256 : 16), SD_ERR_UNSUPPORTED,
              "sd_model_forward: B*q_len = %d outside 1..%d", rows, wide ? 256 : 16);
+  SD_REQUIRE(a->q_len * (d.n_heads / d.n_kv_heads) <= 64 || (wide && a->B == 1), SD_ERR_UNSUPPORTED,
+             "sd_model_forward: q_len %d * (Hq/Hkv) > 64 needs the wide family and one sequence",
+             a->q_len);
   SD_REQUIRE(a->token_ids && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
              SD_ERR_INVALID, "sd_model_forward: null buffer");
   SD_REQUIRE(a->max_ctx >= 1 && a->max_ctx <= d.max_pos, SD_ERR_INVALID,
@@ -198,10 +201,18 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                               llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
                               kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
                               Hq, Hkv, D, H, wws, w.wide_ws_bytes, stream));
-      SD_TRY(sd_paged_attention(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
-                                kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
-                                (int64_t)Hq * D, a->B, a->q_len, Hq, Hkv, D, d.attn_scale,
-                                a->max_ctx, a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
+      // One attention launch covers 64 / (Hq/Hkv) query tokens of a sequence; a longer chunk
+      // of ONE sequence (prefill) is walked in blocks of that many tokens (their K/V is in
+      // the cache already, the causal mask is per row).
+      const int q_blk = 64 / (Hq / Hkv);
+      for (int t0 = 0; t0 < a->q_len; t0 += q_blk) {
+        const int qn = a->q_len - t0 < q_blk ? a->q_len - t0 : q_blk;
+        SD_TRY(sd_paged_attention((const char*)qkv + (size_t)t0 * Hq * D * 2, (int64_t)Hq * D, kc, vc,
+                                  kv->block_tables, kv->max_blocks_per_seq, a->seq_lens,
+                                  a->pos_offset + t0, (char*)attn + (size_t)t0 * Hq * D * 2,
+                                  (int64_t)Hq * D, a->B, qn, Hq, Hkv, D, d.attn_scale, a->max_ctx,
+                                  a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
+      }
       SD_TRY(sd_linear_wide(l.o_w, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
                             Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));

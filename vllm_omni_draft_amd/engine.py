@@ -201,16 +201,17 @@ class SpecEngine:
         for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
             if model is None:
                 continue
-            # prefill in chunks: <= MAX_ROWS rows, and q_len * (Hq/Hkv) <= 64 for attention
-            chunk = min(MAX_ROWS, 64 // (model.cfg.n_heads // model.cfg.n_kv_heads))
-            for c0 in range(0, n, chunk):
-                q = min(chunk, n - c0)
-                last = c0 + q >= n
-                want = last and model is self.target
-                self._forward(model, kv, self.prompt_buf, 0, c0, zl, c0, 1, q,
-                              self.t_logits if want else None, slot0=slot)
-                if want:
-                    q_last = q
+            # prefill in chunks of the model's prefill_rows tokens (wide kernel family); only
+            # the last token's logits are needed, so the last chunk ends with a 1-token pass
+            chunk = model.prefill_rows
+            wide = chunk > MAX_ROWS or self.wide
+            bounds = list(range(0, n - 1, chunk)) + [n - 1]
+            for c0, c1 in zip(bounds, bounds[1:] + [n]):
+                want = c1 == n and model is self.target
+                view = _KvView(kv, slot)
+                model.forward(view, self.prompt_buf, 0, c0, zl, c0, 1, c1 - c0,
+                              self.t_logits[:c1 - c0] if want else None, self._ctx, wide=wide)
+            q_last = 1
         # first generated token from the last prompt row
         row = self.t_logits[q_last - 1:q_last]
         if self.sampling:

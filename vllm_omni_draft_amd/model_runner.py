@@ -17,6 +17,7 @@ from .weights import ModelWeights
 
 MAX_ROWS = 16        # token rows one forward pass may carry (B * q_len), narrow kernel family
 MAX_ROWS_WIDE = 256  # the same for the wide family (batched draft passes / verify)
+PREFILL_ROWS = 192   # prompt tokens of one sequence per prefill pass (wide family)
 
 
 def _ptr(t):
@@ -27,7 +28,7 @@ def _ptr(t):
 
 class DecoderModel:
     def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
-                 tp_group=None, wide: bool = False):
+                 tp_group=None, wide: bool = False, wide_prefill: bool = True):
         """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
@@ -36,6 +37,10 @@ class DecoderModel:
         # kernel family per model, because the two round differently)
         self.wide = bool(wide)
         self.max_rows = MAX_ROWS_WIDE if wide else MAX_ROWS
+        # Prompt chunks of one sequence always may take the wide family (up to PREFILL_ROWS
+        # tokens per pass): every engine prefills the same way, so streams stay comparable.
+        self.prefill_rows = PREFILL_ROWS if (wide or wide_prefill) else min(
+            MAX_ROWS, 64 // (cfg.n_heads // cfg.n_kv_heads))
         self.cfg: ModelConfig = weights.cfg
         cfg = self.cfg
         if max_ctx > cfg.max_pos:
@@ -62,7 +67,8 @@ class DecoderModel:
         self._handle = lib.sd_model_create(C.byref(desc))
         if not self._handle:
             raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")
-        nbytes = lib.sd_model_workspace_bytes(self._handle, self.max_rows, max_ctx, split_tokens)
+        nbytes = lib.sd_model_workspace_bytes(self._handle, max(self.max_rows, self.prefill_rows),
+                                              max_ctx, split_tokens)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=weights.embed.device)
 
     def __del__(self):
@@ -76,7 +82,8 @@ class DecoderModel:
 
     def forward(self, kv: PagedKVCache, token_ids: torch.Tensor, tok_stride: int, tok_offset: int,
                 seq_lens: torch.Tensor, pos_offset: int, B: int, q_len: int,
-                logits: Optional[torch.Tensor], max_ctx: Optional[int] = None) -> None:
+                logits: Optional[torch.Tensor], max_ctx: Optional[int] = None,
+                wide: Optional[bool] = None) -> None:
         """Enqueues one pass over B*q_len token rows on the current stream.
         Token t of sequence b is token_ids[b*tok_stride + tok_offset + t] at
         position seq_lens[b] + pos_offset + t.  `logits` ([B*q_len, vocab] f32)
@@ -94,7 +101,7 @@ class DecoderModel:
                                 tok_stride=tok_stride, tok_offset=tok_offset,
                                 seq_lens=seq_lens.data_ptr(), pos_offset=pos_offset,
                                 max_ctx=max_ctx or self.max_ctx, split_tokens=self.split_tokens,
-                                logits=_ptr(logits), wide=int(self.wide))
+                                logits=_ptr(logits), wide=int(self.wide if wide is None else wide))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           self.workspace.data_ptr(), self.workspace.numel(),
                                           torch.cuda.current_stream().cuda_stream)
