@@ -325,7 +325,7 @@ void plan_split(int n_tiles, int K, int& S, int& ks_per_split) {
   const int groups = (n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
   // one split (epilogue inside the kernel, no partial sums) once half the CUs have a
   // workgroup; otherwise enough splits for every CU
-  int want = groups >= 128 ? 1 : (256 + groups - 1) / groups;
+  int want = groups >= 128 ? 1 : 256 / groups;  // never more workgroups than CUs: one round
   const int max_s = (KS + 7) / 8;                   // at least 8 k-steps (256 columns) per split
   want = want < 1 ? 1 : (want > max_s ? max_s : want);
   ks_per_split = ((KS + want - 1) / want + kChunkSteps - 1) / kChunkSteps * kChunkSteps;
