@@ -277,3 +277,29 @@ def test_prompt_lookup_proposer_equals_ar_and_accepts_repeats(use_graph):
     eng = _engine(tw, None, 4, max_batch=2, ngram_max=3, temperature=1.0, seed=1, use_graph=use_graph)
     out = _generate(eng, prompts, 30)
     assert all(0 <= t < tcfg.vocab for o in out for t in o)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_disable_by_batch_size_keeps_streams_and_draft_cache(use_graph):
+    """Above the threshold a step emits one target token per sequence and proposes nothing;
+    when a sequence leaves, speculation resumes with an intact draft cache (draft == target:
+    every proposal accepted again)."""
+    tcfg = MODELS["llama"]
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    prompts = [[5, 9, 200, 31, 7], [1, 2, 3], list(range(10, 30))]
+    ar = [_generate(_engine(tw, None, 0, use_graph=use_graph), [p], 40)[0] for p in prompts]
+    eng = _engine(tw, tw, 3, max_batch=3, disable_by_batch_size=2, use_graph=use_graph)
+    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    for _ in range(6):                                   # 3 running > 2: no speculation
+        for o, new in zip(outs, eng.step()):
+            assert len(new) == 1
+            o.extend(new)
+    assert eng.metrics()["draft"] == 0
+    eng.remove_request(2)                                # 2 running: speculate again
+    done = outs.pop(2)
+    while min(len(o) for o in outs) < 40:
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    m = eng.metrics()
+    assert m["draft"] > 0 and m["accepted"] == m["draft"]
+    assert [o[:40] for o in outs] == ar[:2] and done == ar[2][:len(done)]

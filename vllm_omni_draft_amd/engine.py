@@ -51,6 +51,10 @@ class EngineConfig:
     # tokens after the most recent match are proposed (none if nothing matches).
     ngram_max: int = 0
     ngram_min: int = 1
+    # With more than this many running sequences a step does not speculate (0 = always
+    # speculate): one target token per sequence, and one draft pass that only keeps the
+    # draft's KV cache in step (upstream's speculative_disable_by_batch_size).
+    disable_by_batch_size: int = 0
 
 
 class SpecEngine:
@@ -255,6 +259,9 @@ class SpecEngine:
         if self.k == 0:
             self._enqueue_ar_step()
             return
+        if self._spec_disabled():
+            self._enqueue_no_spec_step()
+            return
         if self.ngram:
             self._enqueue_lookup_proposals()
         else:
@@ -271,13 +278,38 @@ class SpecEngine:
                              scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
-            ops.advance_state(self.ids_tmp.view(-1, 1), self.seq_lens, self.tok_buf,
-                              self.gen_tokens, self.gen_counts, 0, self.step_out)
+            ops.advance_state(self.ids_tmp[:B].view(-1, 1), self.seq_lens[:B], self.tok_buf[:B],
+                              self.gen_tokens[:B], self.gen_counts[:B], 0, self.step_out[:B])
         else:
             ops.argmax_partial(self.t_logits[:B], self.part_val, self.part_idx)
-            ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf, None, None,
-                                     self.seq_lens, self.gen_tokens, self.gen_counts, 0,
-                                     self.step_out)
+            ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf[:B], None, None,
+                                     self.seq_lens[:B], self.gen_tokens[:B], self.gen_counts[:B],
+                                     0, self.step_out[:B])
+
+    def _spec_disabled(self) -> bool:
+        t = self.cfg.disable_by_batch_size
+        return self.k > 0 and t > 0 and self.active > t
+
+    def _enqueue_no_spec_step(self) -> None:
+        """A step of a speculative engine that does not speculate (batch above
+        disable_by_batch_size): the target scores the last token only; the draft re-feeds the
+        last two tokens without its LM head, so its KV cache stays complete."""
+        B, k = self.active, self.k
+        if self.draft is not None:
+            self._forward(self.draft, self.d_kv, self.tok_buf, k + 2, 0, self.seq_lens, -2, B, 2, None)
+        self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, 1,
+                      self.t_logits)
+        if self.sampling:
+            ops.softmax_rows(self.t_logits[:B], self.cfg.temperature,
+                             out=self.t_probs.view(-1, self.V)[:B], scratch=self.samp_scratch)
+            ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
+                            scratch=self.samp_scratch)
+        else:
+            ops.argmax_rows(self.t_logits[:B], out=self.ids_tmp)
+        self.out_ids[:B].fill_(-1)
+        self.out_ids[:B, 0].copy_(self.ids_tmp[:B])
+        ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
+                          self.gen_tokens[:B], self.gen_counts[:B], k, self.step_out[:B])
 
     def _enqueue_propose(self, fused: bool = False) -> None:
         """k draft passes; proposals land in tok_buf[:, 2:], their probability
@@ -297,9 +329,9 @@ class SpecEngine:
             rows = self.d_logits[:B * step]
             if fused:
                 ops.argmax_partial(rows, self.part_val, self.part_idx)
-                ops.propose_from_partials(self.part_val, self.part_idx, off, step, self.tok_buf, k,
-                                          i, self.seq_lens, self.truth, self.accept_prob,
-                                          self.accept_seed)
+                ops.propose_from_partials(self.part_val, self.part_idx, off, step,
+                                          self.tok_buf[:B], k, i, self.seq_lens[:B], self.truth,
+                                          self.accept_prob, self.accept_seed)
                 continue
             if self.sampling:
                 ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
@@ -309,17 +341,17 @@ class SpecEngine:
                                 out=self.ids_tmp, row_offset=i, row_step=k, scratch=self.samp_scratch)
             else:
                 ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
-            ops.store_proposal(self.ids_tmp, self.tok_buf, k, i, self.seq_lens, self.truth,
-                               self.accept_prob, self.accept_seed)
+            ops.store_proposal(self.ids_tmp[:B], self.tok_buf[:B], k, i, self.seq_lens[:B],
+                               self.truth, self.accept_prob, self.accept_seed)
         if not fused:
-            ops.gather_proposals(self.tok_buf, self.draft_ids, k)
+            ops.gather_proposals(self.tok_buf[:B], self.draft_ids[:B], k)
 
     def _enqueue_lookup_proposals(self) -> None:
         """Prompt-lookup proposals (uploaded by _prepare_step) into the token window; in
         sampling mode their one-hot 'draft distribution' into d_probs."""
         B, k = self.active, self.k
-        ops.set_proposals(self.ext_props, self.tok_buf, k)
-        ops.gather_proposals(self.tok_buf, self.draft_ids, k)
+        ops.set_proposals(self.ext_props[:B], self.tok_buf[:B], k)
+        ops.gather_proposals(self.tok_buf[:B], self.draft_ids[:B], k)
         if self.sampling:
             self.d_probs.zero_()
             self.d_probs.scatter_(2, self.draft_ids.unsqueeze(-1), 1.0)
@@ -363,9 +395,10 @@ class SpecEngine:
         B, k = self.active, self.k
         lens = self.prop_lens[:B] if self.ngram else None
         if fused:
-            ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf, self.out_ids,
-                                     self.counters, self.seq_lens, self.gen_tokens,
-                                     self.gen_counts, k, self.step_out, proposal_lens=lens)
+            ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf[:B],
+                                     self.out_ids[:B], self.counters, self.seq_lens[:B],
+                                     self.gen_tokens[:B], self.gen_counts[:B], k,
+                                     self.step_out[:B], proposal_lens=lens)
             return
         if self.sampling:
             ops.rejection_sample(self.t_probs[:B], self.bonus_ids[:B], self.d_probs[:B],
@@ -374,8 +407,8 @@ class SpecEngine:
         else:
             ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], lens, self.counters,
                               out=self.out_ids)
-        ops.advance_state(self.out_ids, self.seq_lens, self.tok_buf, self.gen_tokens,
-                          self.gen_counts, k, self.step_out)
+        ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
+                          self.gen_tokens[:B], self.gen_counts[:B], k, self.step_out[:B])
 
     def remove_request(self, slot: int) -> None:
         """Frees batch slot `slot`; the last active sequence moves into it so
@@ -462,7 +495,7 @@ class SpecEngine:
         stream = torch.cuda.current_stream().cuda_stream
         lib = _lib.load()
         if self.cfg.use_graph:
-            key = (B, k, self.truth is not None, self._ctx)
+            key = (B, k, self.truth is not None, self._ctx, self._spec_disabled())
             g = self._graphs.get(key)
             if g is None:
                 self._enqueue_step()          # eager warm-up step (also a real step)

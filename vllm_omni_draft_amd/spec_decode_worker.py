@@ -247,6 +247,7 @@ class SpecDecodeConfig:
     split_tokens: int = 256
     use_graph: bool = True
     rows: str = "auto"             # kernel family, see EngineConfig.rows
+    speculative_disable_by_batch_size: int = 0   # 0 = speculate at every batch size
     # Tensor-parallel verify: the target is sharded over this many ranks (one process per
     # GPU), the draft stays whole on each.  `target` is then either this rank's shard or a
     # (ModelConfig, state_dict) pair that load_model shards itself.
@@ -307,7 +308,8 @@ class SpecDecodeWorker:
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
             # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
             use_graph=c.use_graph and tp == 1, rows=c.rows,
-            ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min),
+            ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
+            disable_by_batch_size=c.speculative_disable_by_batch_size),
             tp_group=getattr(self, "tp_group", None))
         self._wire()
 
@@ -369,7 +371,7 @@ class SpecDecodeWorker:
     def _run_speculative_decoding_step(self, req: ExecuteModelRequest) -> List[List[int]]:
         """propose -> score -> verify, as one replayed graph when enabled."""
         eng = self.engine
-        if eng.cfg.use_graph:
+        if eng.cfg.use_graph or eng._spec_disabled():
             return eng.step()
         eng.prepare_step()
         proposals = self.proposer.get_spec_proposals(req, frozenset())
