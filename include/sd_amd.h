@@ -89,6 +89,20 @@ int sd_greedy_verify(const int64_t* target_ids, const int64_t* draft_ids,
 /* Row-wise helpers over logits [R, V] f32 (row stride ld, in elements).
  * argmax: smallest index among equal maxima.  softmax: exp((x-max)/T)/sum.
  * sample: inverse CDF of probs with one uniform per row (f64 running sum).  */
+/* Typical acceptance (Cai et al. 2024, "Medusa"; replaces upstream
+ * `TypicalAcceptanceSampler.forward`, the alternative acceptor behind the same
+ * sampler surface as sd_rejection_sample).  Proposal x_i stands iff
+ *   p_i(x_i) > min(posterior_threshold, posterior_alpha * exp(-H(p_i))),
+ * H(p) = -sum p log(p + 1e-5) (f32 terms, f64 sum).  The first rejected position
+ * emits argmax p_j; k accepted proposals are followed by bonus_ids[b]; a short
+ * proposal (L < k) fully accepted emits argmax p_L.  Arguments as in
+ * sd_rejection_sample; no uniforms (the rule is deterministic).              */
+int sd_typical_acceptance(const float* target_probs, const int64_t* bonus_ids,
+                          const int64_t* draft_ids, const int32_t* proposal_lens,
+                          float posterior_threshold, float posterior_alpha,
+                          int64_t* out_ids, int64_t* counters, int B, int k, int V,
+                          sd_stream_t stream);
+
 int sd_argmax_rows(const float* logits, int64_t ld, int64_t* ids, int R, int V,
                    sd_stream_t stream);
 int sd_softmax_rows(const float* logits, int64_t ld, float temperature,

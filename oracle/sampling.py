@@ -91,6 +91,47 @@ def greedy_verify(target_ids, draft_ids, proposal_lens=None):
     return out, counters
 
 
+def typical_acceptance(target_probs, bonus_ids, draft_ids, posterior_threshold: float = 0.09,
+                       posterior_alpha: float = 0.3, proposal_lens=None, margin_out=None):
+    """Typical acceptance (Cai et al. 2024, "Medusa", section 3.3.1; upstream vLLM's
+    TypicalAcceptanceSampler, absent from the reference tree): proposal x_i is accepted iff
+        p_i(x_i) > min(posterior_threshold, posterior_alpha * exp(-H(p_i))),
+    H(p) = -sum p * log(p + 1e-5) (f32 terms, f64 sum); the token at the first rejected position
+    is argmax p_j; the bonus token follows k accepted proposals.  No uniforms: deterministic.
+    `margin_out`, if a list, receives |p_i(x_i) - threshold| of every tested position, so that a
+    comparison with another implementation can skip cases decided by rounding."""
+    p = np.asarray(target_probs, dtype=np.float32)
+    x = np.asarray(draft_ids, dtype=np.int64)
+    bonus = np.asarray(bonus_ids, dtype=np.int64).reshape(-1)
+    B, k1, V = p.shape
+    k = k1 - 1
+    out = np.full((B, k + 1), -1, dtype=np.int64)
+    counters = np.zeros(3, dtype=np.int64)
+    for b in range(B):
+        L = k if proposal_lens is None else int(min(max(int(proposal_lens[b]), 0), k))
+        j = 0
+        while j < L:
+            tok = int(x[b, j])
+            row = p[b, j]
+            terms = row * np.log(row + np.float32(1e-5))
+            entropy = -terms.astype(np.float64).sum()
+            thr = np.float32(min(np.float64(np.float32(posterior_threshold)),
+                                 np.float64(np.float32(posterior_alpha)) * np.exp(-entropy)))
+            cand = row[tok] if 0 <= tok < V else np.float32(-1.0)
+            if margin_out is not None:
+                margin_out.append(abs(float(cand) - float(thr)))
+            if not cand > thr:
+                break
+            out[b, j] = tok
+            j += 1
+        if j == L and L == k:
+            out[b, j] = bonus[b]
+        else:
+            out[b, j] = int(np.argmax(p[b, j]))
+        counters += (j, j + 1, L)
+    return out, counters
+
+
 def argmax_rows(logits) -> np.ndarray:
     return np.argmax(np.asarray(logits, dtype=np.float32), axis=-1).astype(np.int64)
 

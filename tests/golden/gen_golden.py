@@ -88,6 +88,36 @@ def rejection_cases():
     np.savez_compressed(os.path.join(HERE, "rejection_cases.npz"), **out)
 
 
+def typical_cases():
+    """Typical-acceptance cases; every tested position is decided by more than 1e-4."""
+    rng = np.random.default_rng(4242)
+    out = {}
+    n = 0
+    specs = [(1, 1, 64, None, 2.0), (4, 3, 64, None, 2.0), (4, 5, 256, None, 0.5),
+             (32, 5, 64, None, 1.0), (2, 5, 2048, None, 1.0), (4, 3, 64, "ragged", 2.0),
+             (3, 5, 512, "peaked", 6.0), (3, 4, 128, "flat", 0.05)]
+    for (B, k, V, kind, scale) in specs:
+        while True:
+            tl = rng.standard_normal((B, k + 1, V)).astype(np.float32) * scale
+            p = np.stack([sampling.softmax_rows(tl[b]) for b in range(B)])
+            # proposals: the target's own top tokens half of the time, random otherwise
+            ids = np.where(rng.random((B, k)) < 0.5, np.argmax(p[:, :k], axis=-1),
+                           rng.integers(0, V, size=(B, k))).astype(np.int64)
+            lens = rng.integers(0, k + 1, size=B).astype(np.int32) if kind == "ragged" else None
+            bonus = rng.integers(0, V, size=B).astype(np.int64)
+            margins = []
+            o, c = sampling.typical_acceptance(p, bonus, ids, 0.09, 0.3, lens, margin_out=margins)
+            if not margins or min(margins) > 1e-4:
+                break
+        pre = f"c{n}_"
+        out.update({pre + "target_probs": p, pre + "draft_ids": ids, pre + "bonus_ids": bonus,
+                    pre + "proposal_lens": np.zeros(0, np.int32) if lens is None else lens,
+                    pre + "out_ids": o, pre + "counters": c})
+        n += 1
+    out["n_cases"] = np.int64(n)
+    np.savez_compressed(os.path.join(HERE, "typical_cases.npz"), **out)
+
+
 def greedy_cases():
     rng = np.random.default_rng(7)
     out = {}
@@ -146,6 +176,7 @@ def e2e_tiny():
 
 if __name__ == "__main__":
     rejection_cases()
+    typical_cases()
     greedy_cases()
     e2e_tiny()
     print("golden vectors written to", HERE)

@@ -259,6 +259,32 @@ def test_sampling_mode_runs_and_preserves_first_token_distribution():
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_typical_acceptance_engine_known_answers(use_graph):
+    """Typical acceptance at its two extremes.  A threshold nothing can exceed rejects every
+    proposal and emits the target's most likely token: the stream after the (sampled) first
+    token is the greedy continuation.  A zero threshold lets every proposal stand."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    prompt = [5, 9, 200, 31, 7]
+    kw = dict(temperature=1.0, seed=3, use_graph=use_graph,
+              acceptance_method="typical_acceptance_sampler")
+    never = _engine(tw, dw, 3, posterior_threshold=2.0, posterior_alpha=1e9, **kw)
+    toks = _generate(never, [prompt], 24)[0]
+    m = never.metrics()
+    assert m["accepted"] == 0 and m["draft"] > 0
+    greedy = _generate(_engine(tw, None, 0, use_graph=use_graph), [prompt + toks[:1]], 23)[0]
+    assert toks[1:] == greedy
+    always = _engine(tw, dw, 3, posterior_threshold=0.0, posterior_alpha=0.0, **kw)
+    _generate(always, [prompt], 24)
+    m = always.metrics()
+    assert m["draft"] > 0 and m["accepted"] == m["draft"]
+    with pytest.raises(ValueError):
+        _engine(tw, dw, 3, acceptance_method="nonsense")
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_prompt_lookup_proposer_equals_ar_and_accepts_repeats(use_graph):
     """No draft model: n-gram proposals from the sequence's own history.  Greedy stream ==
     autoregressive stream; on a sequence that repeats, proposals are accepted."""

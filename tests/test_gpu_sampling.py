@@ -49,6 +49,64 @@ def test_rejection_golden(split):
         np.testing.assert_array_equal(counters.cpu().numpy(), g[f"c{i}_counters"])
 
 
+def test_typical_acceptance_golden():
+    ops = _ops()
+    g = np.load(os.path.join(GOLDEN, "typical_cases.npz"))
+    for i in range(int(g["n_cases"])):
+        pl = g[f"c{i}_proposal_lens"]
+        counters = torch.zeros(3, dtype=torch.int64, device="cuda")
+        out = ops.typical_acceptance(cu(g[f"c{i}_target_probs"]), cu(g[f"c{i}_bonus_ids"]),
+                                     cu(g[f"c{i}_draft_ids"]), 0.09, 0.3,
+                                     None if pl.size == 0 else cu(pl), counters)
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"c{i}_out_ids"], err_msg=f"case {i}")
+        np.testing.assert_array_equal(counters.cpu().numpy(), g[f"c{i}_counters"])
+
+
+@pytest.mark.parametrize("B,k,V,scale", [(1, 5, 128256, 4.0), (4, 3, 50272, 6.0), (8, 5, 151936, 8.0)])
+def test_typical_acceptance_full_vocab(B, k, V, scale):
+    """Full vocabulary rows from the library's own softmax; sequences whose outcome hangs on a
+    margin below 1e-6 (rounding of the entropy sum) are left out of the comparison."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(B * 100 + k)
+    tl = torch.randn(B * (k + 1), V, generator=gen, device="cuda") * scale
+    p = ops.softmax_rows(tl).view(B, k + 1, V)
+    top = p[:, :k].argmax(-1)
+    rnd = torch.randint(0, V, (B, k), generator=gen, device="cuda")
+    ids = torch.where(torch.rand(B, k, generator=gen, device="cuda") < 0.7, top, rnd)
+    bonus = torch.randint(0, V, (B,), generator=gen, device="cuda")
+    lens = torch.randint(0, k + 1, (B,), generator=gen, device="cuda").to(torch.int32)
+    for pl in (None, lens):
+        counters = torch.zeros(3, dtype=torch.int64, device="cuda")
+        out = ops.typical_acceptance(p, bonus, ids, 0.09, 0.3, pl, counters).cpu().numpy()
+        checked = 0
+        for b in range(B):
+            margins = []
+            want, _ = sampling.typical_acceptance(
+                p[b:b + 1].cpu().numpy(), bonus[b:b + 1].cpu().numpy(), ids[b:b + 1].cpu().numpy(),
+                0.09, 0.3, None if pl is None else pl[b:b + 1].cpu().numpy(), margin_out=margins)
+            if margins and min(margins) < 1e-6:
+                continue
+            np.testing.assert_array_equal(out[b], want[0], err_msg=f"sequence {b}")
+            checked += 1
+        assert checked >= max(1, B - 1)
+        acc, emitted, draft = counters.tolist()
+        assert emitted == acc + B and draft == (B * k if pl is None else int(lens.sum()))
+        assert emitted == int((out >= 0).sum())
+
+
+def test_typical_acceptance_rejects_bad_arguments():
+    ops = _ops()
+    from vllm_omni_draft_amd import _lib
+    p = torch.full((1, 2, 6), 1 / 6, device="cuda")
+    with pytest.raises(_lib.SdError):
+        ops.typical_acceptance(p, torch.zeros(1, dtype=torch.int64, device="cuda"),
+                               torch.zeros(1, 1, dtype=torch.int64, device="cuda"))   # V % 4 != 0
+    p = torch.full((1, 2, 8), 1 / 8, device="cuda")
+    with pytest.raises(_lib.SdError):
+        ops.typical_acceptance(p, torch.zeros(1, dtype=torch.int64, device="cuda"),
+                               torch.zeros(1, 3, dtype=torch.int64, device="cuda"))   # k mismatch
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("B,k,V", [(1, 5, 128256), (4, 3, 50272), (32, 5, 151936), (3, 1, 64)])
 def test_rejection_random_full_vocab(B, k, V, split):

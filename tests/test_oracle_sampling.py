@@ -40,6 +40,46 @@ def test_golden_greedy_cases():
         np.testing.assert_array_equal(cnt, g[f"c{i}_counters"])
 
 
+def test_golden_typical_cases():
+    g = np.load(os.path.join(GOLDEN, "typical_cases.npz"))
+    n = int(g["n_cases"])
+    assert n >= 8
+    for i in range(n):
+        pl = g[f"c{i}_proposal_lens"]
+        out, cnt = sampling.typical_acceptance(g[f"c{i}_target_probs"], g[f"c{i}_bonus_ids"],
+                                               g[f"c{i}_draft_ids"], 0.09, 0.3,
+                                               None if pl.size == 0 else pl)
+        np.testing.assert_array_equal(out, g[f"c{i}_out_ids"])
+        np.testing.assert_array_equal(cnt, g[f"c{i}_counters"])
+
+
+def test_typical_acceptance_known_answers():
+    """Hand-computed thresholds.  One-hot rows: H = 0, threshold = min(cap, alpha) -> only the
+    hot token stands.  Uniform rows over V = 64: H = -log(1/64 + 1e-5) ~ 4.158, threshold
+    0.3 * exp(-H) ~ 0.00469 < 1/64 -> every token stands."""
+    V, k = 64, 3
+    hot = np.zeros((1, k + 1, V), np.float32)
+    for i, t in enumerate([7, 8, 9, 10]):
+        hot[0, i, t] = 1.0
+    out, cnt = sampling.typical_acceptance(hot, [33], [[7, 8, 9]])
+    assert out.tolist() == [[7, 8, 9, 33]] and cnt.tolist() == [3, 4, 3]      # all stand + bonus
+    out, cnt = sampling.typical_acceptance(hot, [33], [[7, 5, 9]])
+    assert out.tolist() == [[7, 8, -1, -1]] and cnt.tolist() == [1, 2, 3]     # argmax replaces x_1
+    out, cnt = sampling.typical_acceptance(hot, [33], [[7, 8, 9]], proposal_lens=[2])
+    assert out.tolist() == [[7, 8, 9, -1]] and cnt.tolist() == [2, 3, 2]      # short: argmax p_L
+    flat = np.full((1, k + 1, V), 1.0 / V, np.float32)
+    out, cnt = sampling.typical_acceptance(flat, [5], [[1, 2, 3]])
+    assert out.tolist() == [[1, 2, 3, 5]] and cnt.tolist() == [3, 4, 3]
+    # the cap rules when alpha * exp(-H) is above it: 0.05 stands under cap 0.04, falls under 0.09
+    row = np.zeros(V, np.float32)
+    row[0], row[1] = 0.95, 0.05
+    two = np.tile(row, (1, 2, 1))
+    assert sampling.typical_acceptance(two, [9], [[1]], 0.04, 0.3)[0].tolist() == [[1, 9]]
+    assert sampling.typical_acceptance(two, [9], [[1]], 0.09, 0.3)[0].tolist() == [[0, -1]]
+    # out-of-range proposal ids never stand
+    assert sampling.typical_acceptance(two, [9], [[V + 3]])[0].tolist() == [[0, -1]]
+
+
 def test_greedy_known_answers():
     t = np.array([[5, 6, 7, 8]])
     out, cnt = sampling.greedy_verify(t, np.array([[5, 6, 7]]))

@@ -60,6 +60,7 @@ SIGNATURES = {
     "sd_last_error": (i32, [C.c_char_p, C.c_size_t]),
     "sd_device_info": (i32, [C.POINTER(i32), C.c_char_p, C.c_size_t]),
     "sd_rejection_sample": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "sd_typical_acceptance": (i32, [vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, i32, i32, i32, vp]),
     "sd_greedy_verify": (i32, [vp, vp, vp, vp, vp, i32, i32, vp]),
     "sd_argmax_rows": (i32, [vp, i64, vp, i32, i32, vp]),
     "sd_softmax_rows": (i32, [vp, i64, C.c_float, vp, i64, i32, i32, vp]),

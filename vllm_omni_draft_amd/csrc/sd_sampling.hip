@@ -210,6 +210,57 @@ __global__ __launch_bounds__(kSampleThreads) void rejection_sample_kernel(
   }
 }
 
+// Typical acceptance: proposal x_i stands iff p_i(x_i) > min(cap, alpha * exp(-H(p_i))),
+// H(p) = -sum p log(p + 1e-5); the first rejected position emits argmax p_j.  One workgroup per
+// sequence walks the positions in order and stops at the first rejection, so rows past it are
+// never read.  Every thread computes the same threshold: the walk is uniform.
+__global__ __launch_bounds__(kSampleThreads) void typical_acceptance_kernel(
+    const float* __restrict__ target_probs, const int64_t* __restrict__ bonus_ids,
+    const int64_t* __restrict__ draft_ids, const int32_t* __restrict__ proposal_lens,
+    float cap, float alpha, int64_t* __restrict__ out_ids,
+    unsigned long long* __restrict__ counters, int k, int V) {
+  __shared__ double s_d[kSampleWaves];
+  __shared__ float s_f[kSampleWaves];
+  __shared__ int s_i[kSampleWaves];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int L = proposal_lens ? proposal_lens[b] : k;
+  L = min(max(L, 0), k);
+  const float* pb = target_probs + (size_t)b * (k + 1) * V;
+  int j = 0;
+  for (; j < L; ++j) {
+    const float* row = pb + (size_t)j * V;
+    double local = 0.0;
+    for (int i = tid * 4; i < V; i += kSampleThreads * 4) {
+      if (i + 3 < V) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        local += (double)(v.x * logf(v.x + 1e-5f)) + (double)(v.y * logf(v.y + 1e-5f)) +
+                 (double)(v.z * logf(v.z + 1e-5f)) + (double)(v.w * logf(v.w + 1e-5f));
+      } else {
+        for (int e = i; e < V; ++e) local += (double)(row[e] * logf(row[e] + 1e-5f));
+      }
+    }
+    const double entropy = -block_sum_f64(local, s_d);
+    const float thr = (float)fmin((double)cap, (double)alpha * exp(-entropy));
+    const int64_t x = draft_ids[(size_t)b * k + j];
+    const float cand = (x >= 0 && x < V) ? row[x] : -1.f;
+    if (!(cand > thr)) break;
+  }
+  int64_t tok;
+  if (j == L && L == k) tok = bonus_ids[b];
+  else tok = block_argmax(pb + (size_t)j * V, V, s_f, s_i);
+  if (tid <= k) {
+    int64_t v = -1;
+    if (tid < j) v = draft_ids[(size_t)b * k + tid];
+    else if (tid == j) v = tok;
+    out_ids[(size_t)b * (k + 1) + tid] = v;
+  }
+  if (tid == 0 && counters) {
+    atomicAdd(&counters[0], (unsigned long long)j);
+    atomicAdd(&counters[1], (unsigned long long)(j + 1));
+    atomicAdd(&counters[2], (unsigned long long)L);
+  }
+}
+
 __global__ __launch_bounds__(SD_WAVE) void greedy_verify_kernel(
     const int64_t* __restrict__ target_ids, const int64_t* __restrict__ draft_ids,
     const int32_t* __restrict__ proposal_lens, int64_t* __restrict__ out_ids,
@@ -831,6 +882,29 @@ extern "C" int sd_rejection_sample(const float* target_probs, const int64_t* bon
                      u_accept, u_recover, proposal_lens, out_ids,
                      (unsigned long long*)counters, k, V);
   SD_CHECK_LAUNCH("sd_rejection_sample");
+  return SD_OK;
+}
+
+extern "C" int sd_typical_acceptance(const float* target_probs, const int64_t* bonus_ids,
+                                     const int64_t* draft_ids, const int32_t* proposal_lens,
+                                     float posterior_threshold, float posterior_alpha,
+                                     int64_t* out_ids, int64_t* counters, int B, int k, int V,
+                                     sd_stream_t stream) {
+  SD_REQUIRE(B >= 0 && k >= 1 && k <= 63 && V >= 1, SD_ERR_INVALID,
+             "sd_typical_acceptance: need B>=0, 1<=k<=63, V>=1 (B=%d k=%d V=%d)", B, k, V);
+  SD_REQUIRE(V % 4 == 0, SD_ERR_UNSUPPORTED, "sd_typical_acceptance: V %% 4 != 0 (V=%d)", V);
+  SD_REQUIRE(target_probs && bonus_ids && draft_ids && out_ids, SD_ERR_INVALID,
+             "sd_typical_acceptance: null pointer");
+  SD_REQUIRE(sd_aligned16(target_probs), SD_ERR_INVALID,
+             "sd_typical_acceptance: probability rows must be 16-byte aligned");
+  SD_REQUIRE(posterior_threshold >= 0.f && posterior_alpha >= 0.f, SD_ERR_INVALID,
+             "sd_typical_acceptance: negative threshold or alpha");
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(typical_acceptance_kernel, dim3(B), dim3(kSampleThreads), 0,
+                     (hipStream_t)stream, target_probs, bonus_ids, draft_ids, proposal_lens,
+                     posterior_threshold, posterior_alpha, out_ids,
+                     (unsigned long long*)counters, k, V);
+  SD_CHECK_LAUNCH("sd_typical_acceptance");
   return SD_OK;
 }
 

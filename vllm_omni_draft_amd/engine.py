@@ -55,6 +55,13 @@ class EngineConfig:
     # speculate): one target token per sequence, and one draft pass that only keeps the
     # draft's KV cache in step (upstream's speculative_disable_by_batch_size).
     disable_by_batch_size: int = 0
+    # Acceptance rule under sampling (temperature > 0): "rejection_sampler" (lossless,
+    # Leviathan et al.) or "typical_acceptance_sampler" (a proposal stands if the target gives
+    # it more than min(posterior_threshold, posterior_alpha * exp(-entropy)); the first
+    # rejected position emits the target's most likely token).  Greedy decoding matches tokens.
+    acceptance_method: str = "rejection_sampler"
+    posterior_threshold: float = 0.09
+    posterior_alpha: float = 0.3
 
 
 class SpecEngine:
@@ -65,6 +72,9 @@ class SpecEngine:
         draft is whole.  Every rank runs the same steps on the same inputs."""
         if cfg.k < 0 or cfg.k > 7:
             raise ValueError("k must be in 0..7")
+        if cfg.acceptance_method not in ("rejection_sampler", "typical_acceptance_sampler"):
+            raise ValueError(f"unknown acceptance_method {cfg.acceptance_method!r}")
+        self.typical = cfg.acceptance_method == "typical_acceptance_sampler"
         self.ngram = cfg.k > 0 and draft is None and cfg.ngram_max > 0
         if cfg.k > 0 and draft is None and not self.ngram:
             raise ValueError("k > 0 needs a draft model (or ngram_max > 0 for prompt lookup)")
@@ -400,7 +410,11 @@ class SpecEngine:
                                      self.gen_tokens[:B], self.gen_counts[:B], k,
                                      self.step_out[:B], proposal_lens=lens)
             return
-        if self.sampling:
+        if self.sampling and self.typical:
+            ops.typical_acceptance(self.t_probs[:B], self.bonus_ids[:B], self.draft_ids[:B],
+                                   self.cfg.posterior_threshold, self.cfg.posterior_alpha, lens,
+                                   self.counters, out=self.out_ids[:B])
+        elif self.sampling:
             ops.rejection_sample(self.t_probs[:B], self.bonus_ids[:B], self.d_probs[:B],
                                  self.draft_ids[:B], self.u_accept[:B], self.u_recover[:B], lens,
                                  self.counters, scratch=self.samp_scratch, out=self.out_ids[:B])

@@ -87,6 +87,29 @@ def rejection_sample(target_probs, bonus_ids, draft_probs, draft_ids, u_accept, 
     return out
 
 
+def typical_acceptance(target_probs, bonus_ids, draft_ids, posterior_threshold=0.09,
+                       posterior_alpha=0.3, proposal_lens=None, counters=None, out=None):
+    """Typical acceptance over probability rows [B, k+1, V]; returns [B, k+1] int64."""
+    B, k1, V = target_probs.shape
+    k = k1 - 1
+    _need(target_probs, torch.float32, "target_probs")
+    _need(draft_ids, torch.int64, "draft_ids")
+    bonus = bonus_ids.reshape(-1)
+    _need(bonus, torch.int64, "bonus_ids")
+    if tuple(draft_ids.shape) != (B, k) or bonus.numel() != B:
+        raise _lib.SdError("typical_acceptance: inconsistent shapes")
+    if proposal_lens is not None:
+        _need(proposal_lens, torch.int32, "proposal_lens")
+    if counters is not None:
+        _need(counters, torch.int64, "counters")
+    if out is None:
+        out = torch.empty(B, k + 1, dtype=torch.int64, device=target_probs.device)
+    _lib.check(_lib.load().sd_typical_acceptance(
+        _p(target_probs), _p(bonus), _p(draft_ids), _p(proposal_lens), float(posterior_threshold),
+        float(posterior_alpha), _p(out), _p(counters), B, k, V, _stream()), "sd_typical_acceptance")
+    return out
+
+
 def greedy_verify(target_ids, draft_ids, proposal_lens=None, counters=None, out=None):
     B, k1 = target_ids.shape
     k = k1 - 1

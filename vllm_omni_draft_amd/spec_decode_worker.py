@@ -231,6 +231,35 @@ class RejectionSampler(nn.Module):
             self.num_accepted_tokens, self.num_emitted_tokens, self.num_draft_tokens = a, e, d
 
 
+class TypicalAcceptanceSampler(nn.Module):
+    """Typical acceptance (Cai et al. 2024): a proposal stands if the target gives it more than
+    min(posterior_threshold, posterior_alpha * exp(-entropy)).  Call shape and counters of
+    vLLM's `TypicalAcceptanceSampler.forward`; `draft_probs` is accepted and unused."""
+
+    def __init__(self, posterior_threshold: float = 0.09, posterior_alpha: float = 0.3):
+        super().__init__()
+        self.posterior_threshold, self.posterior_alpha = posterior_threshold, posterior_alpha
+        self.num_accepted_tokens = 0
+        self.num_emitted_tokens = 0
+        self.num_draft_tokens = 0
+        self._counters: Optional[torch.Tensor] = None
+
+    def forward(self, target_with_bonus_probs: torch.Tensor, bonus_token_ids: torch.Tensor,
+                draft_probs: Optional[torch.Tensor], draft_token_ids: torch.Tensor) -> torch.Tensor:
+        dev = target_with_bonus_probs.device
+        if self._counters is None or self._counters.device != dev:
+            self._counters = torch.zeros(3, dtype=torch.int64, device=dev)
+        return ops.typical_acceptance(target_with_bonus_probs.contiguous(),
+                                      bonus_token_ids.contiguous(), draft_token_ids.contiguous(),
+                                      self.posterior_threshold, self.posterior_alpha, None,
+                                      self._counters)
+
+    def sync_counters(self) -> None:
+        if self._counters is not None:
+            a, e, d = self._counters.tolist()
+            self.num_accepted_tokens, self.num_emitted_tokens, self.num_draft_tokens = a, e, d
+
+
 # --------------------------------------------------------------------------- worker
 @dataclass
 class SpecDecodeConfig:
@@ -248,6 +277,9 @@ class SpecDecodeConfig:
     use_graph: bool = True
     rows: str = "auto"             # kernel family, see EngineConfig.rows
     speculative_disable_by_batch_size: int = 0   # 0 = speculate at every batch size
+    spec_decoding_acceptance_method: str = "rejection_sampler"  # or "typical_acceptance_sampler"
+    typical_acceptance_sampler_posterior_threshold: float = 0.09
+    typical_acceptance_sampler_posterior_alpha: float = 0.3
     # Tensor-parallel verify: the target is sharded over this many ranks (one process per
     # GPU), the draft stays whole on each.  `target` is then either this rank's shard or a
     # (ModelConfig, state_dict) pair that load_model shards itself.
@@ -309,7 +341,10 @@ class SpecDecodeWorker:
             # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
             use_graph=c.use_graph and tp == 1, rows=c.rows,
             ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
-            disable_by_batch_size=c.speculative_disable_by_batch_size),
+            disable_by_batch_size=c.speculative_disable_by_batch_size,
+            acceptance_method=c.spec_decoding_acceptance_method,
+            posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
+            posterior_alpha=c.typical_acceptance_sampler_posterior_alpha),
             tp_group=getattr(self, "tp_group", None))
         self._wire()
 
