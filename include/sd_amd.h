@@ -218,6 +218,16 @@ size_t sd_tiled_weight_elems(int N, int K, int mode);
 /* src row-major -> dst tiled; param = head_dim for SD_TILE_ROTARY, else 0.  */
 int sd_tile_weights(const void* src, void* dst, int N, int K, int mode,
                     int param, sd_stream_t stream);
+/* The same for fp8 (OCP e4m3) weights, one byte per element: tile (nt, ks2) holds
+ * two 32-column k-steps per lane (16 bytes), so a wave load is still 1 KiB.
+ * dst holds sd_tiled_weight_elems(N, K, mode) bytes.  K must be a multiple of 64.
+ * The linear layers below take such a buffer as W when w_scale is not NULL:
+ * w_scale[r] (f32, indexed by source row like bias) multiplies the finished sum
+ * of output row r, i.e. the matrix is W[r, :] * w_scale[r]; weights are
+ * converted to bf16 in registers and activations stay bf16 (weight-only fp8:
+ * these layers are bound by the weight stream, which halves).                  */
+int sd_tile_weights_fp8(const void* src, void* dst, int N, int K, int mode,
+                        int param, sd_stream_t stream);
 
 typedef enum {
   SD_EPI_STORE = 0,     /* out = bf16(acc + bias)                           */
@@ -234,10 +244,11 @@ typedef enum {
  *   residual [M, N] bf16 (row stride ldo) or NULL.
  * Each output element is accumulated in an order that depends only on K, so
  * a row's result does not depend on M or on the other rows.
- * Requires K % 32 == 0 and 16-byte aligned rows.                            */
-int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
-              const void* residual, void* out, int64_t ldo, int M, int N, int K,
-              int epilogue, sd_stream_t stream);
+ * Requires K % 32 == 0 and 16-byte aligned rows.  w_scale: NULL for bf16
+ * tiles, else W holds fp8 tiles (sd_tile_weights_fp8) and K % 64 == 0.       */
+int sd_linear(const void* W, const float* w_scale, const void* x, int64_t ldx,
+              const void* bias, const void* residual, void* out, int64_t ldo,
+              int M, int N, int K, int epilogue, sd_stream_t stream);
 
 /* The same linear layers at up to 256 token rows (batched draft passes, batched
  * verify; replaces the batch-expanded target pass of
@@ -270,8 +281,9 @@ int sd_qkv_rope_wide(const void* W, const void* x, int64_t ldx, const void* bias
  * Same B, q_len, heads, max_ctx and split_tokens as the attention call; at most
  * 8 splits, B*q_len <= 16; epilogue STORE or RESIDUAL.  Every workgroup redoes
  * the merge, so it pays only for few rows and splits (decode, short verify).  */
-int sd_linear_attn_merge(const void* W, const void* workspace,
-                         size_t workspace_bytes, const int32_t* seq_lens,
+int sd_linear_attn_merge(const void* W, const float* w_scale,
+                         const void* workspace, size_t workspace_bytes,
+                         const int32_t* seq_lens,
                          int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
                          int max_ctx, int split_tokens, const void* bias,
                          const void* residual, void* out, int64_t ldo, int N,
@@ -282,7 +294,8 @@ int sd_linear_attn_merge(const void* W, const void* workspace,
 * sd_layernorm would, then multiplied.  K is the hidden size; needs
  * (M + 1) * K * 2 <= 128 KiB (the normalised rows live in LDS).  Epilogues: STORE,
  * SILU_MUL, RELU, F32.                                                        */
-int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w,
+int sd_norm_linear(const void* W, const float* w_scale, const void* x,
+                   int64_t ldx, const void* norm_w,
                    const void* norm_b, float eps, int layer_norm,
                    const void* bias, void* out, int64_t ldo, int M, int N,
                    int K, int epilogue, sd_stream_t stream);
@@ -292,7 +305,8 @@ int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w
  * bias is indexed by source row.  Rotated q goes to
  * q_out [B*q_len, Hq*D] (row stride ldq); rotated k and v go straight into the
  * cache pages (arguments as sd_rope_append).  norm_w == NULL skips the norm. */
-int sd_norm_qkv_rope(const void* W, const void* x, int64_t ldx,
+int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x,
+                     int64_t ldx,
                      const void* norm_w, const void* norm_b, float eps,
                      int layer_norm, const void* bias, void* q_out, int64_t ldq,
                      const float* rope_cs, int max_pos, void* k_cache,
@@ -341,6 +355,12 @@ typedef struct {
   const void* up_b;         /* or NULL */
   const void* down_w;       /* [H, F], tiled SD_TILE_PLAIN */
   const void* down_b;       /* or NULL */
+  /* fp8 weights (sd_model_desc.weight_fp8): f32 scale per source row of the
+   * matrix (qkv: (Hq+2Hkv)*D, o: H, up: 2F or F, down: H); else NULL.        */
+  const float* qkv_s;
+  const float* o_s;
+  const float* up_s;
+  const float* down_s;
 } sd_layer_weights;
 
 typedef struct {
@@ -367,6 +387,12 @@ typedef struct {
   int tp_rank;
   sd_allreduce_fn allreduce;
   void* allreduce_ctx;
+  /* weight_fp8 != 0: every layer matrix and the LM head are fp8 tiles
+   * (sd_tile_weights_fp8) with per-row scales (layers[i].*_s, lm_head_s); the
+   * embedding table, norms and biases stay bf16.  Passes of more than 16 rows
+   * (forward args.wide) are not available for fp8 weights.                   */
+  int weight_fp8;
+  const float* lm_head_s;
 } sd_model_desc;
 
 typedef struct sd_model sd_model;

@@ -173,6 +173,121 @@ def test_fused_qkv_rope_append_matches_unfused(Hq, Hkv, D, H, rope):
     assert caches[1][1].abs().sum() > 0 and caches[1][2].abs().sum() > 0
 
 
+# ------------------------------------------------------------------ fp8 weights
+def _fp8_pow2(W):
+    """(fp8 values, power-of-two f32 scale per row, the bf16 matrix they stand for exactly)."""
+    Wf = W.float()
+    e = torch.ceil(torch.log2(Wf.abs().amax(dim=1).clamp_min(1e-12) / 448.0))
+    scale = torch.exp2(e).to(torch.float32)
+    q = (Wf / scale[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    exact = (q.float() * scale[:, None]).to(torch.bfloat16)
+    assert torch.equal(exact.float(), q.float() * scale[:, None])
+    return q, scale, exact
+
+
+@pytest.mark.parametrize("M", [1, 6, 16])
+@pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (257, 896), (96, 14336)])
+def test_fp8_linear_is_the_bf16_kernel_on_dequantised_weights(M, N, K):
+    """With power-of-two scales the dequantised matrix is exact in bf16 and scaling commutes
+    with every rounding, so the fp8 kernel must reproduce the bf16 kernel bit for bit, in
+    every epilogue: this pins the byte layout, the in-register conversion and the scale
+    indexing (plain, gated) at once."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(M * 11 + N)
+    x = torch.randn(M, K, generator=gen, device="cuda").to(torch.bfloat16)
+    bias = (torch.randn(2 * N, generator=gen, device="cuda") * 0.1).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=gen, device="cuda").to(torch.bfloat16)
+    W2 = (torch.randn(2 * N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    W2[3] *= 37.0          # rows of very different magnitude: per-row scales matter
+    W2[N + 1] *= 0.01
+    q2, s2, exact2 = _fp8_pow2(W2)
+    q, sc, exact = q2[:N].contiguous(), s2[:N].contiguous(), exact2[:N].contiguous()
+    Wt = ops.tile_weights(q, ops.TILE_PLAIN, scale=sc)
+    assert Wt.data.dtype == torch.uint8 and Wt.nbytes() < 0.6 * ops.tile_weights(exact).nbytes()
+    for epi in (ops.EPI_STORE, ops.EPI_RESIDUAL, ops.EPI_RELU, ops.EPI_F32, ops.EPI_GELU_TANH):
+        for b in (None, bias[:N].contiguous()):
+            r = res if epi == ops.EPI_RESIDUAL else None
+            assert torch.equal(ops.linear(Wt, x, b, r, epi), ops.linear(exact, x, b, r, epi)), epi
+    Wg = ops.tile_weights(q2, ops.TILE_GATED, scale=s2)
+    for b in (None, bias):
+        assert torch.equal(ops.linear(Wg, x, b, None, ops.EPI_SILU_MUL),
+                           ops.linear(exact2, x, b, None, ops.EPI_SILU_MUL))
+
+
+def test_fp8_linear_general_scales_and_quantisation_error():
+    """Arbitrary per-row scales: the f32 output is exactly (sum over the fp8 values) * scale,
+    and the quantised layer stays within e4m3's relative step of the bf16 layer."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    M, N, K = 6, 512, 4096
+    x = torch.randn(M, K, generator=gen, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=gen, device="cuda") * 0.02).to(torch.bfloat16)
+    q, scale = ops.quantize_fp8(W)
+    assert q.dtype == torch.float8_e4m3fn and scale.dtype == torch.float32
+    got = ops.linear(ops.tile_weights(q, scale=scale), x, None, None, ops.EPI_F32)
+    unscaled = ops.linear(q.to(torch.bfloat16), x, None, None, ops.EPI_F32)
+    assert torch.equal(got, unscaled * scale[None, :])
+    ref = x.double() @ W.double().t()
+    # 3 mantissa bits: relative steps of 6-12%, i.e. ~2-3% rms error per weight, which carries
+    # over to a sum of K independent terms
+    err = (got.double() - ref).abs()
+    assert err.max().item() < 0.05 * ref.abs().max().item()
+    assert err.mean().item() < 0.05 * ref.abs().mean().item()
+
+
+@pytest.mark.parametrize("ln", [False, True])
+def test_fp8_fused_norm_and_qkv_rope_match_bf16_kernels(ln):
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    gen = torch.Generator(device="cuda").manual_seed(17)
+    Hq, Hkv, D, H, B, q_len = 4, 2, 64, 256, 2, 3
+    M = B * q_len
+    x = torch.randn(M, H, generator=gen, device="cuda").to(torch.bfloat16)
+    g = (1 + 0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16)
+    nb = (0.1 * torch.randn(H, generator=gen, device="cuda")).to(torch.bfloat16) if ln else None
+    W2 = (torch.randn(2 * 192, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    q2, s2, exact2 = _fp8_pow2(W2)
+    for epi, tm in ((ops.EPI_F32, ops.TILE_PLAIN), (ops.EPI_STORE, ops.TILE_PLAIN),
+                    (ops.EPI_SILU_MUL, ops.TILE_GATED), (ops.EPI_RELU, ops.TILE_PLAIN)):
+        got = ops.norm_linear(ops.tile_weights(q2, tm, scale=s2), x, g, nb, 1e-5, ln, None, epi)
+        ref = ops.norm_linear(ops.tile_weights(exact2, tm), x, g, nb, 1e-5, ln, None, epi)
+        assert torch.equal(got, ref), epi
+    # QKV + rotary + cache append: the scale is indexed by source row through the rotary tiling
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=128)
+    cs = rope_table(cfg).cuda()
+    Wq = (torch.randn((Hq + 2 * Hkv) * D, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    Wq[5] *= 20.0
+    qq, sq, exq = _fp8_pow2(Wq)
+    bias = (0.1 * torch.randn((Hq + 2 * Hkv) * D, generator=gen, device="cuda")).to(torch.bfloat16)
+    bt = torch.tensor([[3, 1, 4], [0, 5, 2]], dtype=torch.int32, device="cuda")
+    seq_lens = torch.tensor([17, 30], dtype=torch.int32, device="cuda")
+    outs = []
+    for Wt in (ops.tile_weights(qq, ops.TILE_ROTARY, D, scale=sq), ops.tile_weights(exq, ops.TILE_ROTARY, D)):
+        kc = torch.zeros(6, Hkv, D * 16, dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        qo = ops.norm_qkv_rope(Wt, x, g, nb, 1e-5, ln, bias, cs, kc, vc, bt, seq_lens, -1, B, q_len,
+                               Hq, Hkv, D)
+        outs.append((qo, kc, vc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][1].abs().sum() > 0
+
+
+def test_fp8_rejects_unsupported_uses():
+    ops = _ops()
+    from vllm_omni_draft_amd._lib import SdError
+    W = torch.randn(64, 96, device="cuda").to(torch.bfloat16)        # K % 64 != 0
+    q, s = ops.quantize_fp8(W)
+    with pytest.raises(SdError):
+        ops.tile_weights(q, scale=s)
+    q, s = ops.quantize_fp8(torch.randn(64, 128, device="cuda").to(torch.bfloat16))
+    with pytest.raises(SdError):
+        ops.tile_weights(q)                                           # no scale
+    Wt = ops.tile_weights(q, scale=s)
+    with pytest.raises(SdError):
+        ops.linear_wide(Wt, torch.zeros(32, 128, dtype=torch.bfloat16, device="cuda"))
+
+
 # ------------------------------------------------------------------ 17..256 token rows
 @pytest.mark.parametrize("M", [17, 32, 50, 192, 256])
 @pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (257, 896), (96, 14336)])

@@ -15,14 +15,32 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _product(ocfg: OracleConfig, state, qkv_bias=False):
+def _product(ocfg: OracleConfig, state, qkv_bias=False, fp8=False):
     from vllm_omni_draft_amd import config, weights
     cfg = config.create_model_config(
         None, arch=ocfg.arch, n_layers=ocfg.n_layers, hidden=ocfg.hidden, n_heads=ocfg.n_heads,
         n_kv_heads=ocfg.n_kv_heads, head_dim=ocfg.head_dim, ffn=ocfg.ffn, vocab=ocfg.vocab,
         norm_eps=ocfg.norm_eps, rope_theta=ocfg.rope_theta, rope_scaling=ocfg.rope_scaling,
         max_pos=ocfg.max_pos, tie_embeddings=ocfg.tie_embeddings, qkv_bias=qkv_bias)
-    return weights.from_state_dict(cfg, state, "cuda")
+    return weights.from_state_dict(cfg, state, "cuda", fp8=fp8)
+
+
+def _fp8_dequantised(ocfg: OracleConfig, state):
+    """The state dict the fp8 product computes with: every projection matrix (and the LM
+    head, a quantised copy when tied) replaced by fp8(W / scale) * scale, per-row scales."""
+    from vllm_omni_draft_amd import ops
+    out = {}
+    for k, v in state.items():
+        is_matrix = k.endswith("weight") and v.dim() == 2 and "embed" not in k
+        if is_matrix:
+            q, sc = ops.quantize_fp8(v.to(torch.bfloat16))
+            v = q.float() * sc[:, None]
+        out[k] = v
+    if "lm_head.weight" not in state:
+        emb = next(v for k, v in state.items() if k.endswith("embed_tokens.weight"))
+        q, sc = ops.quantize_fp8(emb.to(torch.bfloat16))
+        out["lm_head.weight"] = q.float() * sc[:, None]
+    return out
 
 
 def _bf(state):
@@ -101,6 +119,47 @@ def test_wide_forward_logits_match_oracle_and_are_chunk_invariant(name):
     assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
     again = _logits_via_engine(w, toks, [1] * 5 + [8, 8, 8, 6, 2], wide=True)
     assert torch.equal(got, again)
+
+
+@pytest.mark.parametrize("name", ["llama", "opt", "qwen2"])
+def test_fp8_forward_logits_match_oracle_on_dequantised_weights(name):
+    """fp8 weights (quantised at load, per-row scales): the native forward against the CPU
+    oracle run on the dequantised matrices, to the bf16-activation tolerance of the bf16 test."""
+    ocfg = MODELS[name]
+    if ocfg.ffn % 64:   # fp8 tiles hold 64 input columns
+        ocfg = OracleConfig(**{**vars(ocfg), "ffn": (ocfg.ffn + 63) // 64 * 64})
+    state = _bf(random_state(ocfg, seed=11, qkv_bias=(name == "qwen2")))
+    w = _product(ocfg, state, qkv_bias=(name == "qwen2"), fp8=True)
+    assert w.fp8 and w.lm_head.data.dtype == torch.uint8 and not w.embed_tiled
+    toks = torch.randint(0, ocfg.vocab, (37,), generator=torch.Generator().manual_seed(4)).tolist()
+    got = _logits_via_engine(w, toks, [8, 8, 8, 6, 1, 2, 4])
+    lm = OracleLM(ocfg, _fp8_dequantised(ocfg, state), bf16_acts=True)
+    ref = lm.forward(toks, 0, lm.new_cache())
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 0.03 * scale, (got - ref).abs().max().item() / scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() > 0.9
+    # and it is a different model from the bf16 one (the quantisation is really applied)
+    plain = _logits_via_engine(_product(ocfg, state, qkv_bias=(name == "qwen2")), toks, [8, 8, 8, 6, 1, 2, 4])
+    assert (got - plain).abs().max().item() > 1e-3 * scale
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fp8_greedy_spec_equals_ar(use_graph):
+    """The engine invariant holds with fp8 weights on both models (narrow family, 16-token
+    prefill passes), alone and in a batch of 3."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)), fp8=True)
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)), fp8=True)
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 73)), [1, 2, 3]]
+    ar = [_generate(_engine(tw, None, 0, use_graph=use_graph), [p], 40)[0] for p in prompts]
+    for p, want in zip(prompts[:2], ar):
+        assert _generate(_engine(tw, dw, 3, use_graph=use_graph), [p], 40)[0] == want
+    eng = _engine(tw, dw, 3, max_batch=3, use_graph=use_graph)
+    assert not eng.wide
+    assert _generate(eng, prompts, 40) == ar
+    with pytest.raises(ValueError):
+        _engine(tw, dw, 3, rows="wide")
 
 
 def test_chunking_is_bit_invariant():

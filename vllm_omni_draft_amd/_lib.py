@@ -25,7 +25,7 @@ class SdError(RuntimeError):
 class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in (
         "attn_norm_w", "attn_norm_b", "qkv_w", "qkv_b", "o_w", "o_b", "mlp_norm_w", "mlp_norm_b",
-        "up_w", "up_b", "down_w", "down_b")]
+        "up_w", "up_b", "down_w", "down_b", "qkv_s", "o_s", "up_s", "down_s")]
 
 
 class ModelDesc(C.Structure):
@@ -36,6 +36,7 @@ class ModelDesc(C.Structure):
         ("embed", vp), ("embed_tiled", i32), ("pos_table", vp), ("rope_cs", vp), ("final_norm_w", vp),
         ("final_norm_b", vp), ("lm_head", vp), ("layers", C.POINTER(LayerWeights)),
         ("tp_rank", i32), ("allreduce", vp), ("allreduce_ctx", vp),
+        ("weight_fp8", i32), ("lm_head_s", vp),
     ]
 
 
@@ -69,15 +70,16 @@ SIGNATURES = {
     "sd_paged_attention_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
     "sd_paged_attention": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, i32,
                                  i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
-    "sd_linear": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
-    "sd_norm_linear": (i32, [vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
-    "sd_norm_qkv_rope": (i32, [vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,
+    "sd_linear": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "sd_norm_linear": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "sd_norm_qkv_rope": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,
                                i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
     "sd_rmsnorm": (i32, [vp, i64, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_layernorm": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_embed": (i32, [vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "sd_tiled_weight_elems": (C.c_size_t, [i32, i32, i32]),
     "sd_tile_weights": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "sd_tile_weights_fp8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sd_model_create": (vp, [C.POINTER(ModelDesc)]),
     "sd_model_destroy": (None, [vp]),
     "sd_model_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
@@ -91,7 +93,7 @@ SIGNATURES = {
     "sd_linear_wide": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "sd_qkv_rope_wide": (i32, [vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
                                i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
-    "sd_linear_attn_merge": (i32, [vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
+    "sd_linear_attn_merge": (i32, [vp, vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                    vp, vp, vp, i64, i32, i32, vp]),
     "sd_tp_unique_id": (i32, [vp]),
     "sd_tp_comm_create": (vp, [vp, i32, i32]),

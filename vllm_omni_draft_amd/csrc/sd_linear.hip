@@ -58,7 +58,8 @@ struct MergeArgs {
 };
 
 struct LinArgs {
-  const bf16_t* W;         // tiled [n_tiles][K/32][64][8]
+  const bf16_t* W;         // tiled [n_tiles][K/32][64][8] bf16, or [n_tiles][K/64][64][16] fp8
+  const float* w_scale;    // fp8 weights: f32 scale per output row (indexed like bias); else null
   const bf16_t* x;
   int64_t ldx;
   const bf16_t* bias;
@@ -85,7 +86,24 @@ __device__ unsigned long long sd_lin_stamps[16];
 #define LSTAMP(i)
 #endif
 
-template <int EPI, int NORM, bool HALF>
+// Eight e4m3 weights (two 32-bit words) as the bf16 MFMA operand: every e4m3 value is exact in
+// bf16, so the f32 conversion is truncated to its upper half.
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t w0, uint32_t w1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+  auto pack = [](f32x2 v) {
+    return __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+  };
+  const u32x4 r = {pack(a), pack(b), pack(c), pack(d)};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// W8: the weights are e4m3 bytes, two k-steps per 16-byte lane load, dequantised in registers
+// (the layer is bound by the weight stream, so the conversion is free and activations keep
+// bf16); the f32 scale of an output row multiplies its finished sum.
+template <int EPI, int NORM, bool HALF, bool W8>
 __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   LSTAMP(0);
   constexpr bool GATED = EPI == SD_EPI_SILU_MUL;
@@ -118,14 +136,17 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   const bool w_live = !HALF || ((lane >> 3) & 1) == row_half;
 
   // A fragments (and, DIRECT, B fragments) of this wave's next segment
-  bf16x8 nxt[kSeg];
+  constexpr int kWLoads = W8 ? kSeg / 2 : kSeg;   // 16-byte loads per segment
+  constexpr int kWSteps = W8 ? 2 : 1;             // k-steps per load
+  bf16x8 nxt[kWLoads];
   bf16x8 nxt_x[DIRECT ? kSeg : 1];
   auto load_seg = [&](int tile, int seg) {
-    const bf16_t* p = a.W + ((size_t)tile * KS + (size_t)seg * kSeg) * 512 + lane * 8;
+    // 512 bf16 (1 KiB) per wave load either way
+    const bf16_t* p = a.W + ((size_t)tile * (KS / kWSteps) + (size_t)seg * kWLoads) * 512 + lane * 8;
 #pragma unroll
-    for (int j = 0; j < kSeg; ++j) {
+    for (int j = 0; j < kWLoads; ++j) {
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (seg * kSeg + j < KS && w_live)
+      if (seg * kSeg + j * kWSteps < KS && w_live)
         v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + (size_t)j * 512));
       nxt[j] = v;
     }
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     load_seg(tile_of(min(unit, n_units - 1)), wave);  // in flight while x is staged
   } else {
 #pragma unroll
-    for (int j = 0; j < kSeg; ++j) nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < kWLoads; ++j) nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
   LSTAMP(1);
   if (!DIRECT) finish_norm();
@@ -316,6 +337,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int next_unit = unit + (int)gridDim.x;
     float pre0 = 0.f, pre1 = 0.f, pre2 = 0.f, pre3 = 0.f;  // bias / residual / cos, sin
+    float sc0 = 1.f, sc1 = 1.f;                            // W8: scales of the thread's rows
     if (epi_live) {
       if (QKV) {
         if (nl < 8) {
@@ -326,6 +348,10 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
             pre0 = (float)a.bias[head * D + i];
             pre1 = (float)a.bias[head * D + i + half];
           }
+          if (W8) {
+            sc0 = a.w_scale[head * D + i];
+            sc1 = a.w_scale[head * D + i + half];
+          }
           if (q_pos >= 0 && head < rp.Hq + rp.Hkv && rp.cs) {
             const float* cs = rp.cs + (size_t)min(q_pos, rp.max_pos - 1) * D;
             pre2 = cs[i];
@@ -334,23 +360,30 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         }
       } else if (GATED) {
         const int n = tile * 8 + nl;
-        if (nl < 8 && n < a.N && a.bias) {
-          pre0 = (float)a.bias[n];
-          pre1 = (float)a.bias[a.N + n];
+        if (nl < 8 && n < a.N) {
+          if (a.bias) {
+            pre0 = (float)a.bias[n];
+            pre1 = (float)a.bias[a.N + n];
+          }
+          if (W8) {
+            sc0 = a.w_scale[n];
+            sc1 = a.w_scale[a.N + n];
+          }
         }
       } else {
         const int n = tile * 16 + nl;
         if (n < a.N) {
           if (a.bias) pre0 = (float)a.bias[n];
           if (EPI == SD_EPI_RESIDUAL) pre1 = (float)a.residual[(size_t)m * a.ldo + n];
+          if (W8) sc0 = a.w_scale[n];
         }
       }
     }
     // this wave's segments: the j with j % 8 == wave, in increasing order
     for (int seg = wave; seg < n_seg; seg += kLinWaves) {
-      bf16x8 cur[kSeg];
+      bf16x8 cur[kWLoads];
 #pragma unroll
-      for (int j = 0; j < kSeg; ++j) cur[j] = nxt[j];
+      for (int j = 0; j < kWLoads; ++j) cur[j] = nxt[j];
       bf16x8 cur_x[DIRECT ? kSeg : 1];
       if (DIRECT) {
 #pragma unroll
@@ -364,7 +397,15 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         if (seg * kSeg + j < KS) {
           const bf16x8 b = DIRECT ? cur_x[DIRECT ? j : 0]
                                   : *reinterpret_cast<const bf16x8*>(xp + j * 32);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[j], b, acc, 0, 0, 0);
+          bf16x8 w;
+          if constexpr (W8) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 raw = __builtin_bit_cast(u32x4, cur[j >> 1]);
+            w = fp8x8_to_bf16(raw[2 * (j & 1)], raw[2 * (j & 1) + 1]);
+          } else {
+            w = cur[j];
+          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc, 0, 0, 0);
         }
       }
     }
@@ -389,7 +430,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
           const int D = rp.D, half = D / 2;
           const int tiles_per_head = D / 16;
           const int head = tile / tiles_per_head, i = (tile % tiles_per_head) * 8 + nl;
-          float lo = round_bf16(total(tid) + pre0), hi = round_bf16(total(tid + 128) + pre1);
+          float lo = round_bf16(total(tid) * sc0 + pre0), hi = round_bf16(total(tid + 128) * sc1 + pre1);
           if (head < rp.Hq + rp.Hkv && rp.cs) {
             const float nlo = lo * pre2 - hi * pre3, nhi = hi * pre2 + lo * pre3;
             lo = nlo;
@@ -418,14 +459,14 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         // tile rows 0..7 are gate rows 8*tile.., rows 8..15 the matching up rows
         const int n = tile * 8 + nl;
         if (nl < 8 && n < a.N) {
-          float g = total(tid) + pre0, u = total(tid + 128) + pre1;
+          float g = total(tid) * sc0 + pre0, u = total(tid + 128) * sc1 + pre1;
           g = round_bf16(silu_f(round_bf16(g)));
           reinterpret_cast<bf16_t*>(a.out)[(size_t)m * a.ldo + n] = (bf16_t)(g * round_bf16(u));
         }
       } else {
         const int n = tile * 16 + nl;
         if (n < a.N) {
-          const float y = total(tid) + pre0;
+          const float y = total(tid) * sc0 + pre0;
           const size_t o = (size_t)m * a.ldo + n;
           if (EPI == SD_EPI_F32) {
             reinterpret_cast<float*>(a.out)[o] = y;
@@ -464,12 +505,12 @@ int choose_kc(int M, int K, int norm) {
   return whole <= kXBudgetNorm && params <= kRedBytes ? kpad : 0;
 }
 
-template <int EPI, int NORM, bool HALF>
-int launch_half(LinArgs& a, hipStream_t st) {
+template <int EPI, int NORM, bool HALF, bool W8>
+int launch_w(LinArgs& a, hipStream_t st) {
   const size_t lds = lin_lds_bytes(a.M, a.KC, NORM);
   static bool attr_set = false;  // once per instantiation and process
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM, HALF>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM, HALF, W8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       sd_set_error("sd_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -481,10 +522,15 @@ int launch_half(LinArgs& a, hipStream_t st) {
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // 16 waves per CU
   const int n_units = HALF ? 2 * a.n_tiles : a.n_tiles;
   const int blocks = n_units < 256 * per_cu ? n_units : 256 * per_cu;
-  hipLaunchKernelGGL((linear_kernel<EPI, NORM, HALF>), dim3(blocks), dim3(kLinThreads), lds, st,
-                     a);
+  hipLaunchKernelGGL((linear_kernel<EPI, NORM, HALF, W8>), dim3(blocks), dim3(kLinThreads), lds,
+                     st, a);
   SD_CHECK_LAUNCH("sd_linear");
   return SD_OK;
+}
+
+template <int EPI, int NORM, bool HALF>
+int launch_half(LinArgs& a, hipStream_t st) {
+  return a.w_scale ? launch_w<EPI, NORM, HALF, true>(a, st) : launch_w<EPI, NORM, HALF, false>(a, st);
 }
 
 template <int EPI, int NORM>
@@ -535,6 +581,8 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
              "sd_linear: residual epilogue without residual pointer");
   SD_REQUIRE(norm == NORM_NONE || norm == STAGE_ATTN_MERGE || a.norm_w, SD_ERR_INVALID,
              "sd_linear: fused norm without weight");
+  SD_REQUIRE(!a.w_scale || a.K % 64 == 0, SD_ERR_UNSUPPORTED,
+             "sd_linear: fp8 weights need K %% 64 == 0 (K=%d)", a.K);
   if (a.M == 0) return SD_OK;
   a.KC = norm == NORM_NONE ? (a.K + 255) / 256 * 256 : choose_kc(a.M, a.K, norm);
   SD_REQUIRE(a.KC > 0, SD_ERR_UNSUPPORTED,
@@ -575,6 +623,38 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const bf16_t* __restr
     bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (row < rows_src) v = *reinterpret_cast<const bf16x8*>(src + (size_t)row * K + ks * 32 + q * 8);
     *reinterpret_cast<bf16x8*>(dst + i * 8) = v;
+  }
+}
+
+// fp8 form: dst (nt, ks2), lane l, byte 8h + j  <-  src[row(nt, l & 15)][64 ks2 + 32 h + 8 (l >> 4) + j]
+__global__ __launch_bounds__(256) void tile_weights_fp8_kernel(const uint8_t* __restrict__ src,
+                                                               uint8_t* __restrict__ dst, int rows_src,
+                                                               int K, int n_tiles, int mode, int p0) {
+  const int KS2 = K / 64;
+  const size_t total = (size_t)n_tiles * KS2 * 64;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i & 63);
+    const size_t t = i >> 6;
+    const int ks2 = (int)(t % KS2), nt = (int)(t / KS2);
+    const int r = l & 15, q = l >> 4;
+    int row;
+    if (mode == SD_TILE_PLAIN) {
+      row = nt * 16 + r;
+    } else if (mode == SD_TILE_GATED) {
+      const int n = nt * 8 + (r & 7);
+      row = n < p0 ? (r < 8 ? n : p0 + n) : rows_src;
+    } else {
+      const int tph = p0 / 16, head = nt / tph, i0 = (nt % tph) * 8;
+      row = head * p0 + ((r < 8) ? i0 + r : i0 + p0 / 2 + (r - 8));
+    }
+    uint2 lo = {0u, 0u}, hi = {0u, 0u};
+    if (row < rows_src) {
+      const uint8_t* sp = src + (size_t)row * K + ks2 * 64 + q * 8;
+      lo = *reinterpret_cast<const uint2*>(sp);
+      hi = *reinterpret_cast<const uint2*>(sp + 32);
+    }
+    *reinterpret_cast<uint4*>(dst + i * 16) = uint4{lo.x, lo.y, hi.x, hi.y};
   }
 }
 
@@ -710,10 +790,13 @@ extern "C" size_t sd_tiled_weight_elems(int N, int K, int mode) {
   return (size_t)tiles * 16 * K;
 }
 
-extern "C" int sd_tile_weights(const void* src, void* dst, int N, int K, int mode, int param,
-                               sd_stream_t stream) {
+namespace {
+int tile_weights_common(const void* src, void* dst, int N, int K, int mode, int param, bool fp8,
+                        hipStream_t stream) {
   SD_REQUIRE(src && dst && N >= 1 && K >= 32 && K % 32 == 0, SD_ERR_INVALID,
              "sd_tile_weights: bad arguments (N=%d K=%d)", N, K);
+  SD_REQUIRE(!fp8 || K % 64 == 0, SD_ERR_UNSUPPORTED,
+             "sd_tile_weights_fp8: K %% 64 != 0 (K=%d)", K);
   SD_REQUIRE(sd_aligned16(src) && sd_aligned16(dst), SD_ERR_INVALID, "sd_tile_weights: unaligned");
   int tiles, rows_src, p0 = 0;
   if (mode == SD_TILE_PLAIN) {
@@ -733,26 +816,43 @@ extern "C" int sd_tile_weights(const void* src, void* dst, int N, int K, int mod
     sd_set_error("sd_tile_weights: unknown mode %d", mode);
     return SD_ERR_INVALID;
   }
-  hipLaunchKernelGGL(tile_weights_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)src, (bf16_t*)dst, rows_src, K, tiles, mode, p0);
+  if (fp8)
+    hipLaunchKernelGGL(tile_weights_fp8_kernel, dim3(2048), dim3(256), 0, stream,
+                       (const uint8_t*)src, (uint8_t*)dst, rows_src, K, tiles, mode, p0);
+  else
+    hipLaunchKernelGGL(tile_weights_kernel, dim3(2048), dim3(256), 0, stream,
+                       (const bf16_t*)src, (bf16_t*)dst, rows_src, K, tiles, mode, p0);
   SD_CHECK_LAUNCH("sd_tile_weights");
   return SD_OK;
 }
+}  // namespace
 
-extern "C" int sd_linear(const void* W, const void* x, int64_t ldx, const void* bias,
-                         const void* residual, void* out, int64_t ldo, int M, int N, int K,
-                         int epilogue, sd_stream_t stream) {
+extern "C" int sd_tile_weights(const void* src, void* dst, int N, int K, int mode, int param,
+                               sd_stream_t stream) {
+  return tile_weights_common(src, dst, N, K, mode, param, false, (hipStream_t)stream);
+}
+
+extern "C" int sd_tile_weights_fp8(const void* src, void* dst, int N, int K, int mode, int param,
+                                   sd_stream_t stream) {
+  return tile_weights_common(src, dst, N, K, mode, param, true, (hipStream_t)stream);
+}
+
+extern "C" int sd_linear(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                         const void* bias, const void* residual, void* out, int64_t ldo, int M,
+                         int N, int K, int epilogue, sd_stream_t stream) {
   SD_REQUIRE(epilogue >= SD_EPI_STORE && epilogue <= SD_EPI_GELU_TANH, SD_ERR_INVALID,
              "sd_linear: unknown epilogue %d", epilogue);
   SD_REQUIRE(ldo >= N, SD_ERR_INVALID, "sd_linear: ldo < N");
   LinArgs a{};
   a.W = (const bf16_t*)W; a.x = (const bf16_t*)x; a.ldx = ldx; a.bias = (const bf16_t*)bias;
   a.residual = (const bf16_t*)residual; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
+  a.w_scale = w_scale;
   a.n_tiles = tiles_for(N, epilogue);
   return linear_common(a, epilogue, NORM_NONE, (hipStream_t)stream);
 }
 
-extern "C" int sd_linear_attn_merge(const void* W, const void* workspace, size_t workspace_bytes,
+extern "C" int sd_linear_attn_merge(const void* W, const float* w_scale, const void* workspace,
+                                    size_t workspace_bytes,
                                     const int32_t* seq_lens, int pos_offset, int B, int q_len,
                                     int Hq, int Hkv, int D, int max_ctx, int split_tokens,
                                     const void* bias, const void* residual, void* out,
@@ -776,13 +876,15 @@ extern "C" int sd_linear_attn_merge(const void* W, const void* workspace, size_t
   a.W = (const bf16_t*)W; a.x = (const bf16_t*)workspace; a.ldx = (int64_t)Hq * D;
   a.bias = (const bf16_t*)bias; a.residual = (const bf16_t*)residual; a.out = out; a.ldo = ldo;
   a.M = B * q_len; a.N = N; a.K = Hq * D;
+  a.w_scale = w_scale;
   a.n_tiles = tiles_for(N, epilogue);
   a.merge = MergeArgs{(const float*)workspace, (const float*)workspace + rows * D, seq_lens,
                       pos_offset, q_len, G, Hkv, D, n_splits, split_tokens, m_pad};
   return linear_common(a, epilogue, STAGE_ATTN_MERGE, (hipStream_t)stream);
 }
 
-extern "C" int sd_norm_linear(const void* W, const void* x, int64_t ldx, const void* norm_w,
+extern "C" int sd_norm_linear(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                              const void* norm_w,
                               const void* norm_b, float eps, int layer_norm, const void* bias,
                               void* out, int64_t ldo, int M, int N, int K, int epilogue,
                               sd_stream_t stream) {
@@ -793,12 +895,14 @@ extern "C" int sd_norm_linear(const void* W, const void* x, int64_t ldx, const v
   LinArgs a{};
   a.W = (const bf16_t*)W; a.x = (const bf16_t*)x; a.ldx = ldx; a.bias = (const bf16_t*)bias;
   a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
+  a.w_scale = w_scale;
   a.n_tiles = tiles_for(N, epilogue);
   a.norm_w = (const bf16_t*)norm_w; a.norm_b = (const bf16_t*)norm_b; a.eps = eps;
   return linear_common(a, epilogue, layer_norm ? NORM_LAYER : NORM_RMS, (hipStream_t)stream);
 }
 
-extern "C" int sd_norm_qkv_rope(const void* W, const void* x, int64_t ldx, const void* norm_w,
+extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                                const void* norm_w,
                                 const void* norm_b, float eps, int layer_norm, const void* bias,
                                 void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
                                 void* k_cache, void* v_cache, const int32_t* block_tables,
@@ -814,6 +918,7 @@ extern "C" int sd_norm_qkv_rope(const void* W, const void* x, int64_t ldx, const
   LinArgs a{};
   a.W = (const bf16_t*)W; a.x = (const bf16_t*)x; a.ldx = ldx; a.bias = (const bf16_t*)bias;
   a.out = q_out; a.ldo = ldq; a.M = B * q_len; a.N = (Hq + 2 * Hkv) * D; a.K = K;
+  a.w_scale = w_scale;
   a.n_tiles = a.N / 16;
   a.norm_w = (const bf16_t*)norm_w; a.norm_b = (const bf16_t*)norm_b; a.eps = eps;
   a.rope = RopeArgs{rope_cs, max_pos, (bf16_t*)k_cache, (bf16_t*)v_cache, block_tables,

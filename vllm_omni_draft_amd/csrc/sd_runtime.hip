@@ -72,6 +72,12 @@ extern "C" sd_model* sd_model_create(const sd_model_desc* desc) {
                  d.ffn, d.head_dim, d.n_heads, d.n_kv_heads);
     return nullptr;
   }
+  if (d.weight_fp8 ? (!d.lm_head_s || d.hidden % 64 || d.ffn % 64 ||
+                      (d.n_heads * d.head_dim) % 64)
+                   : d.lm_head_s != nullptr) {
+    sd_set_error("sd_model_create: fp8 weights need an LM head scale and H, F, Hq*D multiples of 64");
+    return nullptr;
+  }
   if (d.arch == SD_ARCH_LLAMA && !d.rope_cs) {
     sd_set_error("sd_model_create: llama arch needs a rope table");
     return nullptr;
@@ -88,6 +94,14 @@ extern "C" sd_model* sd_model_create(const sd_model_desc* desc) {
     const sd_layer_weights& l = m->layers[i];
     if (!l.attn_norm_w || !l.qkv_w || !l.o_w || !l.mlp_norm_w || !l.up_w || !l.down_w) {
       sd_set_error("sd_model_create: layer %d has a null weight", i);
+      delete m;
+      return nullptr;
+    }
+    const bool scaled = l.qkv_s && l.o_s && l.up_s && l.down_s;
+    const bool plain = !l.qkv_s && !l.o_s && !l.up_s && !l.down_s;
+    if (d.weight_fp8 ? !scaled : !plain) {
+      sd_set_error("sd_model_create: layer %d: weight scales must be given for fp8 weights and "
+                   "only for them", i);
       delete m;
       return nullptr;
     }
@@ -158,6 +172,8 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const sd_model_desc& d = m->d;
   const int rows = a->B * a->q_len;
   const bool wide = a->wide != 0;
+  SD_REQUIRE(!(wide && d.weight_fp8), SD_ERR_UNSUPPORTED,
+             "sd_model_forward: passes of more than 16 rows are not available for fp8 weights");
   SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= (wide ? 256 : 16), SD_ERR_UNSUPPORTED,
              "sd_model_forward: B*q_len = %d outside 1..%d", rows, wide ? 256 : 16);
   SD_REQUIRE(a->q_len * (d.n_heads / d.n_kv_heads) <= 64 || (wide && a->B == 1), SD_ERR_UNSUPPORTED,
@@ -227,14 +243,14 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     }
     const bool fuse = sd_fused_norm_fits(rows, H, !llama);
     if (fuse) {
-      SD_TRY(sd_norm_qkv_rope(l.qkv_w, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
+      SD_TRY(sd_norm_qkv_rope(l.qkv_w, l.qkv_s, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
                               l.qkv_b, qkv, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos,
                               kc, vc, kv->block_tables, kv->max_blocks_per_seq, a->seq_lens,
                               a->pos_offset, a->B, a->q_len, Hq, Hkv, D, H, stream));
     } else {
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_norm_qkv_rope(l.qkv_w, xn, H, nullptr, nullptr, 0.f, 0, l.qkv_b, qkv,
+      SD_TRY(sd_norm_qkv_rope(l.qkv_w, l.qkv_s, xn, H, nullptr, nullptr, 0.f, 0, l.qkv_b, qkv,
                               (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos, kc, vc,
                               kv->block_tables, kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
                               a->B, a->q_len, Hq, Hkv, D, H, stream));
@@ -254,24 +270,24 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     const bool lead = !d.allreduce || d.tp_rank == 0;
     const int proj_epi = lead ? SD_EPI_RESIDUAL : SD_EPI_STORE;
     if (merge_in_proj) {
-      SD_TRY(sd_linear_attn_merge(l.o_w, attn_ws, w.attn_ws_bytes, a->seq_lens, a->pos_offset,
+      SD_TRY(sd_linear_attn_merge(l.o_w, l.o_s, attn_ws, w.attn_ws_bytes, a->seq_lens, a->pos_offset,
                                   a->B, a->q_len, Hq, Hkv, D, a->max_ctx, a->split_tokens,
                                   lead ? l.o_b : nullptr, h, h, H, H, proj_epi, stream));
     } else {
-      SD_TRY(sd_linear(l.o_w, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
+      SD_TRY(sd_linear(l.o_w, l.o_s, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
                        Hq * D, proj_epi, stream));
     }
     if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
     const int act_epi = llama ? SD_EPI_SILU_MUL : SD_EPI_RELU;
     if (fuse) {
-      SD_TRY(sd_norm_linear(l.up_w, h, H, l.mlp_norm_w, l.mlp_norm_b, d.norm_eps, !llama, l.up_b,
+      SD_TRY(sd_norm_linear(l.up_w, l.up_s, h, H, l.mlp_norm_w, l.mlp_norm_b, d.norm_eps, !llama, l.up_b,
                             act, F, rows, F, H, act_epi, stream));
     } else {
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_linear(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H, act_epi, stream));
+      SD_TRY(sd_linear(l.up_w, l.up_s, xn, H, l.up_b, nullptr, act, F, rows, F, H, act_epi, stream));
     }
-    SD_TRY(sd_linear(l.down_w, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F, proj_epi,
+    SD_TRY(sd_linear(l.down_w, l.down_s, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F, proj_epi,
                      stream));
     if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
   }
@@ -282,12 +298,12 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                           SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
   } else if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {
-      SD_TRY(sd_norm_linear(d.lm_head, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
+      SD_TRY(sd_norm_linear(d.lm_head, d.lm_head_s, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
                             nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, stream));
     } else {
       if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_linear(d.lm_head, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
+      SD_TRY(sd_linear(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
                        SD_EPI_F32, stream));
     }
   }

@@ -91,7 +91,11 @@ class SpecEngine:
         self.max_ctx = cfg.max_seq_len + k + 2
         if cfg.rows not in ("auto", "narrow", "wide"):
             raise ValueError("rows must be 'auto', 'narrow' or 'wide'")
-        self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS)
+        fp8 = bool(getattr(target, "fp8", False) or getattr(draft, "fp8", False))
+        if fp8 and cfg.rows == "wide":
+            raise ValueError("fp8 weights are served by the <= 16-row kernels only (rows='narrow')")
+        self.wide = not fp8 and (cfg.rows == "wide" or
+                                 (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS))
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
                                    wide=self.wide)
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,

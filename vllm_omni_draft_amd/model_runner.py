@@ -33,6 +33,12 @@ class DecoderModel:
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
         self.tp_group = tp_group  # keeps the communicator / callback alive
+        self.cfg: ModelConfig = weights.cfg
+        cfg = self.cfg
+        fp8 = bool(getattr(weights, "fp8", False))
+        if fp8 and wide:
+            raise ValueError("fp8 weights are served by the <= 16-row kernels only (rows='narrow')")
+        wide_prefill = wide_prefill and not fp8
         # wide: every pass of this model goes through the 17..256-row linear kernels (one
         # kernel family per model, because the two round differently)
         self.wide = bool(wide)
@@ -41,8 +47,6 @@ class DecoderModel:
         # tokens per pass): every engine prefills the same way, so streams stay comparable.
         self.prefill_rows = PREFILL_ROWS if (wide or wide_prefill) else min(
             MAX_ROWS, 64 // (cfg.n_heads // cfg.n_kv_heads))
-        self.cfg: ModelConfig = weights.cfg
-        cfg = self.cfg
         if max_ctx > cfg.max_pos:
             raise ValueError(f"max_ctx {max_ctx} exceeds the model's max_pos {cfg.max_pos}")
         self.max_ctx = max_ctx
@@ -51,7 +55,10 @@ class DecoderModel:
         layers = (_lib.LayerWeights * cfg.n_layers)()
         for i, l in enumerate(weights.layers):
             for name, _ in _lib.LayerWeights._fields_:
-                setattr(layers[i], name, _ptr(getattr(l, name)))
+                if name.endswith("_s"):   # scale of the fp8 matrix of the same stem
+                    setattr(layers[i], name, _ptr(getattr(l, name[:-2] + "_w").scale))
+                else:
+                    setattr(layers[i], name, _ptr(getattr(l, name)))
         desc = _lib.ModelDesc(
             arch=0 if cfg.arch == "llama" else 1, n_layers=cfg.n_layers, hidden=cfg.hidden,
             n_heads=cfg.n_heads, n_kv_heads=cfg.n_kv_heads, head_dim=cfg.head_dim, ffn=cfg.ffn,
@@ -63,7 +70,8 @@ class DecoderModel:
             final_norm_b=_ptr(weights.final_norm_b), lm_head=_ptr(weights.lm_head), layers=layers,
             tp_rank=tp_group.rank if tp_group else 0,
             allreduce=tp_group.allreduce_ptr if tp_group else None,
-            allreduce_ctx=tp_group.ctx_ptr if tp_group else None)
+            allreduce_ctx=tp_group.ctx_ptr if tp_group else None,
+            weight_fp8=int(fp8), lm_head_s=_ptr(weights.lm_head.scale))
         self._handle = lib.sd_model_create(C.byref(desc))
         if not self._handle:
             raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")

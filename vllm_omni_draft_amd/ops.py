@@ -236,24 +236,52 @@ TILE_PLAIN, TILE_GATED, TILE_ROTARY = 0, 1, 2
 
 class TiledWeight:
     """A weight matrix re-laid-out for the kernels (see include/sd_amd.h):
-    `data` is the flat tiled bf16 buffer, N the number of OUTPUT columns of the
-    linear (F for a gated [2F, K] matrix), K the input width."""
+    `data` is the flat tiled buffer (bf16, or uint8 holding fp8-e4m3 bytes), N the number of
+    OUTPUT columns of the linear (F for a gated [2F, K] matrix), K the input width; `scale`
+    (fp8 only) is the f32 scale per source row."""
 
-    __slots__ = ("data", "N", "K", "mode")
+    __slots__ = ("data", "N", "K", "mode", "scale")
 
-    def __init__(self, data: torch.Tensor, N: int, K: int, mode: int):
-        self.data, self.N, self.K, self.mode = data, N, K, mode
+    def __init__(self, data: torch.Tensor, N: int, K: int, mode: int,
+                 scale: Optional[torch.Tensor] = None):
+        self.data, self.N, self.K, self.mode, self.scale = data, N, K, mode, scale
 
     def nbytes(self) -> int:
-        return self.data.numel() * 2
+        return self.data.numel() * self.data.element_size() + (
+            0 if self.scale is None else self.scale.numel() * 4)
 
 
-def tile_weights(W: torch.Tensor, mode: int = TILE_PLAIN, head_dim: int = 0) -> TiledWeight:
-    """Row-major [rows, K] bf16 -> TiledWeight (one pass on the GPU, at load time)."""
-    _need(W, torch.bfloat16, "W")
+FP8_MAX = 448.0  # largest finite e4m3 value
+
+
+def quantize_fp8(W: torch.Tensor):
+    """Row-major [rows, K] -> (fp8-e4m3 [rows, K], f32 scale [rows]): per-row absmax scaling,
+    W[r] ~ q[r] * scale[r]."""
+    Wf = W.float()
+    scale = (Wf.abs().amax(dim=1).clamp_min(1e-12) / FP8_MAX).to(torch.float32)
+    q = (Wf / scale[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q.contiguous(), scale.contiguous()
+
+
+def tile_weights(W: torch.Tensor, mode: int = TILE_PLAIN, head_dim: int = 0,
+                 scale: Optional[torch.Tensor] = None) -> TiledWeight:
+    """Row-major [rows, K] bf16 -> TiledWeight (one pass on the GPU, at load time).  An
+    fp8-e4m3 W with its per-row f32 `scale` gives the fp8 tiling."""
     rows, K = W.shape
     N = rows // 2 if mode == TILE_GATED else rows
     lib = _lib.load()
+    if W.dtype == torch.float8_e4m3fn:
+        if scale is None or scale.dtype != torch.float32 or scale.numel() != rows:
+            raise _lib.SdError("tile_weights: fp8 weights need an f32 scale per row")
+        n = int(lib.sd_tiled_weight_elems(N, K, mode)) if K % 64 == 0 else 0
+        if n == 0:
+            raise _lib.SdError(f"tile_weights: unsupported fp8 shape {tuple(W.shape)} (K must be a multiple of 64)")
+        src = W.contiguous().view(torch.uint8)
+        dst = torch.empty(n, dtype=torch.uint8, device=W.device)
+        _lib.check(lib.sd_tile_weights_fp8(_p(src), _p(dst), N, K, mode, head_dim, _stream()),
+                   "sd_tile_weights_fp8")
+        return TiledWeight(dst, N, K, mode, scale.contiguous())
+    _need(W, torch.bfloat16, "W")
     n = int(lib.sd_tiled_weight_elems(N, K, mode))
     if n == 0:
         raise _lib.SdError(f"tile_weights: unsupported shape {tuple(W.shape)} (K must be a multiple of 32)")
@@ -282,7 +310,7 @@ def linear(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None) -> torc
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16,
                           device=x.device)
-    _lib.check(_lib.load().sd_linear(_p(Wt.data), _p(x), K, _p(bias), _p(residual), _p(out), N, M, N,
+    _lib.check(_lib.load().sd_linear(_p(Wt.data), _p(Wt.scale), _p(x), K, _p(bias), _p(residual), _p(out), N, M, N,
                                      K, epilogue, _stream()), "sd_linear")
     return out
 
@@ -311,6 +339,8 @@ def linear_wide(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None,
     """linear() for up to 256 token rows (its own summation order; see sd_linear_wide)."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, epilogue)
+    if Wt.scale is not None:
+        raise _lib.SdError("linear_wide: fp8 weights are served by the <= 16-row kernels only")
     M, K = x.shape
     N = Wt.N
     if out is None:
@@ -330,6 +360,8 @@ def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens,
     """QKV projection + rotary embedding + cache append for up to 256 token rows; returns q."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, EPI_STORE, D)
+    if Wt.scale is not None:
+        raise _lib.SdError("qkv_rope_wide: fp8 weights are served by the <= 16-row kernels only")
     M, K = x.shape
     N = (Hq + 2 * Hkv) * D
     q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=x.device)
@@ -352,7 +384,8 @@ def linear_attn_merge(W, workspace, seq_lens, pos_offset, B, q_len, Hq, Hkv, D, 
     if out is None:
         out = torch.empty(B * q_len, Wt.N, dtype=torch.bfloat16, device=workspace.device)
     _lib.check(_lib.load().sd_linear_attn_merge(
-        _p(Wt.data), _p(workspace), workspace.numel(), _p(seq_lens), pos_offset, B, q_len, Hq, Hkv,
+        _p(Wt.data), _p(Wt.scale), _p(workspace), workspace.numel(), _p(seq_lens), pos_offset, B,
+        q_len, Hq, Hkv,
         D, max_ctx, split_tokens, _p(bias), _p(residual), _p(out), out.stride(0), Wt.N, epilogue,
         _stream()), "sd_linear_attn_merge")
     return out
@@ -441,7 +474,7 @@ def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16,
                           device=x.device)
-    _lib.check(_lib.load().sd_norm_linear(_p(Wt.data), _p(x), K, _p(norm_w), _p(norm_b), float(eps),
+    _lib.check(_lib.load().sd_norm_linear(_p(Wt.data), _p(Wt.scale), _p(x), K, _p(norm_w), _p(norm_b), float(eps),
                                           int(layer_norm), _p(bias), _p(out), N, M, N, K, epilogue,
                                           _stream()), "sd_norm_linear")
     return out
@@ -459,7 +492,8 @@ def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache,
     M, K = x.shape
     q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=x.device)
     _lib.check(_lib.load().sd_norm_qkv_rope(
-        _p(Wt.data), _p(x), K, _p(norm_w), _p(norm_b), float(eps), int(layer_norm), _p(bias), _p(q),
+        _p(Wt.data), _p(Wt.scale), _p(x), K, _p(norm_w), _p(norm_b), float(eps), int(layer_norm),
+        _p(bias), _p(q),
         Hq * D, _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache),
         _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
         _stream()), "sd_norm_qkv_rope")

@@ -1,6 +1,9 @@
 """Device-resident model weights in the layout the kernels stream: bf16,
 q/k/v fused into one matrix and gate/up fused into one, every matrix re-tiled
 once for the 16x16x32 MFMA (ops.tile_weights; layouts in include/sd_amd.h).
+With fp8=True the layer matrices and the LM head are quantised at load to
+fp8-e4m3 with one f32 scale per output row (weight-only: activations, norms,
+biases and the embedding table stay bf16).
 
 Sources: a Hugging Face style state dict (names as in transformers), a local
 directory of *.safetensors shards, or seeded random initialisation.  The
@@ -47,6 +50,7 @@ class ModelWeights:
     pos_table: Optional[torch.Tensor] = None
     final_norm_b: Optional[torch.Tensor] = None
     rope_cs: Optional[torch.Tensor] = None
+    fp8: bool = False
 
     def nbytes(self) -> int:
         seen, total = set(), 0
@@ -57,34 +61,52 @@ class ModelWeights:
         return total
 
     def tensors(self):
+        def parts(t):
+            if isinstance(t, ops.TiledWeight):
+                yield t.data
+                if t.scale is not None:
+                    yield t.scale
+            elif t is not None:
+                yield t
+
         for t in (self.embed, self.final_norm_w, self.lm_head, self.pos_table, self.final_norm_b):
-            if t is not None:
-                yield t.data if isinstance(t, ops.TiledWeight) else t
+            yield from parts(t)
         for l in self.layers:
             for t in vars(l).values():
-                if t is not None:
-                    yield t.data if isinstance(t, ops.TiledWeight) else t
+                yield from parts(t)
 
 
 def _dev(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.bfloat16).contiguous()
 
 
-def _tile(w: torch.Tensor, mode: int = ops.TILE_PLAIN, head_dim: int = 0) -> "ops.TiledWeight":
+def _tile_matrix(w: torch.Tensor, mode: int = ops.TILE_PLAIN, head_dim: int = 0,
+                 fp8: bool = False) -> "ops.TiledWeight":
+    if fp8:
+        q, scale = ops.quantize_fp8(w)
+        return ops.tile_weights(q, mode, head_dim, scale=scale)
     return ops.tile_weights(w, mode, head_dim)
 
 
-def _embed_and_head(embed: torch.Tensor, head, device):
+def _embed_and_head(embed: torch.Tensor, head, device, fp8: bool = False):
     """Untied: row-major embedding + tiled head.  Tied: ONE tiled buffer serves
-    both (the embedding gather reads rows out of the tiled layout)."""
+    both (the embedding gather reads rows out of the tiled layout); with fp8 the
+    head is a quantised copy and the embedding table stays row-major bf16."""
     if head is None:
-        t = _tile(embed)
+        if fp8:
+            return embed, _tile_matrix(embed, fp8=True), False
+        t = _tile_matrix(embed)
         return t.data, t, True
-    return embed, _tile(_dev(head, device)), False
+    return embed, _tile_matrix(_dev(head, device), fp8=fp8), False
 
 
-def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cuda") -> ModelWeights:
+def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cuda",
+                    fp8: bool = False) -> ModelWeights:
     cfg.validate()
+
+    def _tile(w, mode=ops.TILE_PLAIN, head_dim=0):  # every layer matrix alike
+        return _tile_matrix(w, mode, head_dim, fp8=fp8)
+
     g = lambda n: state[n]
     opt = lambda n: state.get(n)
     layers = []
@@ -107,8 +129,8 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
                 up_w=_tile(_dev(up_w, device), ops.TILE_GATED),
                 down_w=_tile(_dev(g(lp + "mlp.down_proj.weight"), device))))
         embed, lm_head, tied = _embed_and_head(_dev(g(pre + "embed_tokens.weight"), device),
-                                               opt("lm_head.weight"), device)
-        return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied,
+                                               opt("lm_head.weight"), device, fp8)
+        return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, fp8=fp8,
                             final_norm_w=_dev(g(pre + "norm.weight"), device), lm_head=lm_head,
                             layers=layers, rope_cs=rope_table(cfg, device))
     pre = "model.decoder."
@@ -127,8 +149,8 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
             up_w=_tile(_dev(g(lp + "fc1.weight"), device)), up_b=_dev(g(lp + "fc1.bias"), device),
             down_w=_tile(_dev(g(lp + "fc2.weight"), device)), down_b=_dev(g(lp + "fc2.bias"), device)))
     embed, lm_head, tied = _embed_and_head(_dev(g(pre + "embed_tokens.weight"), device),
-                                           opt("lm_head.weight"), device)
-    return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied,
+                                           opt("lm_head.weight"), device, fp8)
+    return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, fp8=fp8,
                         pos_table=_dev(g(pre + "embed_positions.weight"), device),
                         final_norm_w=_dev(g(pre + "final_layer_norm.weight"), device),
                         final_norm_b=_dev(g(pre + "final_layer_norm.bias"), device),
@@ -167,11 +189,15 @@ def shard_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], tp_size: 
     return local, out
 
 
-def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02) -> ModelWeights:
+def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02,
+                fp8: bool = False) -> ModelWeights:
     """Seeded random weights generated directly on the device in the fused
     layout (no host copy: an 8B model is 16 GB)."""
     cfg.validate()
     gen = torch.Generator(device=device).manual_seed(seed)
+
+    def _tile(w, mode=ops.TILE_PLAIN, head_dim=0):
+        return _tile_matrix(w, mode, head_dim, fp8=fp8)
 
     def rn(*shape, s=std):
         return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s
@@ -198,9 +224,9 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
                 down_w=_tile(rn(H, F)), down_b=rn(H)))
     embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5)
     embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(cfg.vocab, H),
-                                           device)
+                                           device, fp8)
     w = ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, final_norm_w=ones(H), lm_head=lm_head,
-                     layers=layers)
+                     layers=layers, fp8=fp8)
     if cfg.arch == "llama":
         w.rope_cs = rope_table(cfg, device)
     else:
@@ -209,7 +235,8 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
     return w
 
 
-def from_safetensors_dir(cfg: ModelConfig, model_dir: str, device="cuda") -> ModelWeights:
+def from_safetensors_dir(cfg: ModelConfig, model_dir: str, device="cuda",
+                         fp8: bool = False) -> ModelWeights:
     """Loads every *.safetensors shard of a local Hugging Face checkpoint."""
     from safetensors import safe_open
 
@@ -223,4 +250,4 @@ def from_safetensors_dir(cfg: ModelConfig, model_dir: str, device="cuda") -> Mod
                 state[key] = f.get_tensor(key)
     if cfg.arch == "opt" and "decoder.embed_tokens.weight" in state:
         state = {"model." + k if k.startswith("decoder.") else k: v for k, v in state.items()}
-    return from_state_dict(cfg, state, device)
+    return from_state_dict(cfg, state, device, fp8=fp8)
