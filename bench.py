@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--draft", default="llama-3.2-1b")
     ap.add_argument("--split-tokens", type=int, default=256)
     ap.add_argument("--draft-split-tokens", type=int, default=0)
+    ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: both models' matrices quantised at load (e4m3, per-row scales), "
+                         "bf16 activations; an extra data point, the headline is bf16")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -74,15 +77,23 @@ def parse():
     return ap.parse_args()
 
 
-def load_weights(name, seed, device, layers=0):
+def load_weights(name, seed, device, layers=0, fp8=False):
     from vllm_omni_draft_amd import config, weights
     root = os.environ.get("SD_MODEL_ROOT", "")
     path = os.path.join(root, name) if root else ""
     if path and os.path.isdir(path):
         cfg = config.load_hf_config(path)
-        return weights.from_safetensors_dir(cfg, path, device), "local safetensors"
+        return weights.from_safetensors_dir(cfg, path, device, fp8=fp8), "local safetensors"
     cfg = config.preset(name, **({"n_layers": layers} if layers else {}))
-    return weights.random_init(cfg, seed=seed, device=device), "seeded random init"
+    return weights.random_init(cfg, seed=seed, device=device, fp8=fp8), "seeded random init"
+
+
+def streamed_weight_bytes(w):
+    """Bytes of weight matrices (and fp8 scales) one forward pass of the model streams."""
+    n = w.lm_head.nbytes()
+    for l in w.layers:
+        n += l.qkv_w.nbytes() + l.o_w.nbytes() + l.up_w.nbytes() + l.down_w.nbytes()
+    return n
 
 
 def run_generation(eng, prompt, n_steps, warmup, dist_barrier):
@@ -107,13 +118,16 @@ def run_generation(eng, prompt, n_steps, warmup, dist_barrier):
     return out, len(out) - n0, dt, prefill_s
 
 
-def step_bytes(tcfg, dcfg, k, ctx):
-    """Algorithmic HBM bytes of one speculative step at context length ctx."""
+def step_bytes(tcfg, dcfg, k, ctx, t_weight_bytes=None, d_weight_bytes=None):
+    """Algorithmic HBM bytes of one speculative step at context length ctx (weight bytes
+    default to the bf16 sizes of the configurations)."""
     V = tcfg.vocab
     kv_t = tcfg.kv_bytes_per_token() * ctx
     kv_d = dcfg.kv_bytes_per_token() * ctx * k
     logits = (k + 1) * V * 4 * 2 + k * V * 4 * 2  # written once, read once by argmax
-    return tcfg.param_bytes() + k * dcfg.param_bytes() + kv_t + kv_d + logits
+    wt = tcfg.param_bytes() if t_weight_bytes is None else t_weight_bytes
+    wd = dcfg.param_bytes() if d_weight_bytes is None else d_weight_bytes
+    return wt + k * wd + kv_t + kv_d + logits
 
 
 def kernel_roofline(eng, tw, rows, reps=3):
@@ -143,10 +157,11 @@ def kernel_roofline(eng, tw, rows, reps=3):
     bytes_per_launch = w.nbytes() + x.numel() * 2 + out.numel() * 2
     gbs = bytes_per_launch / us * 1e-3
     n_rows = 2 * w.N if cfg.arch == "llama" else w.N
-    return {"kernel": f"linear_kernel<norm+gate_up+silu_mul>, M={rows} [{n_rows}x{w.K}] bf16",
+    wdt = "bf16" if w.scale is None else "fp8"
+    return {"kernel": f"linear_kernel<norm+gate_up+silu_mul>, M={rows} [{n_rows}x{w.K}] {wdt}",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("linear_kernel<2, 1, false>") if rows == 6 else None,
+            "traffic": pmc_traffic("linear_kernel<2, 1, false>") if rows == 6 and w.scale is None else None,
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
@@ -277,8 +292,9 @@ def main():
     from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
 
     k = args.k
-    tw, data_kind = load_weights(args.target, 1, device, args.layers)
-    dw, _ = load_weights(args.draft, 2, device, args.layers)
+    fp8 = args.weights == "fp8"
+    tw, data_kind = load_weights(args.target, 1, device, args.layers, fp8)
+    dw, _ = load_weights(args.draft, 2, device, args.layers, fp8)
     g = torch.Generator().manual_seed(1234 + rank)
     prompt = torch.randint(0, min(tw.cfg.vocab, dw.cfg.vocab), (args.prompt_len,), generator=g).tolist()
     total_steps = args.warmup + args.steps
@@ -336,7 +352,8 @@ def main():
     value = tokens / dt
     ms_per_step = dt / args.steps * 1e3
     ctx_mid = args.prompt_len + (args.warmup + args.steps / 2) * main_res["emitted_per_step"]
-    sb = step_bytes(tw.cfg, dw.cfg, k, ctx_mid)
+    sb = step_bytes(tw.cfg, dw.cfg, k, ctx_mid,
+                    *((streamed_weight_bytes(tw), streamed_weight_bytes(dw)) if fp8 else ()))
     roof = kernel_roofline(eng, tw, k + 1)
     attn = attention_roofline(device, k)
     sweep = []
@@ -362,7 +379,8 @@ def main():
         "metric": "output tokens/sec (+ accept-len), Llama-3-8B + Llama-3.2-1B draft, k=5, greedy",
         "value": round(value, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8 weights (e4m3, per-row scales), bf16 activations, f32 accumulation" if fp8 else "bf16",
         "data": f"synthetic ({data_kind}; random-token prompt; draft proposals replaced by the "
                 f"target's own greedy token with probability {args.accept_prob})",
         "config": {"workload": f"{args.target} target + {args.draft} draft, k={k}, batch 1 per GPU, "
