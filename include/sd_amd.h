@@ -393,6 +393,12 @@ typedef struct {
    * (forward args.wide) are not available for fp8 weights.                   */
   int weight_fp8;
   const float* lm_head_s;
+  /* Vocabulary-parallel LM head under tensor parallelism: lm_head holds lm_vocab
+   * rows (this rank's slice of the vocabulary) and logits are [rows, lm_vocab];
+   * 0 = the whole vocabulary.  The ranks' slice maxima are exchanged with
+   * sd_tp_allgather and merged by sd_argmax_combine (greedy), instead of
+   * gathering logits.                                                       */
+  int lm_vocab;
 } sd_model_desc;
 
 typedef struct sd_model sd_model;
@@ -445,6 +451,11 @@ sd_tp_comm* sd_tp_comm_create(const void* id, int rank, int world_size);
 void sd_tp_comm_destroy(sd_tp_comm* comm);
 /* An sd_allreduce_fn: ctx is the sd_tp_comm*.                                */
 int sd_tp_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream);
+/* recv[r * bytes_per_rank ...] = rank r's send buffer, on every rank (the
+ * exchange of the vocabulary-parallel head: slice maxima, or logits when a
+ * full row is needed for sampling).                                          */
+int sd_tp_allgather(const void* send, void* recv, size_t bytes_per_rank, void* ctx,
+                    sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Speculative step glue that must stay on the device (replaces the tensor
@@ -500,6 +511,21 @@ int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32_t* tok_buf
 #define SD_ARGMAX_PARTS 64
 int sd_argmax_partial(const float* logits, int64_t ld, float* part_val,
                       int32_t* part_idx, int R, int V, sd_stream_t stream);
+/* Distributed argmax of a vocabulary-parallel head.  part_val / part_idx hold
+ * n_ranks blocks of [R, SD_ARGMAX_PARTS] slice maxima (sd_argmax_partial run on
+ * each rank's [R, shard_vocab] logits, indices local to the shard, blocks in rank
+ * order as sd_tp_allgather leaves them, rank_stride elements apart: values and
+ * indices may be packed into one gathered buffer); out_* receive [R, SD_ARGMAX_PARTS]
+ * maxima over the whole vocabulary with global indices (ties: lowest index),
+ * which sd_verify_from_partials / sd_propose_from_partials /
+ * sd_argmax_from_partials finish as usual.                                   */
+int sd_argmax_combine(const float* part_val, const int32_t* part_idx, int n_ranks,
+                      int R, int shard_vocab, int64_t rank_stride, float* out_val,
+                      int32_t* out_idx, sd_stream_t stream);
+/* ids[r] = first argmax of row r from its slice maxima.                      */
+int sd_argmax_from_partials(const float* part_val, const int32_t* part_idx,
+                            int64_t* ids, int R, sd_stream_t stream);
+
 int sd_propose_from_partials(const float* part_val, const int32_t* part_idx,
                              int row_offset, int row_step, int32_t* tok_buf,
                              int k, int step, const int32_t* seq_lens,

@@ -49,6 +49,21 @@ class _TwoRankSum:
                 return -1
         return fn
 
+    def make_gather(self, rank):
+        """All-gather of the two virtual ranks (same stream, same barrier discipline)."""
+        def fn(send, recv):
+            try:
+                self.slots[rank] = send
+                self.barrier.wait(timeout=60)
+                both = torch.cat([self.slots[0].reshape(-1).view(torch.uint8),
+                                  self.slots[1].reshape(-1).view(torch.uint8)])
+                self.barrier.wait(timeout=60)
+                recv.reshape(-1).view(torch.uint8).copy_(both)
+            except Exception as e:  # noqa: BLE001
+                self.error = e
+                raise
+        return fn
+
 
 @pytest.mark.parametrize("arch", ["llama", "opt"])
 def test_two_rank_forward_matches_single_gpu(arch):
@@ -113,12 +128,111 @@ def test_two_rank_forward_matches_single_gpu(arch):
     assert (ranks[0][2].argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.8
 
 
+def test_distributed_argmax_equals_argmax_of_the_whole_row():
+    """Slice maxima of vocabulary shards, gathered and combined, finish to the first argmax of
+    the whole row (ties to the lowest global index, also across shard borders)."""
+    from vllm_omni_draft_amd import ops
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    for n_ranks, V, R in ((2, 512, 3), (4, 50304, 6), (8, 128256, 6)):
+        Vl = V // n_ranks
+        assert Vl % 16 == 0 and Vl * n_ranks == V
+        logits = torch.randn(R, V, generator=gen, device="cuda")
+        logits[0, 5] = logits[0, Vl + 3] = 50.0            # tie across two shards: index 5 wins
+        logits[1, V - 1] = 60.0                             # maximum in the last shard
+        if R > 2:
+            logits[2, Vl - 1] = logits[2, Vl] = 70.0        # tie at a shard border
+        n = R * ops.ARGMAX_PARTS
+        blocks = []
+        for r in range(n_ranks):
+            send = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+            ops.argmax_partial(logits[:, r * Vl:(r + 1) * Vl].contiguous(), send[:n].view(R, -1),
+                               send[n:].view(torch.int32).view(R, -1))
+            blocks.append(send)
+        pv = torch.empty(R, ops.ARGMAX_PARTS, dtype=torch.float32, device="cuda")
+        pi = torch.empty(R, ops.ARGMAX_PARTS, dtype=torch.int32, device="cuda")
+        ops.argmax_combine(torch.cat(blocks), n_ranks, R, Vl, pv, pi)
+        got = ops.argmax_from_partials(pv, pi, R)
+        want = ops.argmax_rows(logits)
+        assert torch.equal(got, want)
+        assert got[0].item() == 5 and got[1].item() == V - 1
+        if R > 2:
+            assert got[2].item() == Vl - 1
+
+
+@pytest.mark.parametrize("temperature", [0.0, 1.0])
+def test_two_rank_engine_with_vocabulary_parallel_head(temperature):
+    """Two virtual ranks (threads, one stream, host callbacks as collectives) run whole
+    engines on sharded targets.  The vocabulary-parallel head (slice maxima exchanged, or rows
+    gathered for sampling) must give the stream of the replicated head, rank for rank; greedy
+    speculative decoding must equal greedy autoregressive decoding under the same sharding."""
+    from vllm_omni_draft_amd import parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=256, n_heads=4, n_kv_heads=2, head_dim=64,
+                      ffn=512, vocab=512, max_pos=256, tie_embeddings=True)
+    dc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64,
+                      ffn=256, vocab=512, max_pos=256)
+    state = {k: v.to(torch.bfloat16) for k, v in random_state(oc, seed=7).items()}
+    cfg = _cfg_of(oc)
+    dw = weights.from_state_dict(_cfg_of(dc), {k: v.to(torch.bfloat16) for k, v in
+                                               random_state(dc, seed=8).items()}, "cuda")
+    stream = torch.cuda.Stream()
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 60))]
+
+    def run(vocab_parallel, k):
+        coll = _TwoRankSum()
+        engines = []
+        for r in range(2):
+            local, st = weights.shard_state_dict(cfg, state, 2, r, vocab_parallel=vocab_parallel)
+            assert local.head_rows == (256 if vocab_parallel else 512)
+            tw = weights.from_state_dict(local, st, "cuda")
+            group = parallel.CallbackAllReduce(r, coll.make(r), world_size=2,
+                                               gather=coll.make_gather(r))
+            eng = SpecEngine(tw, dw if k else None, EngineConfig(
+                k=k, max_batch=2, max_seq_len=120, split_tokens=128, use_graph=False,
+                temperature=temperature, seed=11), tp_group=group)
+            eng.stream = stream
+            coll.models[r] = eng.target
+            engines.append(eng)
+        torch.cuda.synchronize()
+        outs = [None, None]
+
+        def worker(r):
+            eng = engines[r]
+            toks = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+            while min(len(t) for t in toks) < 24:
+                for t, new in zip(toks, eng.step()):
+                    t.extend(new)
+            outs[r] = [t[:24] for t in toks]
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+            assert not t.is_alive()
+        torch.cuda.synchronize()
+        assert coll.error is None, coll.error
+        assert outs[0] == outs[1]          # the ranks agree without exchanging decisions
+        return outs[0], engines[0].metrics()
+
+    spec_vp, m = run(True, 3)
+    spec_rep, _ = run(False, 3)
+    assert spec_vp == spec_rep
+    assert m["draft"] > 0 and m["emitted"] >= 24
+    if temperature == 0.0:
+        ar_vp, _ = run(True, 0)
+        assert spec_vp == ar_vp
+
+
 def test_rccl_group_of_one():
     from vllm_omni_draft_amd import parallel
     g = parallel.TensorParallelGroup(0, 1)
     x = torch.randn(5, 1000, device="cuda").to(torch.bfloat16)
     y = x.clone()
     g.all_reduce(y)
+    send = torch.arange(300, dtype=torch.float32, device="cuda")
+    recv = torch.zeros_like(send)
+    g.all_gather(send, recv)
     torch.cuda.synchronize()
-    assert torch.equal(x, y)
+    assert torch.equal(x, y) and torch.equal(send, recv)
     g.close()

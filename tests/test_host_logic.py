@@ -204,6 +204,18 @@ def test_tensor_parallel_shards_reproduce_the_layer_math(arch):
     assert all(torch.equal(st[emb], state[emb]) for _, st in shards)
     with pytest.raises(ValueError):
         cfg.tp_shard(3)
+    # vocabulary-parallel head: the ranks' slices are the rows of the head (the tied embedding
+    # when the checkpoint has no separate head), the embedding table stays whole
+    head = state.get("lm_head.weight", state[emb])
+    vshards = [weights.shard_state_dict(cfg, state, tp, r, vocab_parallel=True) for r in range(tp)]
+    assert all(local.lm_vocab == 32 and local.head_rows == 32 and local.vocab == 64
+               for local, _ in vshards)
+    assert torch.equal(torch.cat([st["lm_head.weight"] for _, st in vshards]), head)
+    assert all(torch.equal(st[emb], state[emb]) for _, st in vshards)
+    assert shards[0][0].lm_vocab == 0 and shards[0][0].head_rows == 64
+    with pytest.raises(ValueError):
+        # 48 rows do not split into 2 slices of whole 16-row tiles
+        config.create_model_config(cfg, vocab=48).tp_shard(2, vocab_parallel=True)
 
 
 def test_prompt_lookup_matches_longest_most_recent_ngram():

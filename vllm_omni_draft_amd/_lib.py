@@ -36,7 +36,7 @@ class ModelDesc(C.Structure):
         ("embed", vp), ("embed_tiled", i32), ("pos_table", vp), ("rope_cs", vp), ("final_norm_w", vp),
         ("final_norm_b", vp), ("lm_head", vp), ("layers", C.POINTER(LayerWeights)),
         ("tp_rank", i32), ("allreduce", vp), ("allreduce_ctx", vp),
-        ("weight_fp8", i32), ("lm_head_s", vp),
+        ("weight_fp8", i32), ("lm_head_s", vp), ("lm_vocab", i32),
     ]
 
 
@@ -79,6 +79,9 @@ SIGNATURES = {
     "sd_embed": (i32, [vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "sd_tiled_weight_elems": (C.c_size_t, [i32, i32, i32]),
     "sd_tile_weights": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "sd_argmax_combine": (i32, [vp, vp, i32, i32, i32, i64, vp, vp, vp]),
+    "sd_argmax_from_partials": (i32, [vp, vp, vp, i32, vp]),
+    "sd_tp_allgather": (i32, [vp, vp, C.c_size_t, vp, vp]),
     "sd_tile_weights_fp8": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "sd_model_create": (vp, [C.POINTER(ModelDesc)]),
     "sd_model_destroy": (None, [vp]),

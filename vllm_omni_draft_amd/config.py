@@ -34,6 +34,9 @@ class ModelConfig:
     qkv_bias: bool = False
     pos_bias: int = 2              # OPT learned-position offset
     name: str = "custom"
+    # Vocabulary-parallel LM head (tensor parallelism): rows of the head one rank holds;
+    # 0 = the whole vocabulary.  The embedding table is never split.
+    lm_vocab: int = 0
 
     def validate(self) -> None:
         if self.arch not in ("llama", "opt"):
@@ -60,9 +63,18 @@ class ModelConfig:
     def kv_bytes_per_token(self) -> int:
         return 2 * self.n_layers * self.n_kv_heads * self.head_dim * 2
 
-    def tp_shard(self, tp_size: int) -> "ModelConfig":
+    @property
+    def head_rows(self) -> int:
+        """Rows of the LM head (= columns of the logits) this model instance computes."""
+        return self.lm_vocab or self.vocab
+
+    def tp_shard(self, tp_size: int, vocab_parallel: bool = False) -> "ModelConfig":
         """The per-rank view under tensor parallelism: heads and ffn columns divided,
-        hidden size, vocabulary and layer count unchanged."""
+        hidden size, vocabulary and layer count unchanged; with vocab_parallel the LM head
+        is cut into tp_size row slices (each a multiple of 16 rows)."""
+        if vocab_parallel and self.vocab % (16 * tp_size):
+            raise ValueError(f"vocab {self.vocab} must be a multiple of 16 * tp_size for a "
+                             "vocabulary-parallel head")
         if tp_size < 1 or self.n_heads % tp_size or self.n_kv_heads % tp_size:
             raise ValueError(f"tp_size {tp_size} must divide n_heads={self.n_heads} and "
                              f"n_kv_heads={self.n_kv_heads}")
@@ -70,7 +82,8 @@ class ModelConfig:
             raise ValueError(f"ffn {self.ffn} must be a multiple of 32 * tp_size")
         return dataclasses.replace(self, n_heads=self.n_heads // tp_size,
                                    n_kv_heads=self.n_kv_heads // tp_size,
-                                   ffn=self.ffn // tp_size, name=f"{self.name}/tp{tp_size}")
+                                   ffn=self.ffn // tp_size, name=f"{self.name}/tp{tp_size}",
+                                   lm_vocab=self.vocab // tp_size if vocab_parallel else 0)
 
 
 def create_model_config(base: Optional[ModelConfig] = None, **overrides) -> ModelConfig:

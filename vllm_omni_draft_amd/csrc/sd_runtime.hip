@@ -78,6 +78,10 @@ extern "C" sd_model* sd_model_create(const sd_model_desc* desc) {
     sd_set_error("sd_model_create: fp8 weights need an LM head scale and H, F, Hq*D multiples of 64");
     return nullptr;
   }
+  if (d.lm_vocab < 0 || d.lm_vocab % 16 || d.lm_vocab > d.vocab) {
+    sd_set_error("sd_model_create: lm_vocab %d must be 0 or a multiple of 16 up to vocab", d.lm_vocab);
+    return nullptr;
+  }
   if (d.arch == SD_ARCH_LLAMA && !d.rope_cs) {
     sd_set_error("sd_model_create: llama arch needs a rope table");
     return nullptr;
@@ -144,7 +148,7 @@ Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int spli
         sd_linear_wide_workspace_bytes(rows, H, QD, SD_EPI_RESIDUAL),
         sd_linear_wide_workspace_bytes(rows, F, H, up_epi),
         sd_linear_wide_workspace_bytes(rows, H, F, SD_EPI_RESIDUAL),
-        sd_linear_wide_workspace_bytes(rows, d.vocab, H, SD_EPI_F32)};
+        sd_linear_wide_workspace_bytes(rows, d.lm_vocab > 0 ? d.lm_vocab : d.vocab, H, SD_EPI_F32)};
     for (size_t n : need) w.wide_ws_bytes = n > w.wide_ws_bytes ? n : w.wide_ws_bytes;
   }
   w.wide_ws = off; off += align256(w.wide_ws_bytes);
@@ -291,19 +295,20 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                      stream));
     if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
   }
+  const int lm_vocab = d.lm_vocab > 0 ? d.lm_vocab : d.vocab;
   if (a->logits && wide) {
     if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
     else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
-    SD_TRY(sd_linear_wide(d.lm_head, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
+    SD_TRY(sd_linear_wide(d.lm_head, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
                           SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
   } else if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {
       SD_TRY(sd_norm_linear(d.lm_head, d.lm_head_s, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
-                            nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, stream));
+                            nullptr, a->logits, lm_vocab, rows, lm_vocab, H, SD_EPI_F32, stream));
     } else {
       if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_linear(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, d.vocab, rows, d.vocab, H,
+      SD_TRY(sd_linear(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
                        SD_EPI_F32, stream));
     }
   }
@@ -398,6 +403,16 @@ extern "C" void sd_tp_comm_destroy(sd_tp_comm* c) {
   if (!c) return;
   ncclCommDestroy(c->comm);
   delete c;
+}
+
+extern "C" int sd_tp_allgather(const void* send, void* recv, size_t bytes_per_rank, void* ctx,
+                               sd_stream_t stream) {
+  SD_REQUIRE(send && recv && ctx, SD_ERR_INVALID, "sd_tp_allgather: null pointer");
+  sd_tp_comm* c = static_cast<sd_tp_comm*>(ctx);
+  const ncclResult_t r = ncclAllGather(send, recv, bytes_per_rank, ncclChar, c->comm,
+                                       (hipStream_t)stream);
+  SD_REQUIRE(r == ncclSuccess, SD_ERR_HIP, "sd_tp_allgather: %s", ncclGetErrorString(r));
+  return SD_OK;
 }
 
 extern "C" int sd_tp_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream) {

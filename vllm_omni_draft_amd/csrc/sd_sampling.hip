@@ -804,6 +804,34 @@ __device__ __forceinline__ int wave_argmax_finish(const float* __restrict__ part
   return bi == 0x7fffffff ? 0 : bi;
 }
 
+// Slice maxima of n_ranks vocabulary shards (each rank's indices local to its shard) -> slice
+// maxima over the whole vocabulary: slot (row, part) keeps the largest value, ties to the lowest
+// global index, so a finish over the combined slots is the first argmax of the full row.
+__global__ __launch_bounds__(256) void argmax_combine_kernel(
+    const float* __restrict__ vals, const int32_t* __restrict__ idx, int n_ranks, int n,
+    int shard_vocab, int64_t rank_stride, float* __restrict__ out_val,
+    int32_t* __restrict__ out_idx) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int r = 0; r < n_ranks; ++r) {
+    const float v = vals[(size_t)r * rank_stride + i];
+    int id = idx[(size_t)r * rank_stride + i];
+    if (id != 0x7fffffff) id += r * shard_vocab;
+    if (v > best || (v == best && id < bi)) { best = v; bi = id; }
+  }
+  out_val[i] = best;
+  out_idx[i] = bi;
+}
+
+__global__ __launch_bounds__(SD_WAVE) void argmax_from_partials_kernel(
+    const float* __restrict__ part_val, const int32_t* __restrict__ part_idx,
+    int64_t* __restrict__ ids) {
+  const int id = wave_argmax_finish(part_val, part_idx, blockIdx.x, threadIdx.x);
+  if (threadIdx.x == 0) ids[blockIdx.x] = id;
+}
+
 __global__ __launch_bounds__(SD_WAVE) void propose_from_partials_kernel(
     const float* __restrict__ part_val, const int32_t* __restrict__ part_idx, int row_offset,
     int row_step, int32_t* __restrict__ tok_buf, int k, int step,
@@ -1100,6 +1128,34 @@ extern "C" int sd_argmax_partial(const float* logits, int64_t ld, float* part_va
   hipLaunchKernelGGL(argmax_partial_kernel, dim3(kArgmaxParts, R), dim3(256), 0,
                      (hipStream_t)stream, logits, ld, part_val, part_idx, V);
   SD_CHECK_LAUNCH("sd_argmax_partial");
+  return SD_OK;
+}
+
+extern "C" int sd_argmax_combine(const float* part_val, const int32_t* part_idx, int n_ranks,
+                                 int R, int shard_vocab, int64_t rank_stride, float* out_val,
+                                 int32_t* out_idx, sd_stream_t stream) {
+  SD_REQUIRE(part_val && part_idx && out_val && out_idx, SD_ERR_INVALID,
+             "sd_argmax_combine: null pointer");
+  SD_REQUIRE(n_ranks >= 1 && R >= 0 && shard_vocab >= 1 &&
+                 rank_stride >= (int64_t)R * kArgmaxParts, SD_ERR_INVALID,
+             "sd_argmax_combine: bad arguments (ranks=%d R=%d shard=%d)", n_ranks, R, shard_vocab);
+  if (R == 0) return SD_OK;
+  const int n = R * kArgmaxParts;
+  hipLaunchKernelGGL(argmax_combine_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, part_val, part_idx, n_ranks, n, shard_vocab,
+                     rank_stride, out_val, out_idx);
+  SD_CHECK_LAUNCH("sd_argmax_combine");
+  return SD_OK;
+}
+
+extern "C" int sd_argmax_from_partials(const float* part_val, const int32_t* part_idx,
+                                       int64_t* ids, int R, sd_stream_t stream) {
+  SD_REQUIRE(part_val && part_idx && ids && R >= 0, SD_ERR_INVALID,
+             "sd_argmax_from_partials: bad arguments");
+  if (R == 0) return SD_OK;
+  hipLaunchKernelGGL(argmax_from_partials_kernel, dim3(R), dim3(SD_WAVE), 0, (hipStream_t)stream,
+                     part_val, part_idx, ids);
+  SD_CHECK_LAUNCH("sd_argmax_from_partials");
   return SD_OK;
 }
 

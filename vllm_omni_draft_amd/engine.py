@@ -131,6 +131,20 @@ class SpecEngine:
         n_rows = max(MAX_ROWS, B * (k + 1))
         self.part_val = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
         self.part_idx = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.int32, device=dev)
+        # Vocabulary-parallel target head (tensor parallelism): a pass leaves this rank's
+        # slice of the logits in t_out; greedy steps exchange slice maxima (2 x 256 bytes per
+        # row and rank), sampling steps gather whole rows into t_logits.
+        self.tp = tp_group
+        self.vp = tp_group is not None and target.cfg.lm_vocab > 0
+        self.t_out = self.t_logits
+        if self.vp:
+            n_tp, Vl = tp_group.world_size, target.cfg.lm_vocab
+            if Vl * n_tp != self.V:
+                raise ValueError("the ranks' LM head slices do not add up to the vocabulary")
+            self.t_out = torch.empty(n_rows, Vl, dtype=torch.float32, device=dev)
+            self.vp_send = torch.empty(2 * n_rows * ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
+            self.vp_recv = torch.empty(n_tp * self.vp_send.numel(), dtype=torch.float32, device=dev)
+            self.vp_rows = torch.empty(n_tp * n_rows * Vl, dtype=torch.float32, device=dev)
         # Step record {n_emitted, seq_len, tokens}: the last kernel of a step writes it to
         # pinned host memory, so returning a step's tokens takes one stream
         # synchronisation and no copy.
@@ -228,16 +242,15 @@ class SpecEngine:
                 want = c1 == n and model is self.target
                 view = _KvView(kv, slot)
                 model.forward(view, self.prompt_buf, 0, c0, zl, c0, 1, c1 - c0,
-                              self.t_logits[:c1 - c0] if want else None, self._ctx, wide=wide)
-            q_last = 1
-        # first generated token from the last prompt row
-        row = self.t_logits[q_last - 1:q_last]
+                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=wide)
+        # first generated token from the last prompt row (a 1-token pass: row 0)
         if self.sampling:
+            self._target_full_rows(1)
             u = torch.rand(1, generator=self.rng, device=self.device)
-            probs = ops.softmax_rows(row, self.cfg.temperature)
+            probs = ops.softmax_rows(self.t_logits[:1], self.cfg.temperature)
             first = ops.sample_rows(probs, u)
         else:
-            first = ops.argmax_rows(row)
+            first = self._target_argmax(1, torch.empty(1, dtype=torch.int64, device=self.device))
         first_tok = int(first.item())
         self.tok_buf[slot, 0] = int(prompt[-1])
         self.tok_buf[slot, 1] = first_tok
@@ -283,11 +296,41 @@ class SpecEngine:
         self._enqueue_score(fused)
         self._enqueue_accept(fused)
 
+    # -- the target's logits after a pass of n rows (whole, or one vocabulary slice per rank)
+    def _target_partials(self, n: int) -> None:
+        """Slice maxima of rows 0..n-1 over the whole vocabulary -> part_val / part_idx."""
+        if not self.vp:
+            ops.argmax_partial(self.t_out[:n], self.part_val, self.part_idx)
+            return
+        m = n * ops.ARGMAX_PARTS
+        send = self.vp_send[:2 * m]
+        ops.argmax_partial(self.t_out[:n], send[:m].view(n, -1), send[m:].view(torch.int32).view(n, -1))
+        recv = self.vp_recv[:self.tp.world_size * 2 * m]
+        self.tp.all_gather(send, recv)
+        ops.argmax_combine(recv, self.tp.world_size, n, self.target.cfg.lm_vocab,
+                           self.part_val, self.part_idx)
+
+    def _target_argmax(self, n: int, out: torch.Tensor) -> torch.Tensor:
+        if not self.vp:
+            return ops.argmax_rows(self.t_out[:n], out=out)
+        self._target_partials(n)
+        return ops.argmax_from_partials(self.part_val, self.part_idx, n, out=out)
+
+    def _target_full_rows(self, n: int) -> None:
+        """Whole logits rows 0..n-1 in t_logits (sampling needs the full distribution)."""
+        if not self.vp:
+            return
+        n_tp, Vl = self.tp.world_size, self.target.cfg.lm_vocab
+        recv = self.vp_rows[:n_tp * n * Vl]
+        self.tp.all_gather(self.t_out[:n].reshape(-1), recv)
+        self.t_logits[:n].view(n, n_tp, Vl).copy_(recv.view(n_tp, n, Vl).permute(1, 0, 2))
+
     def _enqueue_ar_step(self) -> None:
         B = self.active
         self._forward(self.target, self.t_kv, self.tok_buf, 2, 1, self.seq_lens, -1, B, 1,
-                      self.t_logits)
+                      self.t_out)
         if self.sampling:
+            self._target_full_rows(B)
             ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V),
                              scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
@@ -295,7 +338,7 @@ class SpecEngine:
             ops.advance_state(self.ids_tmp[:B].view(-1, 1), self.seq_lens[:B], self.tok_buf[:B],
                               self.gen_tokens[:B], self.gen_counts[:B], 0, self.step_out[:B])
         else:
-            ops.argmax_partial(self.t_logits[:B], self.part_val, self.part_idx)
+            self._target_partials(B)
             ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf[:B], None, None,
                                      self.seq_lens[:B], self.gen_tokens[:B], self.gen_counts[:B],
                                      0, self.step_out[:B])
@@ -312,14 +355,15 @@ class SpecEngine:
         if self.draft is not None:
             self._forward(self.draft, self.d_kv, self.tok_buf, k + 2, 0, self.seq_lens, -2, B, 2, None)
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, 1,
-                      self.t_logits)
+                      self.t_out)
         if self.sampling:
+            self._target_full_rows(B)
             ops.softmax_rows(self.t_logits[:B], self.cfg.temperature,
                              out=self.t_probs.view(-1, self.V)[:B], scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
         else:
-            ops.argmax_rows(self.t_logits[:B], out=self.ids_tmp)
+            self._target_argmax(B, self.ids_tmp[:B])
         self.out_ids[:B].fill_(-1)
         self.out_ids[:B, 0].copy_(self.ids_tmp[:B])
         ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
@@ -391,18 +435,19 @@ class SpecEngine:
         t_logits [B*(k+1), V], plus target_ids (greedy) or t_probs / bonus_ids."""
         B, k = self.active, self.k
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, k + 1,
-                      self.t_logits)
+                      self.t_out)
         rows = self.t_logits[:B * (k + 1)]
         if fused:
-            ops.argmax_partial(rows, self.part_val, self.part_idx)
+            self._target_partials(B * (k + 1))
         elif self.sampling:
+            self._target_full_rows(B * (k + 1))
             ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V),
                              scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
                             out=self.bonus_ids, row_offset=k, row_step=k + 1,
                             scratch=self.samp_scratch)
         else:
-            ops.argmax_rows(rows, out=self.target_ids.view(-1))
+            self._target_argmax(B * (k + 1), self.target_ids.view(-1)[:B * (k + 1)])
 
     def _enqueue_accept(self, fused: bool = False) -> None:
         """Acceptance (rejection sampling or greedy match) and the state update."""

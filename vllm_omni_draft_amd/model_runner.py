@@ -71,7 +71,7 @@ class DecoderModel:
             tp_rank=tp_group.rank if tp_group else 0,
             allreduce=tp_group.allreduce_ptr if tp_group else None,
             allreduce_ctx=tp_group.ctx_ptr if tp_group else None,
-            weight_fp8=int(fp8), lm_head_s=_ptr(weights.lm_head.scale))
+            weight_fp8=int(fp8), lm_head_s=_ptr(weights.lm_head.scale), lm_vocab=cfg.lm_vocab)
         self._handle = lib.sd_model_create(C.byref(desc))
         if not self._handle:
             raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")
@@ -99,8 +99,8 @@ class DecoderModel:
         if token_ids.dtype != torch.int32 or seq_lens.dtype != torch.int32:
             raise _lib.SdError("token_ids and seq_lens must be int32 device tensors")
         if logits is not None and (logits.dtype != torch.float32 or not logits.is_contiguous()
-                                   or logits.numel() < B * q_len * self.cfg.vocab):
-            raise _lib.SdError("logits must be a contiguous float32 [B*q_len, vocab] tensor")
+                                   or logits.numel() < B * q_len * self.cfg.head_rows):
+            raise _lib.SdError("logits must be a contiguous float32 [B*q_len, head rows] tensor")
         kvd = _lib.KvCacheDesc(k_cache=kv.k.data_ptr(), v_cache=kv.v.data_ptr(),
                                layer_stride_bytes=kv.layer_stride_bytes,
                                block_tables=kv.block_tables.data_ptr(),

@@ -444,6 +444,34 @@ def argmax_partial(logits, part_val, part_idx) -> None:
                                              _p(part_idx), R, V, _stream()), "sd_argmax_partial")
 
 
+def argmax_combine(gathered: torch.Tensor, n_ranks: int, R: int, shard_vocab: int,
+                   out_val: torch.Tensor, out_idx: torch.Tensor) -> None:
+    """gathered: n_ranks blocks of {[R, ARGMAX_PARTS] f32 maxima, [R, ARGMAX_PARTS] i32 local
+    indices} (each rank's argmax_partial output, packed values-then-indices, in rank order) ->
+    maxima over the whole vocabulary with global indices in out_val / out_idx."""
+    _need(gathered, torch.float32, "gathered")
+    n = R * ARGMAX_PARTS
+    if gathered.numel() < n_ranks * 2 * n or out_val.numel() < n or out_idx.numel() < n:
+        raise _lib.SdError("argmax_combine: buffers too small")
+    _need(out_val, torch.float32, "out_val")
+    _need(out_idx, torch.int32, "out_idx")
+    base = gathered.data_ptr()
+    _lib.check(_lib.load().sd_argmax_combine(base, base + 4 * n, n_ranks, R, shard_vocab, 2 * n,
+                                             _p(out_val), _p(out_idx), _stream()),
+               "sd_argmax_combine")
+
+
+def argmax_from_partials(part_val, part_idx, R: int, out=None) -> torch.Tensor:
+    if out is None:
+        out = torch.empty(R, dtype=torch.int64, device=part_val.device)
+    _need(out, torch.int64, "out")
+    if out.numel() < R:
+        raise _lib.SdError("argmax_from_partials: out too small")
+    _lib.check(_lib.load().sd_argmax_from_partials(_p(part_val), _p(part_idx), _p(out), R,
+                                                   _stream()), "sd_argmax_from_partials")
+    return out
+
+
 def propose_from_partials(part_val, part_idx, row_offset, row_step, tok_buf, k, step, seq_lens,
                           truth=None, accept_prob=0.0, seed=0) -> None:
     B = tok_buf.shape[0]

@@ -107,6 +107,17 @@ class TensorParallelGroup:
                                                torch.cuda.current_stream().cuda_stream),
                    "sd_tp_allreduce")
 
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        """recv = the ranks' `send` buffers one after the other, in rank order (current stream)."""
+        from . import _lib
+        nbytes = send.numel() * send.element_size()
+        if not (send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()) \
+                or recv.numel() * recv.element_size() != nbytes * self.world_size:
+            raise _lib.SdError("all_gather: contiguous device tensors, recv = world_size x send")
+        _lib.check(_lib.load().sd_tp_allgather(send.data_ptr(), recv.data_ptr(), nbytes, self._comm,
+                                               torch.cuda.current_stream().cuda_stream),
+                   "sd_tp_allgather")
+
     def close(self) -> None:
         if getattr(self, "_comm", None):
             from . import _lib
@@ -125,9 +136,15 @@ class CallbackAllReduce:
     """A tensor-parallel 'group' whose all-reduce is a host callback
     fn(ptr, n_bf16, stream) -> int: for tests and for hosts with their own collective."""
 
-    def __init__(self, rank: int, fn: Callable[[int, int, int], int]):
+    def __init__(self, rank: int, fn: Callable[[int, int, int], int], world_size: int = 2,
+                 gather: Optional[Callable[[torch.Tensor, torch.Tensor], None]] = None):
         from . import _lib
-        self.rank = rank
+        self.rank, self.world_size, self._gather = rank, world_size, gather
         self._cb = _lib.ALLREDUCE_FN(lambda buf, n, ctx, stream: fn(buf, n, stream or 0))
         self.allreduce_ptr = C.cast(self._cb, C.c_void_p).value
         self.ctx_ptr = None
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        if self._gather is None:
+            raise RuntimeError("this group was built without an all-gather")
+        self._gather(send, recv)

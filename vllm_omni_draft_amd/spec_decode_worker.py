@@ -284,6 +284,9 @@ class SpecDecodeConfig:
     # GPU), the draft stays whole on each.  `target` is then either this rank's shard or a
     # (ModelConfig, state_dict) pair that load_model shards itself.
     tensor_parallel_size: int = 1
+    # under tensor parallelism each rank holds vocab / tp rows of the LM head and the ranks
+    # exchange slice maxima (greedy) or gather rows (sampling) instead of replicating the head
+    vocab_parallel_lm_head: bool = True
 
 
 class SpecDecodeWorker:
@@ -333,7 +336,8 @@ class SpecDecodeWorker:
             from . import weights as W
             cfg, state = target
             if tp > 1:
-                cfg, state = W.shard_state_dict(cfg, state, tp, self.rank)
+                vp = c.vocab_parallel_lm_head and cfg.vocab % (16 * tp) == 0
+                cfg, state = W.shard_state_dict(cfg, state, tp, self.rank, vocab_parallel=vp)
             target = W.from_state_dict(cfg, state, torch.device("cuda", self.local_rank))
         self.engine = SpecEngine(target, c.draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,

@@ -158,16 +158,18 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
 
 
 def shard_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], tp_size: int,
-                     tp_rank: int):
+                     tp_rank: int, vocab_parallel: bool = False):
     """(per-rank config, per-rank state dict) for tensor parallelism over `tp_size` GPUs.
 
     Column-parallel: q/k/v projections by head and gate/up (fc1) by ffn column keep the
     rows of the rank's share; row-parallel: o_proj and down_proj (fc2) keep the matching
     input columns, their partial products are summed over the ranks.  Norms, embeddings,
-    LM head and the biases of the row-parallel layers stay whole (rank 0 applies them)."""
+    LM head and the biases of the row-parallel layers stay whole (rank 0 applies them).
+    vocab_parallel: the LM head keeps only the rank's slice of vocabulary rows (a tied head
+    becomes an explicit "lm_head.weight" slice; the embedding table stays whole)."""
     if not 0 <= tp_rank < tp_size:
         raise ValueError(f"tp_rank {tp_rank} outside 0..{tp_size - 1}")
-    local = cfg.tp_shard(tp_size)
+    local = cfg.tp_shard(tp_size, vocab_parallel)
     D = cfg.head_dim
     q0, q1 = tp_rank * local.n_heads * D, (tp_rank + 1) * local.n_heads * D
     k0, k1 = tp_rank * local.n_kv_heads * D, (tp_rank + 1) * local.n_kv_heads * D
@@ -186,6 +188,12 @@ def shard_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], tp_size: 
             a, b = cols[mod]
             t = t[:, a:b]
         out[name] = t.contiguous()
+    if vocab_parallel:
+        v0, v1 = tp_rank * local.lm_vocab, (tp_rank + 1) * local.lm_vocab
+        head = state.get("lm_head.weight")
+        if head is None:
+            head = next(t for n, t in state.items() if n.endswith("embed_tokens.weight"))
+        out["lm_head.weight"] = head[v0:v1].contiguous()
     return local, out
 
 
