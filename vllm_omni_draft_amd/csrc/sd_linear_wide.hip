@@ -2,11 +2,15 @@
 // pre-tiled weights as the <= 16-row kernel.
 //
 // wide_gemm_kernel: a workgroup of 8 waves owns 16 weight tiles (256 weight rows; wave w the
-// tiles 2w, 2w+1) and one K range.  The activations of the K range pass through LDS in
+// tiles w and w + 8 of the group) and one K range.  The activations of the K range pass through LDS in
 // 128-column chunks (double buffered), shared by the 8 waves; the weights go HBM -> VGPR ->
 // MFMA as in the narrow kernel, each A fragment feeding one MFMA per 16-row token tile.  With
 // M = 192 rows an A fragment is used 12 times, so the kernel sits at the MFMA / LDS / HBM
-// balance point rather than being a pure stream.
+// balance point rather than being a pure stream: the B fragments are read through a register
+// ring whose order is pinned for the instruction scheduler, and no load sits inside a branch
+// (see the kernel).  Tried and dropped: groups of 8..15 tiles to fill the CUs in one round
+// (waves without a second tile still pay for it); 4-wave workgroups of 8 tiles, two per CU,
+// with 64-column chunks (the x staging latency of a chunk is then longer than the chunk).
 //
 // Matrices with few tiles split K over several workgroups.  Partial sums go to a workspace
 // as f32 [split][row][tile row] and wide_epilogue_kernel adds the splits in index order and
@@ -23,6 +27,7 @@ constexpr int kTilesPerGroup = kWideWaves * kTilesPerWave;  // 16 tiles = 256 we
 constexpr int kChunkSteps = 4;                              // k-steps (32 columns) per LDS chunk
 constexpr int kChunkCols = kChunkSteps * 32;
 constexpr int kXLD = kChunkCols + 8;                        // padded LDS row (elements)
+constexpr int kBRing = 4;                                   // B fragments in flight per wave
 constexpr int EPI_QKV_ROPE = 100;
 
 __device__ __forceinline__ float silu_w(float v) { return v / (1.0f + __expf(-v)); }
@@ -58,6 +63,7 @@ struct WideArgs {
   int64_t ldx;
   float* part;      // [S][M][NR]
   int M, K, n_tiles, ks_per_split;
+  int group_tiles;  // weight tiles per workgroup (8..16)
   WideEpiArgs epi;  // direct epilogue (one split): EPI >= 0
 };
 
@@ -78,26 +84,38 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
   const int ks_lo = blockIdx.y * a.ks_per_split;
   const int ks_hi = min(ks_lo + a.ks_per_split, KS);
   const int n_chunks = (ks_hi - ks_lo + kChunkSteps - 1) / kChunkSteps;
-  const int tile0 = (blockIdx.x * kWideWaves + wave) * kTilesPerWave;
+  // tile t of this wave: group base + wave + 8 t, if inside the group and the matrix
+  const int tile0 = blockIdx.x * a.group_tiles + wave;
+  auto tile_of = [&](int t) { return tile0 + t * kWideWaves; };
+  auto tile_ok = [&](int t) {
+    return wave + t * kWideWaves < a.group_tiles && tile_of(t) < a.n_tiles;
+  };
 
+  // Every load below is unconditional on a clamped address: a load inside a branch makes the
+  // compiler wait for all outstanding loads at the join, which would drain the weight
+  // prefetch at every chunk.  Rows >= M and tiles outside the group produce sums nobody
+  // stores; columns past the split's K range are zeroed in x, so the weights read there
+  // (clamped, finite) contribute nothing.
   bf16x8 x_stage[kPieces];
   auto load_x = [&](int chunk) {
     const int col0 = (ks_lo + chunk * kChunkSteps) * 32;
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
       const int p = tid + i * kWideThreads;
-      const int row = p / (kChunkCols / 8), col = col0 + (p % (kChunkCols / 8)) * 8;
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (row < a.M && col < ks_hi * 32) v = *reinterpret_cast<const bf16x8*>(a.x + (size_t)row * a.ldx + col);
-      x_stage[i] = v;
+      const int row = min(p / (kChunkCols / 8), a.M - 1);
+      const int col = col0 + (p % (kChunkCols / 8)) * 8;
+      x_stage[i] = *reinterpret_cast<const bf16x8*>(a.x + (size_t)row * a.ldx + min(col, a.K - 8));
     }
   };
-  auto store_x = [&](int buf) {
+  auto store_x = [&](int buf, int chunk) {  // the zeroing happens here: no use of the data earlier
+    const int col0 = (ks_lo + chunk * kChunkSteps) * 32;
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
       const int p = tid + i * kWideThreads;
       const int row = p / (kChunkCols / 8), c8 = p % (kChunkCols / 8);
-      *reinterpret_cast<bf16x8*>(xs + ((size_t)buf * kRows + row) * kXLD + c8 * 8) = x_stage[i];
+      const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+      *reinterpret_cast<bf16x8*>(xs + ((size_t)buf * kRows + row) * kXLD + c8 * 8) =
+          col0 + c8 * 8 < ks_hi * 32 ? x_stage[i] : z;
     }
   };
   bf16x8 a_nxt[kTilesPerWave][kChunkSteps];
@@ -106,12 +124,10 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
     for (int t = 0; t < kTilesPerWave; ++t)
 #pragma unroll
       for (int j = 0; j < kChunkSteps; ++j) {
-        const int ks = ks_lo + chunk * kChunkSteps + j;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (tile0 + t < a.n_tiles && ks < ks_hi)
-          v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
-              a.W + ((size_t)(tile0 + t) * KS + ks) * 512 + lane * 8));
-        a_nxt[t][j] = v;
+        const int ks = min(ks_lo + chunk * kChunkSteps + j, KS - 1);
+        const int tile = min(tile_of(t), a.n_tiles - 1);
+        a_nxt[t][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
+            a.W + ((size_t)tile * KS + ks) * 512 + lane * 8));
       }
   };
 
@@ -123,7 +139,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
 
   load_x(0);
   load_a(0);
-  store_x(0);
+  store_x(0, 0);
   __syncthreads();
   const int xc = lane & 15, xq = lane >> 4;
   for (int c = 0; c < n_chunks; ++c) {
@@ -133,21 +149,44 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
 #pragma unroll
       for (int j = 0; j < kChunkSteps; ++j) a_cur[t][j] = a_nxt[t][j];
     if (c + 1 < n_chunks) {
+      // x first (cache hits, stored to LDS at the end of this chunk), then the weights, which
+      // may stay in flight past that store: loads return in issue order
       load_x(c + 1);
+      __builtin_amdgcn_sched_barrier(0);
       load_a(c + 1);
     }
     const bf16_t* xb = xs + (size_t)(c & 1) * kRows * kXLD + (size_t)xc * kXLD + 8 * xq;
+    // The chunk's B fragments, (k-step j, token tile mt) in order, through a ring of kBRing
+    // registers: a fragment is requested kBRing MFMA pairs before its use, so the LDS latency
+    // hides behind the matrix pipe instead of stalling every pair.
+    constexpr int kReads = kChunkSteps * MT;
+    auto read_b = [&](int idx) {
+      return *reinterpret_cast<const bf16x8*>(xb + (size_t)(idx % MT) * 16 * kXLD + (idx / MT) * 32);
+    };
+    bf16x8 ring[kBRing];
 #pragma unroll
-    for (int j = 0; j < kChunkSteps; ++j) {
+    for (int i = 0; i < kBRing; ++i) ring[i] = read_b(i);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * kXLD + j * 32);
+    for (int idx = 0; idx < kReads; ++idx) {
+      const bf16x8 b = ring[idx % kBRing];
 #pragma unroll
-        for (int t = 0; t < kTilesPerWave; ++t)
-          acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[t][j], b, acc[t][mt], 0, 0, 0);
-      }
+      for (int t = 0; t < kTilesPerWave; ++t)
+        acc[t][idx % MT] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[t][idx / MT], b,
+                                                                   acc[t][idx % MT], 0, 0, 0);
+      if (idx + kBRing < kReads) ring[idx % kBRing] = read_b(idx + kBRing);
     }
-    if (c + 1 < n_chunks) store_x((c + 1) & 1);
+    // Pin that order for the instruction scheduler (it otherwise sinks every LDS read to just
+    // before its MFMA pair): kBRing reads, then {MFMA pair, read} ..., then the last pairs.
+#pragma unroll
+    for (int i = 0; i < kBRing; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int i = 0; i < kReads - kBRing; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, kTilesPerWave, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < kBRing; ++i) __builtin_amdgcn_sched_group_barrier(0x008, kTilesPerWave, 0);
+    if (c + 1 < n_chunks) store_x((c + 1) & 1, c + 1);
     __syncthreads();
   }
 
@@ -156,19 +195,19 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
     float* part = a.part + (size_t)blockIdx.y * a.M * NR;
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; ++t) {
-      if (tile0 + t >= a.n_tiles) continue;
+      if (!tile_ok(t)) continue;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + xc;
         if (m < a.M)
-          *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)(tile0 + t) * 16 + 4 * xq) = acc[t][mt];
+          *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)tile_of(t) * 16 + 4 * xq) = acc[t][mt];
       }
     }
   } else {
     constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; ++t) {
-      const bool tile_ok = tile0 + t < a.n_tiles;  // wave-uniform
+      const bool t_ok = tile_ok(t);  // wave-uniform
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + xc;
@@ -177,8 +216,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) hi[j] = __shfl(acc[t][mt][j], (lane + 32) & 63, 64);
         }
-        if (tile_ok && m < a.M && (!PAIRED || xq < 2))
-          emit_unit<EPI == EPI_PARTIAL ? 0 : EPI>(a.epi, m, tile0 + t, 4 * xq, acc[t][mt], hi);
+        if (t_ok && m < a.M && (!PAIRED || xq < 2))
+          emit_unit<EPI == EPI_PARTIAL ? 0 : EPI>(a.epi, m, tile_of(t), 4 * xq, acc[t][mt], hi);
       }
     }
   }
@@ -320,9 +359,10 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
 
 // K split: a function of the matrix alone (never of M), so results do not depend on the
 // number of rows in the pass.
-void plan_split(int n_tiles, int K, int& S, int& ks_per_split) {
+void plan_split(int n_tiles, int K, int& S, int& ks_per_split, int& group_tiles) {
   const int KS = K / 32;
-  const int groups = (n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
+  group_tiles = kTilesPerGroup;
+  const int groups = (n_tiles + group_tiles - 1) / group_tiles;
   // one split (epilogue inside the kernel, no partial sums) once half the CUs have a
   // workgroup; otherwise enough splits for every CU
   int want = groups >= 128 ? 1 : 256 / groups;  // never more workgroups than CUs: one round
@@ -335,8 +375,8 @@ void plan_split(int n_tiles, int K, int& S, int& ks_per_split) {
 int tiles_of(int N, int epi) { return epi == SD_EPI_SILU_MUL ? (N + 7) / 8 : (N + 15) / 16; }
 
 size_t wide_ws_bytes(int M, int n_tiles, int K) {
-  int S, ksp;
-  plan_split(n_tiles, K, S, ksp);
+  int S, ksp, g;
+  plan_split(n_tiles, K, S, ksp, g);
   return (size_t)S * M * n_tiles * 16 * sizeof(float);
 }
 
@@ -353,7 +393,7 @@ int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
     }
     attr_set = true;
   }
-  const int groups = (a.n_tiles + kTilesPerGroup - 1) / kTilesPerGroup;
+  const int groups = (a.n_tiles + a.group_tiles - 1) / a.group_tiles;
   hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
   SD_CHECK_LAUNCH("sd_linear_wide");
   return SD_OK;
@@ -418,12 +458,12 @@ int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_t
                  sd_aligned16(workspace), SD_ERR_INVALID,
              "sd_linear_wide: rows must be 16-byte aligned (ldx=%lld)", (long long)ldx);
   if (M == 0) return SD_OK;
-  int S, ksp;
-  plan_split(n_tiles, K, S, ksp);
+  int S, ksp, g;
+  plan_split(n_tiles, K, S, ksp, g);
   const size_t need = (size_t)S * M * n_tiles * 16 * sizeof(float);
   SD_REQUIRE(ws_bytes >= need, SD_ERR_WORKSPACE, "sd_linear_wide: workspace %zu < %zu bytes",
              ws_bytes, need);
-  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp, e};
+  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp, g, e};
   e.part = (const float*)workspace;
   e.S = S;
   e.M = M;
