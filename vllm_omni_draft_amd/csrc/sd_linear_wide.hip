@@ -22,8 +22,10 @@ namespace {
 
 constexpr int kWideThreads = 512;
 constexpr int kWideWaves = kWideThreads / SD_WAVE;
-constexpr int kTilesPerWave = 2;
-constexpr int kTilesPerGroup = kWideWaves * kTilesPerWave;  // 16 tiles = 256 weight rows
+constexpr int kTilesPerGroup = kWideWaves * 2;              // 16 tiles = 256 weight rows
+// Matrices with fewer than kSmallTiles tiles run with one tile per wave (8-tile groups) and
+// shorter K splits: twice the workgroups, each half as long.
+constexpr int kSmallTiles = 1024;
 constexpr int kChunkSteps = 4;                              // k-steps (32 columns) per LDS chunk
 constexpr int kChunkCols = kChunkSteps * 32;
 constexpr int kXLD = kChunkCols + 8;                        // padded LDS row (elements)
@@ -69,8 +71,9 @@ struct WideArgs {
 
 constexpr int EPI_PARTIAL = -1;  // several K splits: partial sums to the workspace
 
-template <int MT, int EPI>  // MT token tiles of 16 rows
+template <int MT, int EPI, int TPW>  // MT token tiles of 16 rows; TPW weight tiles per wave
 __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
+  constexpr int kTilesPerWave = TPW;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [2][MT*16][kXLD]
   constexpr int kRows = MT * 16;
@@ -361,12 +364,14 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
 // number of rows in the pass.
 void plan_split(int n_tiles, int K, int& S, int& ks_per_split, int& group_tiles) {
   const int KS = K / 32;
-  group_tiles = kTilesPerGroup;
+  const bool small = n_tiles < kSmallTiles;
+  group_tiles = small ? kWideWaves : kTilesPerGroup;
   const int groups = (n_tiles + group_tiles - 1) / group_tiles;
   // one split (epilogue inside the kernel, no partial sums) once half the CUs have a
   // workgroup; otherwise enough splits for every CU
   int want = groups >= 128 ? 1 : 256 / groups;  // never more workgroups than CUs: one round
-  const int max_s = (KS + 7) / 8;                   // at least 8 k-steps (256 columns) per split
+  const int min_steps = small ? 4 : 8;              // k-steps (32 columns) per split, at least
+  const int max_s = (KS + min_steps - 1) / min_steps;
   want = want < 1 ? 1 : (want > max_s ? max_s : want);
   ks_per_split = ((KS + want - 1) / want + kChunkSteps - 1) / kChunkSteps * kChunkSteps;
   S = (KS + ks_per_split - 1) / ks_per_split;
@@ -380,12 +385,12 @@ size_t wide_ws_bytes(int M, int n_tiles, int K) {
   return (size_t)S * M * n_tiles * 16 * sizeof(float);
 }
 
-template <int MT, int EPI>
-int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
+template <int MT, int EPI, int TPW>
+int launch_gemm_t(const WideArgs& a, int S, hipStream_t st) {
   const size_t lds = (size_t)2 * MT * 16 * kXLD * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI, TPW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -394,9 +399,15 @@ int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
     attr_set = true;
   }
   const int groups = (a.n_tiles + a.group_tiles - 1) / a.group_tiles;
-  hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
+  hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI, TPW>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
   SD_CHECK_LAUNCH("sd_linear_wide");
   return SD_OK;
+}
+
+template <int MT, int EPI>
+int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
+  return a.group_tiles == kWideWaves ? launch_gemm_t<MT, EPI, 1>(a, S, st)
+                                     : launch_gemm_t<MT, EPI, 2>(a, S, st);
 }
 
 template <int EPI>
