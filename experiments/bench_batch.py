@@ -1,7 +1,7 @@
 """Batched speculative decoding (the wide kernel family): Qwen2.5-7B target + Qwen2.5-0.5B draft,
 k = 5, B sequences, synthetic weights and teacher-forced acceptance, next to the batched
 autoregressive baseline on the same kernels.
-    python experiments/bench_batch.py [B] [prompt_len]
+    python experiments/bench_batch.py [B] [prompt_len] [draft_rows: auto | same | narrow | wide] [target] [draft]
 """
 import os
 import sys
@@ -15,9 +15,12 @@ from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+DRAFT_ROWS = sys.argv[3] if len(sys.argv) > 3 else "auto"
+TARGET = sys.argv[4] if len(sys.argv) > 4 else "qwen2.5-7b"
+DRAFT = sys.argv[5] if len(sys.argv) > 5 else "qwen2.5-0.5b"
 k, steps, warm, alpha = 5, 24, 4, 0.8
-tcfg = config.preset("qwen2.5-7b")
-dcfg = config.preset("qwen2.5-0.5b", vocab=tcfg.vocab)  # draft vocabulary padded to the target's
+tcfg = config.preset(TARGET)
+dcfg = config.preset(DRAFT, vocab=tcfg.vocab)  # draft vocabulary padded to the target's
 tw = weights.random_init(tcfg, seed=0)
 dw = weights.random_init(dcfg, seed=1)
 V = min(tcfg.vocab, dcfg.vocab)
@@ -55,7 +58,7 @@ for b in range(B):
 del ar
 torch.cuda.empty_cache()
 eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=B, max_seq_len=max_seq, rows=rows,
-                                      gen_capacity=n_new + 64))
+                                      draft_rows=DRAFT_ROWS, gen_capacity=n_new + 64))
 eng.set_synthetic_acceptance(truth.cuda(), alpha, seed=3)
 out, n, dt = run(eng, steps, warm)
 exact = all(o[:min(len(o), len(a))] == a[:min(len(o), len(a))] for o, a in zip(out, ar_out))

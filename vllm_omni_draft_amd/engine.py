@@ -46,6 +46,12 @@ class EngineConfig:
     # the whole batch exceeds 16 rows).  The families round differently, so an autoregressive
     # engine that is to reproduce a speculative engine's stream must be given the same one.
     rows: str = "auto"
+    # Kernel family of the draft model's passes: "narrow", "wide", "same" as the target's, or
+    # "auto": narrow while one token per sequence fits a narrow pass (max_batch <= 16), else
+    # the target's.  The draft's rounding never shows in the output (only in what gets
+    # proposed), so its family may differ from the target's; measured at 8 sequences the
+    # narrow draft makes the step 18 % shorter, at 32 (two sub-batches per pass) 26 % longer.
+    draft_rows: str = "auto"
     # Prompt-lookup proposals instead of a draft model (k > 0, draft = None): the last
     # ngram_max..ngram_min tokens of a sequence are searched in its own history and the k
     # tokens after the most recent match are proposed (none if nothing matches).
@@ -98,8 +104,16 @@ class SpecEngine:
                                  (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS))
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
                                    wide=self.wide)
+        if cfg.draft_rows not in ("auto", "same", "narrow", "wide"):
+            raise ValueError("draft_rows must be 'auto', 'same', 'narrow' or 'wide'")
+        if cfg.draft_rows == "auto":
+            draft_wide = self.wide and B > MAX_ROWS
+        else:
+            draft_wide = self.wide if cfg.draft_rows == "same" else cfg.draft_rows == "wide"
+        if draft is not None and getattr(draft, "fp8", False):
+            draft_wide = False
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
-                                   wide=self.wide) if k > 0 and draft is not None else None)
+                                   wide=draft_wide) if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self.V = target.cfg.vocab
         pages = PagedKVCache.pages_for(target.cfg, B, self.max_ctx)
@@ -269,7 +283,7 @@ class SpecEngine:
                  seq_lens, pos_offset, B, q_len, logits, slot0: int = 0) -> None:
         """One model pass over B sequences x q_len tokens, in sub-batches of at
         most max_rows token rows."""
-        per = max(1, self.max_rows // q_len)
+        per = max(1, model.max_rows // q_len)
         for b0 in range(0, B, per):
             nb = min(per, B - b0)
             sub_logits = None

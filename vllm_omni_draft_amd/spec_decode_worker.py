@@ -276,6 +276,7 @@ class SpecDecodeConfig:
     split_tokens: int = 256
     use_graph: bool = True
     rows: str = "auto"             # kernel family, see EngineConfig.rows
+    draft_rows: str = "auto"       # the draft's kernel family, see EngineConfig.draft_rows
     speculative_disable_by_batch_size: int = 0   # 0 = speculate at every batch size
     spec_decoding_acceptance_method: str = "rejection_sampler"  # or "typical_acceptance_sampler"
     typical_acceptance_sampler_posterior_threshold: float = 0.09
@@ -343,7 +344,7 @@ class SpecDecodeWorker:
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
             # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
-            use_graph=c.use_graph and tp == 1, rows=c.rows,
+            use_graph=c.use_graph and tp == 1, rows=c.rows, draft_rows=c.draft_rows,
             ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
             acceptance_method=c.spec_decoding_acceptance_method,
