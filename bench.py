@@ -161,7 +161,7 @@ def kernel_roofline(eng, tw, rows, reps=3):
     return {"kernel": f"linear_kernel<norm+gate_up+silu_mul>, M={rows} [{n_rows}x{w.K}] {wdt}",
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("linear_kernel<2, 1, false>") if rows == 6 and w.scale is None else None,
+            "traffic": pmc_traffic("linear_kernel<2, 1, false, false>") if rows == 6 and w.scale is None else None,
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
