@@ -368,7 +368,7 @@ def main():
             del e2
             torch.cuda.empty_cache()
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
         try:
             cpu = cpu_baseline(args, main_res["emitted_per_step"])
         except Exception as e:  # the baseline is a report item, never the product path
