@@ -23,9 +23,11 @@ namespace {
 constexpr int kWideThreads = 512;
 constexpr int kWideWaves = kWideThreads / SD_WAVE;
 constexpr int kTilesPerGroup = kWideWaves * 2;              // 16 tiles = 256 weight rows
-// Matrices with fewer than kSmallTiles tiles run with one tile per wave (8-tile groups) and
-// shorter K splits: twice the workgroups, each half as long.
+// Matrices with fewer than kPairTiles tiles run with one tile per wave (8-tile groups): from
+// kSmallTiles up that gives 128..255 workgroups in one pass with the epilogue inside; below,
+// K is split (in shorter pieces than for the large matrices).
 constexpr int kSmallTiles = 1024;
+constexpr int kPairTiles = 2048;
 constexpr int kChunkSteps = 4;                              // k-steps (32 columns) per LDS chunk
 constexpr int kChunkCols = kChunkSteps * 32;
 constexpr int kXLD = kChunkCols + 8;                        // padded LDS row (elements)
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
 void plan_split(int n_tiles, int K, int& S, int& ks_per_split, int& group_tiles) {
   const int KS = K / 32;
   const bool small = n_tiles < kSmallTiles;
-  group_tiles = small ? kWideWaves : kTilesPerGroup;
+  group_tiles = n_tiles < kPairTiles ? kWideWaves : kTilesPerGroup;
   const int groups = (n_tiles + group_tiles - 1) / group_tiles;
   // one split (epilogue inside the kernel, no partial sums) once half the CUs have a
   // workgroup; otherwise enough splits for every CU
