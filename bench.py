@@ -177,10 +177,10 @@ def attention_roofline(device, k):
     bt = torch.randperm(n_pages, device=device).to(torch.int32).view(B, pages_per_seq).contiguous()
     q = torch.randn(B * q_len, Hq * D, device=device).to(torch.bfloat16)
     sl = torch.full((B,), ctx, dtype=torch.int32, device=device)
-    ws = torch.empty(ops.paged_attention_workspace_bytes(B, q_len, Hq, D, ctx + q_len, 1024),
+    ws = torch.empty(ops.paged_attention_workspace_bytes(B, q_len, Hq, D, ctx + q_len, 4096),
                      dtype=torch.uint8, device=device)
     run = lambda: ops.paged_attention(q, kc, vc, bt, sl, 0, B, q_len, Hq, Hkv, D, D ** -0.5,
-                                      ctx + q_len, 1024, workspace=ws)
+                                      ctx + q_len, 4096, workspace=ws)
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -193,7 +193,7 @@ def attention_roofline(device, k):
     us = e0.elapsed_time(e1) * 1e3 / reps
     kv_bytes = B * (ctx + q_len) * Hkv * D * 2 * 2
     gbs = kv_bytes / us * 1e-3
-    return {"kernel": "paged_attn_kernel<D=128> + merge, B=32 ctx=4096 q_len=%d, 1024 keys per workgroup" % q_len,
+    return {"kernel": "paged_attn_kernel<D=128> + merge, B=32 ctx=4096 q_len=%d, 4096 keys per workgroup" % q_len,
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("paged_attn_kernel<128, 1"),
             "bytes_per_launch": kv_bytes, "avg_us": round(us, 2)}

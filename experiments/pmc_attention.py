@@ -1,5 +1,5 @@
 """Launches the verify attention kernel (32 sequences x 4096 cached tokens, Llama-3-8B head
-shape, 6 query tokens, 1024 keys per workgroup) 8 times over distinct caches, for counter
+shape, 6 query tokens, 4096 keys per workgroup) 8 times over distinct caches, for counter
 collection:
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d out -- python3 experiments/pmc_attention.py
@@ -13,7 +13,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_omni_draft_amd import ops  # noqa: E402
 
-B, ctx, Hq, Hkv, D, q_len, split, L = 32, 4096, 32, 8, 128, 6, 1024, 8
+B, ctx, Hq, Hkv, D, q_len, split, L = 32, 4096, 32, 8, 128, 6, 4096, 8
 dev = "cuda"
 pages_per_seq = (ctx + q_len + 15) // 16
 n_pages = B * pages_per_seq
