@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: both models' matrices quantised at load (e4m3, per-row scales), "
                          "bf16 activations; an extra data point, the headline is bf16")
+    ap.add_argument("--read-back", choices=["overlapped", "sync"], default="sync",
+                    help="host read-back of a step's tokens: while the next step runs, or before it "
+                         "is enqueued (both rates are reported; `value` is this one)")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -96,22 +99,34 @@ def streamed_weight_bytes(w):
     return n
 
 
-def run_generation(eng, prompt, n_steps, warmup, dist_barrier):
-    """Prefill, `warmup` untimed steps, then exactly n_steps timed steps with a
-    read-back after each.  Returns (tokens, timed_tokens, seconds, prefill_s)."""
+def run_generation(eng, prompt, n_steps, warmup, dist_barrier, overlapped=False):
+    """Prefill, `warmup` untimed steps, then exactly n_steps timed steps, every step's tokens
+    read back by the host inside the timed region: right after the step (synchronous), or
+    while the next step runs (overlapped: step t+1 is enqueued before step t is read, the
+    last step is flushed before the clock stops).  Returns (tokens, timed_tokens, seconds,
+    prefill_s)."""
+    def steps(n):
+        if not overlapped:
+            for _ in range(n):
+                out.extend(eng.step()[0])
+            return
+        for _ in range(n):
+            r = eng.step_overlapped()
+            if r:
+                out.extend(r[0])
+        out.extend(eng.flush()[0])
+
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = [eng.add_request(0, prompt)]
     torch.cuda.synchronize()
     prefill_s = time.perf_counter() - t0
-    for _ in range(warmup):
-        out.extend(eng.step()[0])
+    steps(warmup)
     dist_barrier()
     torch.cuda.synchronize()
     n0 = len(out)
     t0 = time.perf_counter()
-    for _ in range(n_steps):
-        out.extend(eng.step()[0])
+    steps(n_steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dist_barrier()
@@ -304,8 +319,9 @@ def main():
     # 1) autoregressive baseline (k = 0) on the same kernels: the truth stream
     ar = SpecEngine(tw, None, EngineConfig(k=0, max_seq_len=max_seq, split_tokens=args.split_tokens,
                                            use_graph=not args.no_graph, gen_capacity=n_truth + 64))
+    ovl = args.read_back == "overlapped"
     ar_tokens, ar_n, ar_dt, ar_prefill = run_generation(ar, prompt, n_truth - 4 - args.warmup,
-                                                        args.warmup, barrier)
+                                                        args.warmup, barrier, ovl)
     ar_tps = ar_n / ar_dt
     truth = torch.zeros(1, max_seq, dtype=torch.int32)
     truth[0, :len(prompt)] = torch.tensor(prompt)
@@ -315,12 +331,12 @@ def main():
     torch.cuda.empty_cache()
 
     # 2) speculative run
-    def spec_run(alpha, steps, warmup):
+    def spec_run(alpha, steps, warmup, overlapped=ovl):
         eng = SpecEngine(tw, dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
                                               draft_split_tokens=args.draft_split_tokens,
                                               use_graph=not args.no_graph, gen_capacity=n_truth + 64))
         eng.set_synthetic_acceptance(truth_dev, alpha, seed=99 + rank)
-        toks, n_timed, dt, prefill = run_generation(eng, prompt, steps, warmup, barrier)
+        toks, n_timed, dt, prefill = run_generation(eng, prompt, steps, warmup, barrier, overlapped)
         n_cmp = min(len(toks), len(ar_tokens))
         exact = toks[:n_cmp] == ar_tokens[:n_cmp]
         m = eng.metrics()
@@ -357,8 +373,15 @@ def main():
     roof = kernel_roofline(eng, tw, k + 1)
     attn = attention_roofline(device, k)
     sweep = []
+    other_mode = None
     if not args.no_sweep and world == 1:
         del eng
+        torch.cuda.empty_cache()
+        e2, r = spec_run(args.accept_prob, args.steps, args.warmup, not ovl)
+        other_mode = {"read_back": "sync" if ovl else "overlapped",
+                      "tokens_per_s": round(r["tokens"] / r["seconds"], 2),
+                      "ms_per_step": round(r["seconds"] / args.steps * 1e3, 4), "exact": r["exact"]}
+        del e2
         torch.cuda.empty_cache()
         for a in (0.0, 0.6, 0.7, 0.9, 1.0):
             e2, r = spec_run(a, max(16, args.steps // 2), 4)
@@ -386,7 +409,11 @@ def main():
         "config": {"workload": f"{args.target} target + {args.draft} draft, k={k}, batch 1 per GPU, "
                                f"prompt {args.prompt_len}, TP=1 (BASELINE.json configs[1])",
                    "accept_prob": args.accept_prob, "parallelism": f"dp{world} (independent replicas)",
-                   "hipgraph": not args.no_graph, "split_tokens": args.split_tokens},
+                   "hipgraph": not args.no_graph, "split_tokens": args.split_tokens,
+                   "read_back": args.read_back + (" (every step's tokens reach the host inside the "
+                                                  "timed region; step t is read while step t+1 runs)"
+                                                  if ovl else " (after every step)")},
+        "other_read_back_mode": other_mode,
         "accept_len": round(main_res["accept_len"], 3),
         "emitted_per_step": round(main_res["emitted_per_step"], 3),
         "draft_acceptance_rate": round(main_res["draft_acceptance_rate"], 4),

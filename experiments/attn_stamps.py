@@ -45,3 +45,6 @@ if __name__ == "__main__":
     case(1, 200, 32, 8, 128, 6, 256, 256)
     case(1, 1100, 32, 8, 64, 1, 256, 1280)
     case(1, 1100, 32, 8, 128, 6, 256, 1280)
+    # the KV-bound roofline case: why are 6 query tokens slower than 1?
+    case(32, 4096, 32, 8, 128, 1, 4096, 4102)
+    case(32, 4096, 32, 8, 128, 6, 4096, 4102)

@@ -204,6 +204,37 @@ def test_greedy_spec_equals_ar_on_gpu(k, use_graph):
         assert m["draft"] % k == 0 and m["emitted"] - m["accepted"] == m["draft"] // k
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_overlapped_read_back_gives_the_same_stream(use_graph):
+    """step_overlapped enqueues step t+1 before step t is read: same tokens, one call late,
+    across a context-bucket change and a page boundary; the batch cannot change in between."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 73))]
+    want = _generate(_engine(tw, dw, 3, max_batch=2, use_graph=use_graph), prompts, 36)
+    eng = _engine(tw, dw, 3, max_batch=2, use_graph=use_graph)
+    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    assert eng.step_overlapped() is None
+    with pytest.raises(RuntimeError):
+        eng.step()
+    with pytest.raises(RuntimeError):
+        eng.remove_request(0)
+    while min(len(o) for o in outs) < 36:
+        for o, new in zip(outs, eng.step_overlapped()):
+            o.extend(new)
+    for o, new in zip(outs, eng.flush()):
+        o.extend(new)
+    assert eng.flush() is None
+    assert [o[:36] for o in outs] == want
+    # synchronous stepping resumes after the flush, and the metrics saw every step
+    more = eng.step()
+    assert all(len(t) >= 1 for t in more)
+    m = eng.metrics()
+    assert m["emitted"] == sum(len(o) - 1 for o in outs) + sum(len(t) for t in more)
+
+
 def test_draft_equals_target_accepts_all_and_batches():
     """Known answer: with draft == target every proposal is accepted (accept-len == k)."""
     tcfg = MODELS["llama"]

@@ -162,7 +162,11 @@ class SpecEngine:
         # Step record {n_emitted, seq_len, tokens}: the last kernel of a step writes it to
         # pinned host memory, so returning a step's tokens takes one stream
         # synchronisation and no copy.
-        self.step_out = torch.full((B, k + 3), -1, dtype=torch.int32).pin_memory()
+        # two records: with overlapped read-back (step_overlapped) a step writes one while
+        # the host still reads the other
+        self._records = torch.full((2, B, k + 3), -1, dtype=torch.int32).pin_memory()
+        self._parity = 0
+        self._inflight = None   # (event, record parity, sequences) of a step not yet read back
         self._steps_pending = 0               # steps enqueued since the last read-back
         self.sampling = cfg.temperature > 0.0
         if self.sampling:
@@ -201,6 +205,7 @@ class SpecEngine:
             self._reset()
 
     def _reset(self) -> None:
+        self._inflight = None
         for b in range(self.cfg.max_batch):
             self.t_kv.release(b)
             if self.d_kv is not None:
@@ -233,6 +238,8 @@ class SpecEngine:
             return self._add_request(slot, prompt)
 
     def _add_request(self, slot: int, prompt: Sequence[int]) -> int:
+        if self._inflight is not None:
+            raise RuntimeError("flush() the step in flight before changing the batch")
         n = len(prompt)
         if n < 1 or n + 1 > self.cfg.max_seq_len:
             raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
@@ -350,12 +357,12 @@ class SpecEngine:
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
             ops.advance_state(self.ids_tmp[:B].view(-1, 1), self.seq_lens[:B], self.tok_buf[:B],
-                              self.gen_tokens[:B], self.gen_counts[:B], 0, self.step_out[:B])
+                              self.gen_tokens[:B], self.gen_counts[:B], 0, self._records[self._parity, :B])
         else:
             self._target_partials(B)
             ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf[:B], None, None,
                                      self.seq_lens[:B], self.gen_tokens[:B], self.gen_counts[:B],
-                                     0, self.step_out[:B])
+                                     0, self._records[self._parity, :B])
 
     def _spec_disabled(self) -> bool:
         t = self.cfg.disable_by_batch_size
@@ -381,7 +388,7 @@ class SpecEngine:
         self.out_ids[:B].fill_(-1)
         self.out_ids[:B, 0].copy_(self.ids_tmp[:B])
         ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
-                          self.gen_tokens[:B], self.gen_counts[:B], k, self.step_out[:B])
+                          self.gen_tokens[:B], self.gen_counts[:B], k, self._records[self._parity, :B])
 
     def _enqueue_propose(self, fused: bool = False) -> None:
         """k draft passes; proposals land in tok_buf[:, 2:], their probability
@@ -471,7 +478,7 @@ class SpecEngine:
             ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf[:B],
                                      self.out_ids[:B], self.counters, self.seq_lens[:B],
                                      self.gen_tokens[:B], self.gen_counts[:B], k,
-                                     self.step_out[:B], proposal_lens=lens)
+                                     self._records[self._parity, :B], proposal_lens=lens)
             return
         if self.sampling and self.typical:
             ops.typical_acceptance(self.t_probs[:B], self.bonus_ids[:B], self.draft_ids[:B],
@@ -485,11 +492,13 @@ class SpecEngine:
             ops.greedy_verify(self.target_ids[:B], self.draft_ids[:B], lens, self.counters,
                               out=self.out_ids)
         ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
-                          self.gen_tokens[:B], self.gen_counts[:B], k, self.step_out[:B])
+                          self.gen_tokens[:B], self.gen_counts[:B], k, self._records[self._parity, :B])
 
     def remove_request(self, slot: int) -> None:
         """Frees batch slot `slot`; the last active sequence moves into it so
         that active sequences stay contiguous (synchronises)."""
+        if self._inflight is not None:
+            raise RuntimeError("flush() the step in flight before changing the batch")
         with torch.cuda.stream(self.stream):
             last = self.active - 1
             if not 0 <= slot <= last:
@@ -519,6 +528,8 @@ class SpecEngine:
         """Runs one step for every active sequence.  With sync=True returns the
         tokens each sequence emitted in this step (the V1 worker contract:
         sampled_token_ids, one variable-length list per request)."""
+        if self._inflight is not None:
+            raise RuntimeError("flush() the step in flight before a synchronous step")
         with torch.cuda.stream(self.stream):
             return self._step(sync)
 
@@ -572,7 +583,7 @@ class SpecEngine:
         stream = torch.cuda.current_stream().cuda_stream
         lib = _lib.load()
         if self.cfg.use_graph:
-            key = (B, k, self.truth is not None, self._ctx, self._spec_disabled())
+            key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity)
             g = self._graphs.get(key)
             if g is None:
                 self._enqueue_step()          # eager warm-up step (also a real step)
@@ -596,6 +607,46 @@ class SpecEngine:
         if not sync:
             return None
         return self._read_back()
+
+    def step_overlapped(self) -> Optional[List[List[int]]]:
+        """Enqueues the next step and returns the tokens of the step before it (None on the
+        first call): the host's read-back, bookkeeping and launch work run while the GPU is
+        busy with the step just enqueued, so the card never idles between steps.  Tokens
+        arrive one call late; flush() returns the last step's.  Every step depends on device
+        state only; the host's length bounds (pages, context bucket) allow for the step in
+        flight.  Not with prompt lookup (its proposals come from the tokens read back)."""
+        if self.ngram:
+            raise RuntimeError("step_overlapped: prompt-lookup proposals need each step's tokens")
+        with torch.cuda.stream(self.stream):
+            if self.active == 0:
+                return []
+            prev = self._inflight
+            self._parity ^= 1
+            self._step(False)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._inflight = (ev, self._parity, self.active)
+            return None if prev is None else self._collect(prev, 1)
+
+    def flush(self) -> Optional[List[List[int]]]:
+        """Tokens of the step still in flight after step_overlapped (None if there is none)."""
+        with torch.cuda.stream(self.stream):
+            prev, self._inflight = self._inflight, None
+            return None if prev is None else self._collect(prev, 0)
+
+    def _collect(self, step, later_steps: int) -> List[List[int]]:
+        ev, parity, B = step
+        ev.synchronize()
+        rec = self._records[parity, :B].tolist()
+        self._steps_pending -= 1
+        out = []
+        for b in range(B):
+            n = rec[b][0]
+            out.append(rec[b][2:2 + n])
+            self.host_gen[b] += n
+            # exact after that step, plus the bound of the steps enqueued since
+            self.host_lens[b] = rec[b][1] + later_steps * (self.k + 1)
+        return out
 
     def _ctx_bucket(self, need: Optional[int] = None) -> int:
         if need is None:
@@ -622,7 +673,7 @@ class SpecEngine:
         if pending == 1:
             # the step's last kernel left its record in pinned host memory
             torch.cuda.current_stream().synchronize()
-            rec = self.step_out[:B].tolist()
+            rec = self._records[self._parity, :B].tolist()
             out = []
             for b in range(B):
                 n = rec[b][0]
