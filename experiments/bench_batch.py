@@ -1,7 +1,7 @@
 """Batched speculative decoding (the wide kernel family): Qwen2.5-7B target + Qwen2.5-0.5B draft,
 k = 5, B sequences, synthetic weights and teacher-forced acceptance, next to the batched
 autoregressive baseline on the same kernels.
-    python experiments/bench_batch.py [B] [prompt_len] [draft_rows: auto | same | narrow | wide] [target] [draft]
+    python experiments/bench_batch.py [B] [prompt_len] [draft_rows: auto | same | narrow | wide] [target] [draft] [fp8]
 """
 import os
 import sys
@@ -18,11 +18,12 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 DRAFT_ROWS = sys.argv[3] if len(sys.argv) > 3 else "auto"
 TARGET = sys.argv[4] if len(sys.argv) > 4 else "qwen2.5-7b"
 DRAFT = sys.argv[5] if len(sys.argv) > 5 else "qwen2.5-0.5b"
+FP8 = len(sys.argv) > 6 and sys.argv[6] == "fp8"
 k, steps, warm, alpha = 5, 24, 4, 0.8
 tcfg = config.preset(TARGET)
 dcfg = config.preset(DRAFT, vocab=tcfg.vocab)  # draft vocabulary padded to the target's
-tw = weights.random_init(tcfg, seed=0)
-dw = weights.random_init(dcfg, seed=1)
+tw = weights.random_init(tcfg, seed=0, fp8=FP8)
+dw = weights.random_init(dcfg, seed=1, fp8=FP8)
 V = min(tcfg.vocab, dcfg.vocab)
 g = torch.Generator().manual_seed(7)
 prompts = [torch.randint(0, V, (P,), generator=g).tolist() for _ in range(B)]

@@ -258,15 +258,18 @@ int sd_linear(const void* W, const float* w_scale, const void* x, int64_t ldx,
  * order by a second launch that applies the epilogue.  A token row's result
  * depends on (N, K) only, not on M; it differs in rounding from sd_linear's
  * (another summation order), so a caller uses one family for all its passes.
- * No fused norm: normalise first (sd_rmsnorm / sd_layernorm).
+ * No fused norm: normalise first (sd_rmsnorm / sd_layernorm).  w_scale as in
+ * sd_linear (NULL: bf16 tiles; else fp8 tiles and K % 64 == 0).
  * workspace: sd_linear_wide_workspace_bytes(M, N, K, epilogue) bytes; for
  * sd_qkv_rope_wide pass N = (Hq + 2*Hkv) * D and SD_EPI_STORE.              */
 size_t sd_linear_wide_workspace_bytes(int M, int N, int K, int epilogue);
-int sd_linear_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+int sd_linear_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                   const void* bias,
                    const void* residual, void* out, int64_t ldo, int M, int N,
                    int K, int epilogue, void* workspace, size_t workspace_bytes,
                    sd_stream_t stream);
-int sd_qkv_rope_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+int sd_qkv_rope_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                     const void* bias,
                      void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
                      void* k_cache, void* v_cache, const int32_t* block_tables,
                      int max_blocks_per_seq, const int32_t* seq_lens,
@@ -389,8 +392,7 @@ typedef struct {
   void* allreduce_ctx;
   /* weight_fp8 != 0: every layer matrix and the LM head are fp8 tiles
    * (sd_tile_weights_fp8) with per-row scales (layers[i].*_s, lm_head_s); the
-   * embedding table, norms and biases stay bf16.  Passes of more than 16 rows
-   * (forward args.wide) are not available for fp8 weights.                   */
+   * embedding table, norms and biases stay bf16.                             */
   int weight_fp8;
   const float* lm_head_s;
   /* Vocabulary-parallel LM head under tensor parallelism: lm_head holds lm_vocab

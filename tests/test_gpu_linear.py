@@ -283,9 +283,58 @@ def test_fp8_rejects_unsupported_uses():
     q, s = ops.quantize_fp8(torch.randn(64, 128, device="cuda").to(torch.bfloat16))
     with pytest.raises(SdError):
         ops.tile_weights(q)                                           # no scale
-    Wt = ops.tile_weights(q, scale=s)
-    with pytest.raises(SdError):
-        ops.linear_wide(Wt, torch.zeros(32, 128, dtype=torch.bfloat16, device="cuda"))
+
+
+@pytest.mark.parametrize("M", [17, 50, 192])
+@pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (96, 14336), (20480, 256)])
+def test_fp8_wide_linear_is_the_bf16_wide_kernel_on_dequantised_weights(M, N, K):
+    """The 17..256-row family with fp8 tiles: bit-identical to its bf16 form on the dequantised
+    matrix (power-of-two scales), through split-K partial sums and the direct epilogue alike."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(M * 13 + N)
+    x = torch.randn(M, K, generator=gen, device="cuda").to(torch.bfloat16)
+    bias = (torch.randn(2 * N, generator=gen, device="cuda") * 0.1).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=gen, device="cuda").to(torch.bfloat16)
+    W2 = (torch.randn(2 * N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    W2[3] *= 37.0
+    W2[N + 1] *= 0.01
+    q2, s2, exact2 = _fp8_pow2(W2)
+    q, sc, exact = q2[:N].contiguous(), s2[:N].contiguous(), exact2[:N].contiguous()
+    Wt, Wb = ops.tile_weights(q, ops.TILE_PLAIN, scale=sc), ops.tile_weights(exact)
+    for epi in (ops.EPI_STORE, ops.EPI_RESIDUAL, ops.EPI_RELU, ops.EPI_F32, ops.EPI_GELU_TANH):
+        for b in (None, bias[:N].contiguous()):
+            r = res if epi == ops.EPI_RESIDUAL else None
+            assert torch.equal(ops.linear_wide(Wt, x, b, r, epi), ops.linear_wide(Wb, x, b, r, epi)), epi
+    Wg, Wgb = ops.tile_weights(q2, ops.TILE_GATED, scale=s2), ops.tile_weights(exact2, ops.TILE_GATED)
+    for b in (None, bias):
+        assert torch.equal(ops.linear_wide(Wg, x, b, None, ops.EPI_SILU_MUL),
+                           ops.linear_wide(Wgb, x, b, None, ops.EPI_SILU_MUL))
+
+
+def test_fp8_wide_qkv_rope_matches_bf16_wide():
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    Hq, Hkv, D, H, B, q_len = 4, 2, 64, 256, 6, 5
+    M = B * q_len
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=128)
+    cs = rope_table(cfg).cuda()
+    x = torch.randn(M, H, generator=gen, device="cuda").to(torch.bfloat16)
+    Wq = (torch.randn((Hq + 2 * Hkv) * D, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    Wq[5] *= 20.0
+    qq, sq, exq = _fp8_pow2(Wq)
+    bias = (0.1 * torch.randn((Hq + 2 * Hkv) * D, generator=gen, device="cuda")).to(torch.bfloat16)
+    bt = torch.arange(B * 3, dtype=torch.int32, device="cuda").view(B, 3)
+    seq_lens = torch.tensor([17, 30, 3, 9, 21, 12], dtype=torch.int32, device="cuda")
+    outs = []
+    for Wt in (ops.tile_weights(qq, ops.TILE_ROTARY, D, scale=sq), ops.tile_weights(exq, ops.TILE_ROTARY, D)):
+        kc = torch.zeros(B * 3, Hkv, D * 16, dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        qo = ops.qkv_rope_wide(Wt, x, bias, cs, kc, vc, bt, seq_lens, -1, B, q_len, Hq, Hkv, D)
+        outs.append((qo, kc, vc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][1].abs().sum() > 0
 
 
 # ------------------------------------------------------------------ 17..256 token rows

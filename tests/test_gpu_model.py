@@ -145,8 +145,8 @@ def test_fp8_forward_logits_match_oracle_on_dequantised_weights(name):
 
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_fp8_greedy_spec_equals_ar(use_graph):
-    """The engine invariant holds with fp8 weights on both models (narrow family, 16-token
-    prefill passes), alone and in a batch of 3."""
+    """The engine invariant holds with fp8 weights on both models, alone (narrow family) and
+    in a batch of 3 (wide family for the target, 192-token prefill passes in both)."""
     tcfg, dcfg = MODELS["llama"], MODELS["opt"]
     dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
     tw = _product(tcfg, _bf(random_state(tcfg, seed=21)), fp8=True)
@@ -155,11 +155,13 @@ def test_fp8_greedy_spec_equals_ar(use_graph):
     ar = [_generate(_engine(tw, None, 0, use_graph=use_graph), [p], 40)[0] for p in prompts]
     for p, want in zip(prompts[:2], ar):
         assert _generate(_engine(tw, dw, 3, use_graph=use_graph), [p], 40)[0] == want
-    eng = _engine(tw, dw, 3, max_batch=3, use_graph=use_graph)
-    assert not eng.wide
-    assert _generate(eng, prompts, 40) == ar
-    with pytest.raises(ValueError):
-        _engine(tw, dw, 3, rows="wide")
+    assert _generate(_engine(tw, dw, 3, max_batch=3, rows="narrow", use_graph=use_graph),
+                     prompts, 40) == ar
+    # wide family (12 verify rows would fit a narrow pass: force it), against its own AR
+    eng = _engine(tw, dw, 3, max_batch=3, rows="wide", use_graph=use_graph)
+    assert eng.wide
+    ar_wide = _generate(_engine(tw, None, 0, max_batch=3, rows="wide", use_graph=use_graph), prompts, 40)
+    assert _generate(eng, prompts, 40) == ar_wide
 
 
 def test_chunking_is_bit_invariant():

@@ -93,8 +93,8 @@ SIGNATURES = {
     "sd_set_proposals": (i32, [vp, vp, i32, i32, vp]),
     "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
     "sd_linear_wide_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32]),
-    "sd_linear_wide": (i32, [vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
-    "sd_qkv_rope_wide": (i32, [vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
+    "sd_linear_wide": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
+    "sd_qkv_rope_wide": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
                                i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "sd_linear_attn_merge": (i32, [vp, vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                    vp, vp, vp, i64, i32, i32, vp]),

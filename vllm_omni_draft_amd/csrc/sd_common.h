@@ -46,6 +46,19 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float v) { return (bf16_t)v; }
 // Round-trip through bf16: what a bf16 tensor op would have stored.
 __device__ __forceinline__ float round_bf16(float v) { return (float)(bf16_t)v; }
 
+// Eight e4m3 weights (two 32-bit words) as the bf16 MFMA operand: every e4m3 value is exact in
+// bf16, so the f32 conversion is truncated to its upper half.
+__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t w0, uint32_t w1) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+  auto pack = [](f32x2 v) {
+    return __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
+  };
+  const u32x4 r = {pack(a), pack(b), pack(c), pack(d)};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -86,20 +86,6 @@ __device__ unsigned long long sd_lin_stamps[16];
 #define LSTAMP(i)
 #endif
 
-// Eight e4m3 weights (two 32-bit words) as the bf16 MFMA operand: every e4m3 value is exact in
-// bf16, so the f32 conversion is truncated to its upper half.
-__device__ __forceinline__ bf16x8 fp8x8_to_bf16(uint32_t w0, uint32_t w1) {
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
-  const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
-  auto pack = [](f32x2 v) {
-    return __builtin_amdgcn_perm(__float_as_uint(v[1]), __float_as_uint(v[0]), 0x07060302u);
-  };
-  const u32x4 r = {pack(a), pack(b), pack(c), pack(d)};
-  return __builtin_bit_cast(bf16x8, r);
-}
-
 // W8: the weights are e4m3 bytes, two k-steps per 16-byte lane load, dequantised in registers
 // (the layer is bound by the weight stream, so the conversion is free and activations keep
 // bf16); the f32 scale of an output row multiplies its finished sum.
@@ -399,7 +385,6 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
                                   : *reinterpret_cast<const bf16x8*>(xp + j * 32);
           bf16x8 w;
           if constexpr (W8) {
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 raw = __builtin_bit_cast(u32x4, cur[j >> 1]);
             w = fp8x8_to_bf16(raw[2 * (j & 1)], raw[2 * (j & 1) + 1]);
           } else {

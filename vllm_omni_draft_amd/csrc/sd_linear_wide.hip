@@ -54,6 +54,7 @@ struct WideRope {
 struct WideEpiArgs {
   const float* part;  // [S][M][NR]
   int S, M, NR, N;
+  const float* w_scale;  // fp8 weights: f32 scale per source row (indexed like bias); else null
   const bf16_t* bias;
   const bf16_t* residual;
   void* out;
@@ -62,7 +63,7 @@ struct WideEpiArgs {
 };
 
 struct WideArgs {
-  const bf16_t* W;  // tiled [n_tiles][K/32][64][8]
+  const bf16_t* W;  // tiled [n_tiles][K/32][64][8] bf16, or [n_tiles][K/64][64][16] fp8
   const bf16_t* x;
   int64_t ldx;
   float* part;      // [S][M][NR]
@@ -73,9 +74,13 @@ struct WideArgs {
 
 constexpr int EPI_PARTIAL = -1;  // several K splits: partial sums to the workspace
 
-template <int MT, int EPI, int TPW>  // MT token tiles of 16 rows; TPW weight tiles per wave
+// W8: fp8 (e4m3) weight tiles, two k-steps per 16-byte lane load, converted to bf16 when a
+// chunk's fragments are taken out of the prefetch registers; the row scales are applied by the
+// epilogue.
+template <int MT, int EPI, int TPW, bool W8>  // MT token tiles of 16 rows; TPW tiles per wave
 __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
   constexpr int kTilesPerWave = TPW;
+  constexpr int kALoads = W8 ? kChunkSteps / 2 : kChunkSteps;  // 16-byte loads per tile and chunk
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [2][MT*16][kXLD]
   constexpr int kRows = MT * 16;
@@ -123,16 +128,18 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
           col0 + c8 * 8 < ks_hi * 32 ? x_stage[i] : z;
     }
   };
-  bf16x8 a_nxt[kTilesPerWave][kChunkSteps];
+  bf16x8 a_nxt[kTilesPerWave][kALoads];
   auto load_a = [&](int chunk) {
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; ++t)
 #pragma unroll
-      for (int j = 0; j < kChunkSteps; ++j) {
-        const int ks = min(ks_lo + chunk * kChunkSteps + j, KS - 1);
+      for (int j = 0; j < kALoads; ++j) {
         const int tile = min(tile_of(t), a.n_tiles - 1);
+        // 512 bf16 (1 KiB) per wave load either way; chunks start at even k-steps
+        const int step = W8 ? min((ks_lo + chunk * kChunkSteps) / 2 + j, KS / 2 - 1)
+                            : min(ks_lo + chunk * kChunkSteps + j, KS - 1);
         a_nxt[t][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(
-            a.W + ((size_t)tile * KS + ks) * 512 + lane * 8));
+            a.W + ((size_t)tile * (W8 ? KS / 2 : KS) + step) * 512 + lane * 8));
       }
   };
 
@@ -152,7 +159,14 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; ++t)
 #pragma unroll
-      for (int j = 0; j < kChunkSteps; ++j) a_cur[t][j] = a_nxt[t][j];
+      for (int j = 0; j < kChunkSteps; ++j) {
+        if constexpr (W8) {
+          const u32x4 raw = __builtin_bit_cast(u32x4, a_nxt[t][j >> 1]);
+          a_cur[t][j] = fp8x8_to_bf16(raw[2 * (j & 1)], raw[2 * (j & 1) + 1]);
+        } else {
+          a_cur[t][j] = a_nxt[t][j];
+        }
+      }
     if (c + 1 < n_chunks) {
       // x first (cache hits, stored to LDS at the end of this chunk), then the weights, which
       // may stay in flight past that store: loads return in issue order
@@ -249,6 +263,10 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
     for (int j = 0; j < 4; ++j) {
       const int i = i0 + j;
       float l = lo[j], h = hi[j];
+      if (a.w_scale) {
+        l *= a.w_scale[head * D + i];
+        h *= a.w_scale[head * D + i + half];
+      }
       if (a.bias) {
         l += (float)a.bias[head * D + i];
         h += (float)a.bias[head * D + i + half];
@@ -284,6 +302,10 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
       const int n = n0 + j;
       if (n >= a.N) break;
       float g = lo[j], up = hi[j];
+      if (a.w_scale) {
+        g *= a.w_scale[n];
+        up *= a.w_scale[a.N + n];
+      }
       if (a.bias) {
         g += (float)a.bias[n];
         up += (float)a.bias[a.N + n];
@@ -295,6 +317,11 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
     const int n0 = tile * 16 + r0;
     if (n0 + 3 < a.N && (a.ldo & 3) == 0) {  // four outputs in one store
       f32x4 y = lo;
+      if (a.w_scale) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(a.w_scale + n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] *= sv[j];
+      }
       if (a.bias) {
         const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + n0);
 #pragma unroll
@@ -323,6 +350,7 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
       const int n = n0 + j;
       if (n >= a.N) break;
       float y = lo[j];
+      if (a.w_scale) y *= a.w_scale[n];
       if (a.bias) y += (float)a.bias[n];
       const size_t o = (size_t)m * a.ldo + n;
       if (EPI == SD_EPI_F32) {
@@ -387,12 +415,12 @@ size_t wide_ws_bytes(int M, int n_tiles, int K) {
   return (size_t)S * M * n_tiles * 16 * sizeof(float);
 }
 
-template <int MT, int EPI, int TPW>
-int launch_gemm_t(const WideArgs& a, int S, hipStream_t st) {
+template <int MT, int EPI, int TPW, bool W8>
+int launch_gemm_w(const WideArgs& a, int S, hipStream_t st) {
   const size_t lds = (size_t)2 * MT * 16 * kXLD * sizeof(bf16_t);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI, TPW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI, TPW, W8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) {
       sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -401,9 +429,16 @@ int launch_gemm_t(const WideArgs& a, int S, hipStream_t st) {
     attr_set = true;
   }
   const int groups = (a.n_tiles + a.group_tiles - 1) / a.group_tiles;
-  hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI, TPW>), dim3(groups, S), dim3(kWideThreads), lds, st, a);
+  hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI, TPW, W8>), dim3(groups, S), dim3(kWideThreads), lds,
+                     st, a);
   SD_CHECK_LAUNCH("sd_linear_wide");
   return SD_OK;
+}
+
+template <int MT, int EPI, int TPW>
+int launch_gemm_t(const WideArgs& a, int S, hipStream_t st) {
+  return a.epi.w_scale ? launch_gemm_w<MT, EPI, TPW, true>(a, S, st)
+                       : launch_gemm_w<MT, EPI, TPW, false>(a, S, st);
 }
 
 template <int MT, int EPI>
@@ -467,6 +502,8 @@ int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_t
   SD_REQUIRE(M >= 0 && M <= 256, SD_ERR_UNSUPPORTED, "sd_linear_wide: M=%d outside 0..256", M);
   SD_REQUIRE(K >= 32 && K % 32 == 0 && n_tiles >= 1, SD_ERR_INVALID,
              "sd_linear_wide: K must be a positive multiple of 32 (K=%d)", K);
+  SD_REQUIRE(!e.w_scale || K % 64 == 0, SD_ERR_UNSUPPORTED,
+             "sd_linear_wide: fp8 weights need K %% 64 == 0 (K=%d)", K);
   SD_REQUIRE(ldx % 8 == 0 && ldx >= K && sd_aligned16(W) && sd_aligned16(x) &&
                  sd_aligned16(workspace), SD_ERR_INVALID,
              "sd_linear_wide: rows must be 16-byte aligned (ldx=%lld)", (long long)ldx);
@@ -496,7 +533,8 @@ extern "C" size_t sd_linear_wide_workspace_bytes(int M, int N, int K, int epilog
   return wide_ws_bytes(M, tiles_of(N, epilogue), K);
 }
 
-extern "C" int sd_linear_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+extern "C" int sd_linear_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                              const void* bias,
                               const void* residual, void* out, int64_t ldo, int M, int N, int K,
                               int epilogue, void* workspace, size_t workspace_bytes,
                               sd_stream_t stream) {
@@ -507,6 +545,7 @@ extern "C" int sd_linear_wide(const void* W, const void* x, int64_t ldx, const v
              "sd_linear_wide: residual epilogue without residual pointer");
   WideEpiArgs e{};
   e.N = N;
+  e.w_scale = w_scale;
   e.bias = (const bf16_t*)bias;
   e.residual = (const bf16_t*)residual;
   e.out = out;
@@ -515,7 +554,8 @@ extern "C" int sd_linear_wide(const void* W, const void* x, int64_t ldx, const v
                      workspace_bytes, (hipStream_t)stream);
 }
 
-extern "C" int sd_qkv_rope_wide(const void* W, const void* x, int64_t ldx, const void* bias,
+extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                                const void* bias,
                                 void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
                                 void* k_cache, void* v_cache, const int32_t* block_tables,
                                 int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
@@ -530,6 +570,7 @@ extern "C" int sd_qkv_rope_wide(const void* W, const void* x, int64_t ldx, const
   const int N = (Hq + 2 * Hkv) * D;
   WideEpiArgs e{};
   e.N = N;
+  e.w_scale = w_scale;
   e.bias = (const bf16_t*)bias;
   e.out = q_out;
   e.ldo = ldq;

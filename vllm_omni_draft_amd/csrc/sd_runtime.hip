@@ -176,8 +176,6 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const sd_model_desc& d = m->d;
   const int rows = a->B * a->q_len;
   const bool wide = a->wide != 0;
-  SD_REQUIRE(!(wide && d.weight_fp8), SD_ERR_UNSUPPORTED,
-             "sd_model_forward: passes of more than 16 rows are not available for fp8 weights");
   SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= (wide ? 256 : 16), SD_ERR_UNSUPPORTED,
              "sd_model_forward: B*q_len = %d outside 1..%d", rows, wide ? 256 : 16);
   SD_REQUIRE(a->q_len * (d.n_heads / d.n_kv_heads) <= 64 || (wide && a->B == 1), SD_ERR_UNSUPPORTED,
@@ -217,7 +215,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       const int proj_epi = lead ? SD_EPI_RESIDUAL : SD_EPI_STORE;
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_qkv_rope_wide(l.qkv_w, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
+      SD_TRY(sd_qkv_rope_wide(l.qkv_w, l.qkv_s, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
                               llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
                               kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
                               Hq, Hkv, D, H, wws, w.wide_ws_bytes, stream));
@@ -233,14 +231,14 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                                   (int64_t)Hq * D, a->B, qn, Hq, Hkv, D, d.attn_scale, a->max_ctx,
                                   a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
       }
-      SD_TRY(sd_linear_wide(l.o_w, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
+      SD_TRY(sd_linear_wide(l.o_w, l.o_s, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
                             Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_linear_wide(l.up_w, xn, H, l.up_b, nullptr, act, F, rows, F, H,
+      SD_TRY(sd_linear_wide(l.up_w, l.up_s, xn, H, l.up_b, nullptr, act, F, rows, F, H,
                             llama ? SD_EPI_SILU_MUL : SD_EPI_RELU, wws, w.wide_ws_bytes, stream));
-      SD_TRY(sd_linear_wide(l.down_w, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F,
+      SD_TRY(sd_linear_wide(l.down_w, l.down_s, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F,
                             proj_epi, wws, w.wide_ws_bytes, stream));
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
       continue;
@@ -299,7 +297,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   if (a->logits && wide) {
     if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
     else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
-    SD_TRY(sd_linear_wide(d.lm_head, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
+    SD_TRY(sd_linear_wide(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
                           SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
   } else if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {

@@ -97,11 +97,7 @@ class SpecEngine:
         self.max_ctx = cfg.max_seq_len + k + 2
         if cfg.rows not in ("auto", "narrow", "wide"):
             raise ValueError("rows must be 'auto', 'narrow' or 'wide'")
-        fp8 = bool(getattr(target, "fp8", False) or getattr(draft, "fp8", False))
-        if fp8 and cfg.rows == "wide":
-            raise ValueError("fp8 weights are served by the <= 16-row kernels only (rows='narrow')")
-        self.wide = not fp8 and (cfg.rows == "wide" or
-                                 (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS))
+        self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS)
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
                                    wide=self.wide)
         if cfg.draft_rows not in ("auto", "same", "narrow", "wide"):
@@ -110,8 +106,6 @@ class SpecEngine:
             draft_wide = self.wide and B > MAX_ROWS
         else:
             draft_wide = self.wide if cfg.draft_rows == "same" else cfg.draft_rows == "wide"
-        if draft is not None and getattr(draft, "fp8", False):
-            draft_wide = False
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
                                    wide=draft_wide) if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows

@@ -36,9 +36,6 @@ class DecoderModel:
         self.cfg: ModelConfig = weights.cfg
         cfg = self.cfg
         fp8 = bool(getattr(weights, "fp8", False))
-        if fp8 and wide:
-            raise ValueError("fp8 weights are served by the <= 16-row kernels only (rows='narrow')")
-        wide_prefill = wide_prefill and not fp8
         # wide: every pass of this model goes through the 17..256-row linear kernels (one
         # kernel family per model, because the two round differently)
         self.wide = bool(wide)

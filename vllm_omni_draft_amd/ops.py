@@ -339,8 +339,6 @@ def linear_wide(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None,
     """linear() for up to 256 token rows (its own summation order; see sd_linear_wide)."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, epilogue)
-    if Wt.scale is not None:
-        raise _lib.SdError("linear_wide: fp8 weights are served by the <= 16-row kernels only")
     M, K = x.shape
     N = Wt.N
     if out is None:
@@ -349,7 +347,8 @@ def linear_wide(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None,
     need = int(_lib.load().sd_linear_wide_workspace_bytes(M, N, K, epilogue))
     if workspace is None:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
-    _lib.check(_lib.load().sd_linear_wide(_p(Wt.data), _p(x), x.stride(0), _p(bias), _p(residual),
+    _lib.check(_lib.load().sd_linear_wide(_p(Wt.data), _p(Wt.scale), _p(x), x.stride(0), _p(bias),
+                                          _p(residual),
                                           _p(out), out.stride(0), M, N, K, epilogue, _p(workspace),
                                           workspace.numel(), _stream()), "sd_linear_wide")
     return out
@@ -360,8 +359,6 @@ def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens,
     """QKV projection + rotary embedding + cache append for up to 256 token rows; returns q."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, EPI_STORE, D)
-    if Wt.scale is not None:
-        raise _lib.SdError("qkv_rope_wide: fp8 weights are served by the <= 16-row kernels only")
     M, K = x.shape
     N = (Hq + 2 * Hkv) * D
     q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=x.device)
@@ -369,7 +366,7 @@ def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens,
     if workspace is None:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     _lib.check(_lib.load().sd_qkv_rope_wide(
-        _p(Wt.data), _p(x), x.stride(0), _p(bias), _p(q), Hq * D, _p(rope_cs),
+        _p(Wt.data), _p(Wt.scale), _p(x), x.stride(0), _p(bias), _p(q), Hq * D, _p(rope_cs),
         0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache), _p(block_tables),
         block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K, _p(workspace),
         workspace.numel(), _stream()), "sd_qkv_rope_wide")
