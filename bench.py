@@ -331,8 +331,8 @@ def main():
     torch.cuda.empty_cache()
 
     # 2) speculative run
-    def spec_run(alpha, steps, warmup, overlapped=ovl):
-        eng = SpecEngine(tw, dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
+    def spec_run(alpha, steps, warmup, overlapped=ovl, draft=None):
+        eng = SpecEngine(tw, draft or dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
                                               draft_split_tokens=args.draft_split_tokens,
                                               use_graph=not args.no_graph, gen_capacity=n_truth + 64))
         eng.set_synthetic_acceptance(truth_dev, alpha, seed=99 + rank)
@@ -374,6 +374,7 @@ def main():
     attn = attention_roofline(device, k)
     sweep = []
     other_mode = None
+    fp8_draft = None
     if not args.no_sweep and world == 1:
         del eng
         torch.cuda.empty_cache()
@@ -383,6 +384,21 @@ def main():
                       "ms_per_step": round(r["seconds"] / args.steps * 1e3, 4), "exact": r["exact"]}
         del e2
         torch.cuda.empty_cache()
+        if not fp8:
+            # The draft only proposes: its precision never shows in the emitted tokens, which
+            # stay the bf16 target's own greedy stream.  An fp8 copy of the draft halves the
+            # bytes of its k passes.  (The imposed acceptance ignores what quantisation would
+            # cost a real draft in agreement, so this is a separate data point, not `value`.)
+            dw8, _ = load_weights(args.draft, 2, device, args.layers, True)
+            e2, r = spec_run(args.accept_prob, args.steps, args.warmup, ovl, dw8)
+            fp8_draft = {"tokens_per_s": round(r["tokens"] / r["seconds"], 2),
+                         "ms_per_step": round(r["seconds"] / args.steps * 1e3, 4),
+                         "speedup_vs_ar": round(r["tokens"] / r["seconds"] / ar_tps, 3),
+                         "exact": r["exact"],
+                         "note": "bf16 target (emitted stream identical to its autoregressive "
+                                 "stream), fp8-e4m3 weight copy of the draft"}
+            del e2, dw8
+            torch.cuda.empty_cache()
         for a in (0.0, 0.6, 0.7, 0.9, 1.0):
             e2, r = spec_run(a, max(16, args.steps // 2), 4)
             sweep.append({"accept_prob": a, "tokens_per_s": round(r["tokens"] / r["seconds"], 1),
@@ -414,6 +430,7 @@ def main():
                                                   "timed region; step t is read while step t+1 runs)"
                                                   if ovl else " (after every step)")},
         "other_read_back_mode": other_mode,
+        "bf16_target_fp8_draft": fp8_draft,
         "accept_len": round(main_res["accept_len"], 3),
         "emitted_per_step": round(main_res["emitted_per_step"], 3),
         "draft_acceptance_rate": round(main_res["draft_acceptance_rate"], 4),
