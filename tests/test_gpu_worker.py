@@ -114,3 +114,69 @@ def test_rejection_sampler_module():
     for row, x in zip(a, ids):
         n = int((row >= 0).sum())
         assert 1 <= n <= k + 1 and (row[:n - 1] == x[:n - 1]).all() and (row[n:] == -1).all()
+
+
+def test_typical_acceptance_sampler_module():
+    from vllm_omni_draft_amd.spec_decode_worker import TypicalAcceptanceSampler
+    g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden",
+                                           "typical_cases.npz"))
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ts = TypicalAcceptanceSampler(0.09, 0.3)
+    total = np.zeros(3, dtype=np.int64)
+    for i in range(int(g["n_cases"])):
+        if g[f"c{i}_proposal_lens"].size:      # the module's call shape has no ragged lengths
+            continue
+        out = ts(cu(g[f"c{i}_target_probs"]), cu(g[f"c{i}_bonus_ids"]), None, cu(g[f"c{i}_draft_ids"]))
+        np.testing.assert_array_equal(out.cpu().numpy(), g[f"c{i}_out_ids"], err_msg=f"case {i}")
+        total += g[f"c{i}_counters"]
+    ts.sync_counters()
+    assert [ts.num_accepted_tokens, ts.num_emitted_tokens, ts.num_draft_tokens] == total.tolist()
+
+
+@pytest.mark.parametrize("option", ["ngram", "disable_by_batch_size", "typical_never", "fp8"])
+def test_worker_options_keep_the_greedy_stream(option):
+    """Options that keep upstream's names, through the worker: prompt lookup without a draft
+    model, speculation switched off above a batch size, a typical-acceptance threshold nothing
+    passes (every step emits the target's most likely token), fp8 weights: the stream stays the
+    target's own greedy stream."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeConfig, SpecDecodeWorker)
+    tcfg = MODELS["llama"]
+    dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})
+    fp8 = option == "fp8"
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)), fp8=fp8)
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)), fp8=fp8)
+    prompts = {"a": [5, 9, 200, 31, 7, 5, 9, 200], "b": list(range(40, 60))}
+    want = {r: _generate(_engine(tw, None, 0), [p], 20)[0] for r, p in prompts.items()}
+    kw = dict(target=tw, draft=dw, num_speculative_tokens=3, max_num_seqs=2, max_model_len=200,
+              split_tokens=128)
+    if option == "ngram":
+        kw.update(draft=None, ngram_prompt_lookup_max=3, ngram_prompt_lookup_min=1)
+    elif option == "disable_by_batch_size":
+        kw.update(speculative_disable_by_batch_size=1)
+    elif option == "typical_never":
+        kw.update(temperature=1.0, spec_decoding_acceptance_method="typical_acceptance_sampler",
+                  typical_acceptance_sampler_posterior_threshold=2.0,
+                  typical_acceptance_sampler_posterior_alpha=1e9)
+    w = SpecDecodeWorker(SpecDecodeConfig(**kw))
+    w.init_device()
+    w.load_model()
+    got = {r: [] for r in prompts}
+    out = w.execute_model(ExecuteModelRequest(
+        [SequenceGroupMetadata(r, True, p) for r, p in prompts.items()]))
+    for r, toks in zip(out.req_ids, out.sampled_token_ids):
+        got[r].extend(toks)
+    while min(len(t) for t in got.values()) < 20:
+        out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata(r, False) for r in prompts]))
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            if option in ("disable_by_batch_size", "typical_never"):
+                assert len(toks) == 1
+            got[r].extend(toks)
+    if option == "typical_never":
+        # the first token of each prompt is sampled; what follows is the greedy continuation
+        for r, p in prompts.items():
+            cont = _generate(_engine(tw, None, 0), [p + got[r][:1]], 19)[0]
+            assert got[r][1:20] == cont
+    else:
+        for r in prompts:
+            assert got[r][:20] == want[r], r
