@@ -6,6 +6,8 @@ gpurun_out/<round>_profile:
   <round>_roofline_kernel_stats.csv  statistics of the two roofline kernels run alone
   <round>_pmc_hbm.json               HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
   <round>_step_breakdown.txt         kernels of one speculative step, grouped
+  <round>_pmc_mfma.json              matrix-pipe utilisation of the roofline kernels
+                                     (experiments/profile_mfma.sh), when that pass was run
 
 usage: python profiles/collect_round.py [round-prefix, default r1]
 """
@@ -76,6 +78,29 @@ def main():
            "kernels": kernels}
     with open(os.path.join(dst, f"{rnd}_pmc_hbm.json"), "w") as f:
         json.dump(out, f, indent=1)
+    mfma = {}
+    for sub in ("pmc_linear_mfma", "pmc_attn_mfma"):
+        path = os.path.join(src, sub, "pmc_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        names = ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                 "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES")
+        vals = {n: counter_avg(path, n) for n in names}
+        for name in vals["GRBM_GUI_ACTIVE"]:
+            if not any(k in name for k in ALGORITHMIC):
+                continue
+            e = {n: round(vals[n][name][0]) for n in names if name in vals[n]}
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs, the SQ counters over all 1024 SIMDs
+            active = e["GRBM_GUI_ACTIVE"] / 8
+            e["mfma_util"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (active * 1024), 4)
+            e["waves_waiting_frac"] = round(e["SQ_WAIT_ANY"] / max(e["SQ_WAVE_CYCLES"], 1), 3)
+            mfma[name] = e
+    if mfma:
+        with open(os.path.join(dst, f"{rnd}_pmc_mfma.json"), "w") as f:
+            json.dump({"note": "rocprofv3 --pmc, one pass per script; mfma_util = matrix-pipe busy cycles "
+                               "/ (GPU-active cycles x 1024 SIMDs): these kernels use MFMA to avoid "
+                               "cross-lane work, not for FLOPs, and are bound by HBM",
+                       "kernels": mfma}, f, indent=1)
     trace = os.path.join(src, "stats", "bench_kernel_trace.csv")
     txt = subprocess.run([sys.executable, os.path.join(dst, "step_breakdown.py"), trace],
                          capture_output=True, text=True)
