@@ -6,7 +6,10 @@ SRCS  := $(CSRC)/sd_runtime.hip $(CSRC)/sd_sampling.hip $(CSRC)/sd_linear.hip $(
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vllm_omni_draft_amd/libsd_amd.so
 EXTRA ?=
-FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $(EXTRA)
+# -ffp-contract=off: whether a*b+c becomes one fma is otherwise the compiler's choice per
+# template instantiation, and two instantiations of a kernel (one or two token tiles, ring
+# depths, ...) must give a row the same bits.
+FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $(EXTRA)
 
 all: $(LIB)
 

@@ -130,7 +130,9 @@ def test_fused_norm_linear_matches_unfused(M, H, N):
                         (ops.EPI_SILU_MUL, W), (ops.EPI_RELU, W[:N].contiguous())):
             ref = ops.linear(Wm, xn, None, None, epi).float()
             got = ops.norm_linear(Wm, x, g, b if ln else None, 1e-5, ln, None, epi).float()
-            torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+            # the same arithmetic in the same order: a layer may take either path depending
+            # on how many rows a pass carries, and a row's bits must not depend on that
+            assert torch.equal(got, ref), (ln, epi)
     if not fits(False):
         return
     # rows are independent in the fused kernel too

@@ -643,35 +643,52 @@ __global__ __launch_bounds__(256) void tile_weights_fp8_kernel(const uint8_t* __
   }
 }
 
+// Stand-alone norms: one wave per row (four rows per workgroup), with exactly the arithmetic of
+// the norm fused into linear_kernel (each lane sums its 8-element pieces 512 columns apart, then
+// the wave butterfly), so a layer gives a row the same bits whether its norm was fused or not:
+// which of the two a pass takes depends on how many rows it carries.
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, int64_t ldx,
                                                       const bf16_t* __restrict__ w,
                                                       bf16_t* __restrict__ out, int64_t ldo,
-                                                      int H, float eps) {
-  __shared__ float s_part[4];
-  const int row = blockIdx.x, tid = threadIdx.x;
+                                                      int rows, int H, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
   const bf16_t* xr = x + (size_t)row * ldx;
-  float ss = 0.f;
-  for (int c = tid * 8; c < H; c += 256 * 8) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
+  const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  float s2 = 0.f;
+  for (int c0 = 0; c0 < H; c0 += 4096) {  // eight pieces in flight, summed in column order
+    bf16x8 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = (float)v[j];
-      ss += f * f;
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i * 512 + lane * 8;
+      v[i] = c < H ? *reinterpret_cast<const bf16x8*>(xr + c) : z;
     }
-  }
-  ss = wave_sum(ss);
-  if ((tid & 63) == 0) s_part[tid >> 6] = ss;
-  __syncthreads();
-  const float tot = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
-  const float rs = rsqrtf(tot / (float)H + eps);
-  bf16_t* orow = out + (size_t)row * ldo;
-  for (int c = tid * 8; c < H; c += 256 * 8) {
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
-    const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c);
-    bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(round_bf16((float)v[j] * rs) * (float)g[j]);
-    *reinterpret_cast<bf16x8*>(orow + c) = o;
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[i][j];
+        s2 += f * f;
+      }
+  }
+  const float rs = rsqrtf(wave_sum(s2) / (float)H + eps);
+  bf16_t* orow = out + (size_t)row * ldo;
+  for (int c0 = 0; c0 < H; c0 += 4096) {
+    bf16x8 v[8], g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i * 512 + lane * 8;
+      v[i] = c < H ? *reinterpret_cast<const bf16x8*>(xr + c) : z;
+      g[i] = c < H ? *reinterpret_cast<const bf16x8*>(w + c) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = c0 + i * 512 + lane * 8;
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(round_bf16((float)v[i][j] * rs) * (float)g[i][j]);
+      if (c < H) *reinterpret_cast<bf16x8*>(orow + c) = o;
+    }
   }
 }
 
@@ -679,23 +696,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
                                                         const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ bparam,
                                                         bf16_t* __restrict__ out, int64_t ldo,
-                                                        int H, float eps) {
-  __shared__ float s_part[4];
-  const int row = blockIdx.x, tid = threadIdx.x;
+                                                        int rows, int H, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
   const bf16_t* xr = x + (size_t)row * ldx;
-  float s = 0.f;
-  for (int c = tid * 8; c < H; c += 256 * 8) {
+  float s1 = 0.f;
+  for (int c = lane * 8; c < H; c += 512) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += (float)v[j];
+    for (int j = 0; j < 8; ++j) s1 += (float)v[j];
   }
-  s = wave_sum(s);
-  if ((tid & 63) == 0) s_part[tid >> 6] = s;
-  __syncthreads();
-  const float mean = (((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]) / (float)H;
-  __syncthreads();
+  const float mean = wave_sum(s1) / (float)H;
   float ss = 0.f;
-  for (int c = tid * 8; c < H; c += 256 * 8) {
+  for (int c = lane * 8; c < H; c += 512) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -703,13 +716,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
       ss += f * f;
     }
   }
-  ss = wave_sum(ss);
-  if ((tid & 63) == 0) s_part[tid >> 6] = ss;
-  __syncthreads();
-  const float var = (((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]) / (float)H;
-  const float rs = rsqrtf(var + eps);
+  const float rs = rsqrtf(wave_sum(ss) / (float)H + eps);
   bf16_t* orow = out + (size_t)row * ldo;
-  for (int c = tid * 8; c < H; c += 256 * 8) {
+  for (int c = lane * 8; c < H; c += 512) {
     const bf16x8 v = *reinterpret_cast<const bf16x8*>(xr + c);
     const bf16x8 g = *reinterpret_cast<const bf16x8*>(w + c);
     bf16x8 bb = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -917,8 +926,8 @@ extern "C" int sd_rmsnorm(const void* x, int64_t ldx, const void* w, void* out, 
   SD_REQUIRE(x && w && out && rows >= 0 && H >= 8 && H % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0,
              SD_ERR_INVALID, "sd_rmsnorm: bad arguments (rows=%d H=%d)", rows, H);
   if (rows == 0) return SD_OK;
-  hipLaunchKernelGGL(rmsnorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, ldx, (const bf16_t*)w, (bf16_t*)out, ldo, H, eps);
+  hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (const bf16_t*)w, (bf16_t*)out, ldo, rows, H, eps);
   SD_CHECK_LAUNCH("sd_rmsnorm");
   return SD_OK;
 }
@@ -928,9 +937,9 @@ extern "C" int sd_layernorm(const void* x, int64_t ldx, const void* w, const voi
   SD_REQUIRE(x && w && out && rows >= 0 && H >= 8 && H % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0,
              SD_ERR_INVALID, "sd_layernorm: bad arguments (rows=%d H=%d)", rows, H);
   if (rows == 0) return SD_OK;
-  hipLaunchKernelGGL(layernorm_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)out,
-                     ldo, H, eps);
+                     ldo, rows, H, eps);
   SD_CHECK_LAUNCH("sd_layernorm");
   return SD_OK;
 }
