@@ -70,12 +70,15 @@ def test_paged_attention_matches_oracle(B, ctx_lens, q_len, Hq, Hkv, D, split):
         torch.testing.assert_close(out[b], ref, rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (28, 4, 128), (8, 1, 128), (14, 2, 64)])
 @pytest.mark.parametrize("split,max_pad", [(128, 0), (256, 0), (128, 1000)])
-def test_verify_rows_equal_single_token_decode(split, max_pad):
+def test_verify_rows_equal_single_token_decode(split, max_pad, Hq, Hkv, D):
     """Bit-exact: token t scored inside a (k+1)-token verify pass == the same token
-    scored alone at the same position, for any batch mix and any max_ctx bound."""
+    scored alone at the same position, for any batch mix and any max_ctx bound.  Groups of 7
+    and 8 heads put the verify pass on the two-M-tile kernel and the single token on the
+    one-tile kernel: two instantiations that must give a row the same bits."""
     ops = _ops()
-    B, ctx_lens, q_len, Hq, Hkv, D = 2, [333, 18], 6, 32, 8, 128
+    B, ctx_lens, q_len = 2, [333, 18], 6
     kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed=3)
     pad = (max_pad + 15) // 16
     bt = torch.cat([bt, torch.zeros(B, pad, dtype=torch.int32)], dim=1).contiguous()
