@@ -277,6 +277,26 @@ def test_wide_batch_spec_equals_ar(use_graph):
     assert m["accepted"] == m["draft"]
 
 
+def test_wide_batch_spec_equals_ar_with_seven_head_groups():
+    """Qwen2-like heads (7 query heads per KV head, QKV bias): a verify pass has 42 query rows
+    per KV head (two-M-tile attention kernel), an autoregressive step 7 (one-tile kernel), and
+    the streams must still be equal."""
+    tcfg = MODELS["qwen2"]
+    dcfg = OracleConfig(**{**vars(MODELS["llama"]), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=31, qkv_bias=True)), qkv_bias=True)
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=32)))
+    g = torch.Generator().manual_seed(10)
+    prompts = [torch.randint(0, tcfg.vocab, (int(n),), generator=g).tolist()
+               for n in torch.randint(3, 150, (6,), generator=g)]
+    ar = _generate(_engine(tw, None, 0, max_batch=6, rows="wide"), prompts, 30)
+    eng = _engine(tw, dw, 5, max_batch=6)
+    assert eng.wide
+    assert _generate(eng, prompts, 30) == ar
+    # and alone in the narrow family (6 verify rows), against the narrow autoregressive engine
+    ar1 = _generate(_engine(tw, None, 0), prompts[:1], 30)
+    assert _generate(_engine(tw, dw, 5), prompts[:1], 30) == ar1
+
+
 def test_synthetic_acceptance_control():
     tcfg, dcfg = MODELS["llama"], MODELS["llama"]
     tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
