@@ -263,6 +263,23 @@ int sd_linear(const void* W, const float* w_scale, const void* x, int64_t ldx,
  * workspace: sd_linear_wide_workspace_bytes(M, N, K, epilogue) bytes; for
  * sd_qkv_rope_wide pass N = (Hq + 2*Hkv) * D and SD_EPI_STORE.              */
 size_t sd_linear_wide_workspace_bytes(int M, int N, int K, int epilogue);
+
+/* Rotary positions that differ from the cache position (the multimodal rotary
+ * embedding of Qwen2-VL: transformers/models/qwen2_vl/modeling_qwen2_vl.py,
+ * apply_multimodal_rotary_pos_emb and get_rope_index).  Frequency index i of a
+ * head (0 <= i < D/2) takes the temporal position when i < section_t, the
+ * height position when i < section_t + section_h, else the width position.
+ * pos != NULL: the three positions of every token row, [3][B*q_len] (prompt
+ * chunks with image tokens); else delta != NULL: all three are the cache
+ * position + delta[b] (text after an image; [B], one entry per sequence).
+ * A NULL sd_rope_positions*, or both pointers NULL, is the ordinary rotary
+ * embedding.  Positions are clamped to the rope table.  The cache slot a
+ * token's K/V goes to is never affected.                                     */
+typedef struct {
+  const int32_t* pos;
+  const int32_t* delta;
+  int section_t, section_h;
+} sd_rope_positions;
 int sd_linear_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
                    const void* bias,
                    const void* residual, void* out, int64_t ldo, int M, int N,
@@ -274,8 +291,8 @@ int sd_qkv_rope_wide(const void* W, const float* w_scale, const void* x, int64_t
                      void* k_cache, void* v_cache, const int32_t* block_tables,
                      int max_blocks_per_seq, const int32_t* seq_lens,
                      int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
-                     int K, void* workspace, size_t workspace_bytes,
-                     sd_stream_t stream);
+                     int K, const sd_rope_positions* rope_pos, void* workspace,
+                     size_t workspace_bytes, sd_stream_t stream);
 
 /* Output projection straight from attention partials: sd_paged_attention with
  * out == NULL (and more than one split) leaves its per-split partials in the
@@ -307,7 +324,8 @@ int sd_norm_linear(const void* W, const float* w_scale, const void* x,
  * W is [(Hq + 2*Hkv) * D, K] (q heads, k heads, v heads), tiled SD_TILE_ROTARY;
  * bias is indexed by source row.  Rotated q goes to
  * q_out [B*q_len, Hq*D] (row stride ldq); rotated k and v go straight into the
- * cache pages (arguments as sd_rope_append).  norm_w == NULL skips the norm. */
+ * cache pages (arguments as sd_rope_append).  norm_w == NULL skips the norm.
+ * rope_pos: NULL, or multimodal rotary positions (sd_rope_positions above). */
 int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x,
                      int64_t ldx,
                      const void* norm_w, const void* norm_b, float eps,
@@ -316,7 +334,7 @@ int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x,
                      void* v_cache, const int32_t* block_tables,
                      int max_blocks_per_seq, const int32_t* seq_lens,
                      int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
-                     int K, sd_stream_t stream);
+                     int K, const sd_rope_positions* rope_pos, sd_stream_t stream);
 
 /* out = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w) per row; rows x H bf16. */
 int sd_rmsnorm(const void* x, int64_t ldx, const void* w, void* out,
@@ -401,6 +419,10 @@ typedef struct {
    * sd_tp_allgather and merged by sd_argmax_combine (greedy), instead of
    * gathering logits.                                                       */
   int lm_vocab;
+  /* Multimodal rotary sections (Qwen2-VL: 16, 24 of D/2 = 64); 0, 0 = ordinary
+   * rotary embedding.  With sections set, sd_forward_args.rope_pos / rope_delta
+   * give the rotary positions.                                               */
+  int mrope_section_t, mrope_section_h;
 } sd_model_desc;
 
 typedef struct sd_model sd_model;
@@ -429,6 +451,13 @@ typedef struct {
                                 through sd_linear_wide / sd_qkv_rope_wide.  The two families
                                 round differently: a caller keeps one for all its passes.
                                 sd_model_workspace_bytes plans for it when max_rows > 16. */
+  /* Multimodal inputs (all may be NULL).  input_embeds: [B*q_len, hidden] bf16
+   * rows that replace the token-embedding lookup (image embeddings already
+   * merged in by the caller).  rope_pos / rope_delta: as sd_rope_positions;
+   * used only by a model with mrope sections.                               */
+  const void* input_embeds;
+  const int32_t* rope_pos;
+  const int32_t* rope_delta;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

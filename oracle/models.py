@@ -41,6 +41,10 @@ class OracleConfig:
     max_pos: int = 2048
     tie_embeddings: bool = False
     pos_bias: int = 2  # OPT: learned position rows start at 2
+    # Qwen2-VL multimodal rotary embedding: frequency counts of the temporal, height and width
+    # position components (transformers/models/qwen2_vl/modeling_qwen2_vl.py,
+    # apply_multimodal_rotary_pos_emb); None = ordinary rotary embedding
+    mrope_section: Optional[tuple] = None
 
 
 def rb(x: torch.Tensor, on: bool) -> torch.Tensor:
@@ -132,9 +136,13 @@ class OracleLM:
         return verify_attention(q, cache.k[layer], cache.v[layer], positions, scale)
 
     # -- forward ----------------------------------------------------------------
-    def forward(self, tokens, pos0: int, cache: KVCache) -> torch.Tensor:
+    def forward(self, tokens, pos0: int, cache: KVCache, rope_pos=None,
+                input_embeds=None) -> torch.Tensor:
         """Feeds `tokens` at positions pos0.. (their K/V replace anything cached
-        from pos0 on) and returns float32 logits [len(tokens), vocab]."""
+        from pos0 on) and returns float32 logits [len(tokens), vocab].
+        rope_pos ([3, T] integers; models with mrope_section): the temporal, height and width
+        rotary positions of the tokens instead of pos0..; input_embeds ([T, hidden]): rows that
+        replace the embedding lookup (image embeddings merged in)."""
         cfg, bf = self.cfg, self.bf
         tok = torch.as_tensor(tokens, dtype=torch.long)
         T = tok.shape[0]
@@ -142,7 +150,10 @@ class OracleLM:
         Hq, Hkv, D = cfg.n_heads, cfg.n_kv_heads, cfg.head_dim
         if cfg.arch == "llama":
             pre = "model."
-            h = self.w[pre + "embed_tokens.weight"][tok].float()
+            if input_embeds is not None:
+                h = torch.as_tensor(input_embeds).float()
+            else:
+                h = self.w[pre + "embed_tokens.weight"][tok].float()
         else:
             pre = "model.decoder."
             h = self.w[pre + "embed_tokens.weight"][tok].float() + \
@@ -164,7 +175,15 @@ class OracleLM:
             k = rb(k, bf).view(T, Hkv, D)
             v = rb(v, bf).view(T, Hkv, D)
             if cfg.arch == "llama":
-                cs = self.rope[pos]  # [T, D]
+                if rope_pos is not None:
+                    # frequency i takes the position component of its section
+                    rp = torch.as_tensor(rope_pos, dtype=torch.long)
+                    comp = torch.repeat_interleave(torch.arange(3), torch.tensor(cfg.mrope_section))
+                    idx = torch.arange(D // 2)
+                    per_freq = rp[comp].T.clamp(0, cfg.max_pos - 1)          # [T, D/2]
+                    cs = torch.cat([self.rope[per_freq, idx], self.rope[per_freq, idx + D // 2]], dim=1)
+                else:
+                    cs = self.rope[pos]  # [T, D]
                 c, s = cs[:, None, : D // 2], cs[:, None, D // 2:]
 
                 def rot(u):

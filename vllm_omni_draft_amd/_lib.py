@@ -37,6 +37,7 @@ class ModelDesc(C.Structure):
         ("final_norm_b", vp), ("lm_head", vp), ("layers", C.POINTER(LayerWeights)),
         ("tp_rank", i32), ("allreduce", vp), ("allreduce_ctx", vp),
         ("weight_fp8", i32), ("lm_head_s", vp), ("lm_vocab", i32),
+        ("mrope_section_t", i32), ("mrope_section_h", i32),
     ]
 
 
@@ -52,7 +53,12 @@ class KvCacheDesc(C.Structure):
 class ForwardArgs(C.Structure):
     _fields_ = [("B", i32), ("q_len", i32), ("token_ids", vp), ("tok_stride", i64),
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
-                ("split_tokens", i32), ("logits", vp), ("wide", i32)]
+                ("split_tokens", i32), ("logits", vp), ("wide", i32),
+                ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp)]
+
+
+class RopePositions(C.Structure):
+    _fields_ = [("pos", vp), ("delta", vp), ("section_t", i32), ("section_h", i32)]
 
 
 # name -> (restype, argtypes); every symbol include/sd_amd.h declares.
@@ -73,7 +79,8 @@ SIGNATURES = {
     "sd_linear": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_linear": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_qkv_rope": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,
-                               i32, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+                               i32, vp, i32, i32, i32, i32, i32, i32, i32,
+                               C.POINTER(RopePositions), vp]),
     "sd_rmsnorm": (i32, [vp, i64, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_layernorm": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_embed": (i32, [vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
@@ -95,7 +102,7 @@ SIGNATURES = {
     "sd_linear_wide_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32]),
     "sd_linear_wide": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "sd_qkv_rope_wide": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
-                               i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
+                               i32, i32, i32, i32, i32, C.POINTER(RopePositions), vp, C.c_size_t, vp]),
     "sd_linear_attn_merge": (i32, [vp, vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                    vp, vp, vp, i64, i32, i32, vp]),
     "sd_tp_unique_id": (i32, [vp]),

@@ -37,6 +37,9 @@ class ModelConfig:
     # Vocabulary-parallel LM head (tensor parallelism): rows of the head one rank holds;
     # 0 = the whole vocabulary.  The embedding table is never split.
     lm_vocab: int = 0
+    # Multimodal rotary embedding (Qwen2-VL): frequency counts of the temporal, height and
+    # width position components, summing to head_dim / 2; None = ordinary rotary embedding.
+    mrope_section: Optional[tuple] = None
 
     def validate(self) -> None:
         if self.arch not in ("llama", "opt"):
@@ -47,6 +50,12 @@ class ModelConfig:
             raise ValueError("n_heads must be a multiple of n_kv_heads")
         if self.hidden % 32 or self.ffn % 32 or self.vocab % 16:
             raise ValueError("hidden and ffn must be multiples of 32, vocab a multiple of 16")
+        if self.mrope_section is not None:
+            sec = tuple(int(v) for v in self.mrope_section)
+            if self.arch != "llama" or len(sec) != 3 or min(sec) < 0 or sum(sec) != self.head_dim // 2:
+                raise ValueError(f"mrope_section {self.mrope_section} must be three counts summing "
+                                 f"to head_dim/2 = {self.head_dim // 2} on a rotary model")
+            self.mrope_section = sec
 
     @property
     def qkv_rows(self) -> int:
@@ -119,6 +128,10 @@ PRESETS = {
     "qwen2.5-0.5b": dict(arch="llama", n_layers=24, hidden=896, n_heads=14, n_kv_heads=2,
                          head_dim=64, ffn=4864, vocab=151936, rope_theta=1000000.0,
                          norm_eps=1e-6, qkv_bias=True, tie_embeddings=True, max_pos=8192),
+    # the language model of Qwen2-VL-7B (vision tower: vision.VisionConfig)
+    "qwen2-vl-7b": dict(arch="llama", n_layers=28, hidden=3584, n_heads=28, n_kv_heads=4,
+                        head_dim=128, ffn=18944, vocab=152064, rope_theta=1000000.0,
+                        norm_eps=1e-6, qkv_bias=True, max_pos=8192, mrope_section=(16, 24, 24)),
     "opt-125m": dict(arch="opt", n_layers=12, hidden=768, n_heads=12, n_kv_heads=12,
                      head_dim=64, ffn=3072, vocab=50272, norm_eps=1e-5, tie_embeddings=True,
                      max_pos=2048),
@@ -144,7 +157,11 @@ def from_hf_config(cfg: dict, **overrides) -> ModelConfig:
             raise ValueError("OPT variants with word_embed_proj_dim != hidden_size are not supported")
         if not cfg.get("do_layer_norm_before", True):
             raise ValueError("post-LN OPT variants are not supported")
-    elif mt in ("llama", "qwen2", "mistral"):
+    elif mt in ("llama", "qwen2", "mistral", "qwen2_vl", "qwen2_5_vl", "qwen2_vl_text",
+                "qwen2_5_vl_text"):
+        vl = mt.startswith("qwen2_")
+        if vl and "text_config" in cfg:   # newer checkpoints nest the language model's fields
+            cfg = {**cfg, **cfg["text_config"]}
         nh = cfg["num_attention_heads"]
         kw = dict(arch="llama", n_layers=cfg["num_hidden_layers"], hidden=cfg["hidden_size"],
                   n_heads=nh, n_kv_heads=cfg.get("num_key_value_heads", nh),
@@ -154,7 +171,10 @@ def from_hf_config(cfg: dict, **overrides) -> ModelConfig:
                   rope_scaling=cfg.get("rope_scaling"),
                   max_pos=min(cfg.get("max_position_embeddings", 8192), 32768),
                   tie_embeddings=cfg.get("tie_word_embeddings", False),
-                  qkv_bias=(mt == "qwen2") or bool(cfg.get("attention_bias", False)))
+                  qkv_bias=(mt == "qwen2") or vl or bool(cfg.get("attention_bias", False)))
+        sc = cfg.get("rope_scaling") or {}
+        if sc.get("mrope_section"):
+            kw["mrope_section"] = tuple(sc["mrope_section"])
     else:
         raise ValueError(f"unsupported model_type {mt!r}")
     kw.update(overrides)
@@ -182,7 +202,7 @@ def rope_table(cfg: ModelConfig, device="cpu") -> torch.Tensor:
             scaled = torch.where(wl > lo_w, inv / sc["factor"], inv)
             blend = (1 - smooth) * inv / sc["factor"] + smooth * inv
             inv = torch.where((wl <= lo_w) & (wl >= hi_w), blend, scaled)
-        elif kind not in (None, "default"):
+        elif kind not in (None, "default", "mrope"):  # mrope: plain frequencies, 3 positions
             raise ValueError(f"rope scaling {kind!r} not supported")
     ang = torch.arange(cfg.max_pos, dtype=torch.float32)[:, None] * inv.float()[None, :]
     return torch.cat([ang.cos(), ang.sin()], dim=1).contiguous().to(device)

@@ -75,6 +75,29 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Rotary position of frequency index i (0 <= i < D/2) of token row m of sequence b whose
+// cache position is cache_pos: the cache position itself, or the multimodal one.
+struct RopePos {
+  const int32_t* pos;    // [3][rows] explicit positions, or null
+  const int32_t* delta;  // [B] offset of all three components, or null
+  int s_t, s_th;         // i < s_t: temporal, i < s_th: height, else width
+  int rows;
+};
+__host__ inline RopePos sd_make_rope_pos(const sd_rope_positions* r, int rows) {
+  RopePos o{nullptr, nullptr, 0, 0, rows};
+  if (r) {
+    o.pos = r->pos;
+    o.delta = r->delta;
+    o.s_t = r->section_t;
+    o.s_th = r->section_t + r->section_h;
+  }
+  return o;
+}
+__device__ __forceinline__ int sd_rope_position(const RopePos& r, int cache_pos, int b, int m, int i) {
+  if (r.pos) return r.pos[(size_t)(i < r.s_t ? 0 : (i < r.s_th ? 1 : 2)) * r.rows + m];
+  return r.delta ? cache_pos + r.delta[b] : cache_pos;
+}
+
 // Slot of token t (0..15) inside a V page row: bits 2 and 3 swapped, so that
 // the 8 consecutive slots a lane reads are the keys its accumulator registers
 // hold after the K*Q^T MFMA.

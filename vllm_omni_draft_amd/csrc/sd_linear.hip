@@ -46,6 +46,7 @@ struct RopeArgs {
   int max_blocks;
   const int32_t* seq_lens;
   int pos_offset, q_len, Hq, Hkv, D;
+  RopePos mp;  // multimodal rotary positions (all null: the cache position)
 };
 
 // Attention partials (the workspace layout of sd_paged_attention): per (sequence, KV
@@ -339,7 +340,8 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
             sc1 = a.w_scale[head * D + i + half];
           }
           if (q_pos >= 0 && head < rp.Hq + rp.Hkv && rp.cs) {
-            const float* cs = rp.cs + (size_t)min(q_pos, rp.max_pos - 1) * D;
+            const int r_pos = max(sd_rope_position(rp.mp, q_pos, q_b, m, i), 0);
+            const float* cs = rp.cs + (size_t)min(r_pos, rp.max_pos - 1) * D;
             pre2 = cs[i];
             pre3 = cs[half + i];
           }
@@ -902,9 +904,12 @@ extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void*
                                 void* k_cache, void* v_cache, const int32_t* block_tables,
                                 int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
                                 int B, int q_len, int Hq, int Hkv, int D, int K,
-                                sd_stream_t stream) {
+                                const sd_rope_positions* rope_pos, sd_stream_t stream) {
   SD_REQUIRE(q_out && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
              "sd_norm_qkv_rope: null pointer");
+  SD_REQUIRE(!rope_pos || (rope_pos->section_t >= 0 && rope_pos->section_h >= 0 &&
+                           rope_pos->section_t + rope_pos->section_h <= D / 2),
+             SD_ERR_INVALID, "sd_norm_qkv_rope: rotary sections exceed D/2");
   SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && D % 16 == 0 && D >= 16,
              SD_ERR_INVALID, "sd_norm_qkv_rope: bad shape (D=%d)", D);
   SD_REQUIRE(!rope_cs || max_pos >= 1, SD_ERR_INVALID, "sd_norm_qkv_rope: max_pos < 1");
@@ -916,7 +921,8 @@ extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void*
   a.n_tiles = a.N / 16;
   a.norm_w = (const bf16_t*)norm_w; a.norm_b = (const bf16_t*)norm_b; a.eps = eps;
   a.rope = RopeArgs{rope_cs, max_pos, (bf16_t*)k_cache, (bf16_t*)v_cache, block_tables,
-                    max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D};
+                    max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D,
+                    sd_make_rope_pos(rope_pos, B * q_len)};
   const int norm = norm_w ? (layer_norm ? NORM_LAYER : NORM_RMS) : NORM_NONE;
   return linear_common(a, EPI_QKV_ROPE, norm, (hipStream_t)stream);
 }

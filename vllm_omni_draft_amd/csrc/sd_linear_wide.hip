@@ -49,6 +49,7 @@ struct WideRope {
   int max_blocks;
   const int32_t* seq_lens;
   int pos_offset, q_len, Hq, Hkv, D;
+  RopePos mp;  // multimodal rotary positions (all null: the cache position)
 };
 
 struct WideEpiArgs {
@@ -256,7 +257,6 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
     const int b = m / rp.q_len, t = m - b * rp.q_len;
     const int pos = rp.seq_lens[b] + rp.pos_offset + t;
     if (pos < 0) return;
-    const float* cs = rp.cs ? rp.cs + (size_t)min(pos, rp.max_pos - 1) * D : nullptr;
     const int page = head >= rp.Hq ? rp.block_tables[(size_t)b * rp.max_blocks + (pos >> 4)] : 0;
     const int slot = pos & 15;
 #pragma unroll
@@ -273,7 +273,9 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
       }
       l = round_bf16(l);
       h = round_bf16(h);
-      if (head < rp.Hq + rp.Hkv && cs) {
+      if (head < rp.Hq + rp.Hkv && rp.cs) {
+        const int r_pos = max(sd_rope_position(rp.mp, pos, b, m, i), 0);
+        const float* cs = rp.cs + (size_t)min(r_pos, rp.max_pos - 1) * D;
         const float c = cs[i], sn = cs[half + i];
         const float nl = l * c - h * sn, nh = h * c + l * sn;
         l = nl;
@@ -559,7 +561,8 @@ extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void*
                                 void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
                                 void* k_cache, void* v_cache, const int32_t* block_tables,
                                 int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
-                                int B, int q_len, int Hq, int Hkv, int D, int K, void* workspace,
+                                int B, int q_len, int Hq, int Hkv, int D, int K,
+                                const sd_rope_positions* rope_pos, void* workspace,
                                 size_t workspace_bytes, sd_stream_t stream) {
   SD_REQUIRE(q_out && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
              "sd_qkv_rope_wide: null pointer");
@@ -567,6 +570,9 @@ extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void*
              SD_ERR_INVALID, "sd_qkv_rope_wide: bad shape (D=%d)", D);
   SD_REQUIRE(!rope_cs || max_pos >= 1, SD_ERR_INVALID, "sd_qkv_rope_wide: max_pos < 1");
   SD_REQUIRE(ldq >= (int64_t)Hq * D, SD_ERR_INVALID, "sd_qkv_rope_wide: ldq too small");
+  SD_REQUIRE(!rope_pos || (rope_pos->section_t >= 0 && rope_pos->section_h >= 0 &&
+                           rope_pos->section_t + rope_pos->section_h <= D / 2),
+             SD_ERR_INVALID, "sd_qkv_rope_wide: rotary sections exceed D/2");
   const int N = (Hq + 2 * Hkv) * D;
   WideEpiArgs e{};
   e.N = N;
@@ -575,7 +581,8 @@ extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void*
   e.out = q_out;
   e.ldo = ldq;
   e.rope = WideRope{rope_cs, max_pos, (bf16_t*)k_cache, (bf16_t*)v_cache, block_tables,
-                    max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D};
+                    max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D,
+                    sd_make_rope_pos(rope_pos, B * q_len)};
   return wide_common(W, x, ldx, B * q_len, K, N / 16, EPI_QKV_ROPE, e, workspace, workspace_bytes,
                      (hipStream_t)stream);
 }

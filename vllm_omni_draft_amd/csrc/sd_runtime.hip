@@ -82,6 +82,13 @@ extern "C" sd_model* sd_model_create(const sd_model_desc* desc) {
     sd_set_error("sd_model_create: lm_vocab %d must be 0 or a multiple of 16 up to vocab", d.lm_vocab);
     return nullptr;
   }
+  if (d.mrope_section_t < 0 || d.mrope_section_h < 0 ||
+      d.mrope_section_t + d.mrope_section_h > d.head_dim / 2 ||
+      ((d.mrope_section_t || d.mrope_section_h) && d.arch != SD_ARCH_LLAMA)) {
+    sd_set_error("sd_model_create: rotary sections %d, %d need a rotary model and t + h <= D/2",
+                 d.mrope_section_t, d.mrope_section_h);
+    return nullptr;
+  }
   if (d.arch == SD_ARCH_LLAMA && !d.rope_cs) {
     sd_set_error("sd_model_create: llama arch needs a rope table");
     return nullptr;
@@ -181,7 +188,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   SD_REQUIRE(a->q_len * (d.n_heads / d.n_kv_heads) <= 64 || (wide && a->B == 1), SD_ERR_UNSUPPORTED,
              "sd_model_forward: q_len %d * (Hq/Hkv) > 64 needs the wide family and one sequence",
              a->q_len);
-  SD_REQUIRE(a->token_ids && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
+  SD_REQUIRE((a->token_ids || a->input_embeds) && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
              SD_ERR_INVALID, "sd_model_forward: null buffer");
   SD_REQUIRE(a->max_ctx >= 1 && a->max_ctx <= d.max_pos, SD_ERR_INVALID,
              "sd_model_forward: max_ctx %d outside 1..max_pos %d", a->max_ctx, d.max_pos);
@@ -201,8 +208,23 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const int64_t qkv_cols = (int64_t)(Hq + 2 * Hkv) * D;
   const bool llama = d.arch == SD_ARCH_LLAMA;
 
-  SD_TRY(sd_embed(a->token_ids, a->tok_stride, a->tok_offset, d.embed, d.embed_tiled, d.pos_table, d.pos_bias,
-                  a->seq_lens, a->pos_offset, h, a->B, a->q_len, H, d.vocab, stream));
+  if (a->input_embeds) {
+    // rows given by the caller (image embeddings merged into the token embeddings)
+    SD_REQUIRE(llama, SD_ERR_UNSUPPORTED, "sd_model_forward: input_embeds need a rotary model");
+    const hipError_t e = hipMemcpyAsync(h, a->input_embeds, (size_t)rows * H * 2,
+                                        hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    SD_REQUIRE(e == hipSuccess, SD_ERR_HIP, "sd_model_forward: copying input_embeds: %s",
+               hipGetErrorString(e));
+  } else {
+    SD_TRY(sd_embed(a->token_ids, a->tok_stride, a->tok_offset, d.embed, d.embed_tiled, d.pos_table,
+                    d.pos_bias, a->seq_lens, a->pos_offset, h, a->B, a->q_len, H, d.vocab, stream));
+  }
+  // multimodal rotary positions, for a model that has sections
+  const bool mrope = d.mrope_section_t || d.mrope_section_h;
+  const sd_rope_positions rope_pos{a->rope_pos, a->rope_delta, d.mrope_section_t, d.mrope_section_h};
+  const sd_rope_positions* rpp = mrope && (a->rope_pos || a->rope_delta) ? &rope_pos : nullptr;
+  SD_REQUIRE(mrope || (!a->rope_pos && !a->rope_delta), SD_ERR_INVALID,
+             "sd_model_forward: rotary positions given to a model without rotary sections");
   for (int li = 0; li < d.n_layers; ++li) {
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
@@ -218,7 +240,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       SD_TRY(sd_qkv_rope_wide(l.qkv_w, l.qkv_s, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
                               llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
                               kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
-                              Hq, Hkv, D, H, wws, w.wide_ws_bytes, stream));
+                              Hq, Hkv, D, H, rpp, wws, w.wide_ws_bytes, stream));
       // One attention launch covers 64 / (Hq/Hkv) query tokens of a sequence; a longer chunk
       // of ONE sequence (prefill) is walked in blocks of that many tokens (their K/V is in
       // the cache already, the causal mask is per row).
@@ -248,14 +270,14 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       SD_TRY(sd_norm_qkv_rope(l.qkv_w, l.qkv_s, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
                               l.qkv_b, qkv, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos,
                               kc, vc, kv->block_tables, kv->max_blocks_per_seq, a->seq_lens,
-                              a->pos_offset, a->B, a->q_len, Hq, Hkv, D, H, stream));
+                              a->pos_offset, a->B, a->q_len, Hq, Hkv, D, H, rpp, stream));
     } else {
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
       SD_TRY(sd_norm_qkv_rope(l.qkv_w, l.qkv_s, xn, H, nullptr, nullptr, 0.f, 0, l.qkv_b, qkv,
                               (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos, kc, vc,
                               kv->block_tables, kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
-                              a->B, a->q_len, Hq, Hkv, D, H, stream));
+                              a->B, a->q_len, Hq, Hkv, D, H, rpp, stream));
     }
     // With few rows and splits the output projection merges the attention partials itself
     // (every workgroup redoes the small merge) and the merge launch is saved.

@@ -158,6 +158,9 @@ class SpecEngine:
         # synchronisation and no copy.
         # two records: with overlapped read-back (step_overlapped) a step writes one while
         # the host still reads the other
+        # Multimodal rotary embedding: rotary position of a generated token = its cache
+        # position + the delta its prompt's image tokens left behind (0 for text prompts)
+        self.rope_delta = torch.zeros(B, dtype=torch.int32, device=dev)
         self._records = torch.full((2, B, k + 3), -1, dtype=torch.int32).pin_memory()
         self._parity = 0
         self._inflight = None   # (event, record parity, sequences) of a step not yet read back
@@ -225,13 +228,20 @@ class SpecEngine:
         self.accept_seed = int(seed)
         self._drop_graphs()
 
-    def add_request(self, slot: int, prompt: Sequence[int]) -> int:
+    def add_request(self, slot: int, prompt: Sequence[int],
+                    input_embeds: Optional[torch.Tensor] = None,
+                    rope_positions: Optional[torch.Tensor] = None) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
-        first token from the target and returns it (this synchronises)."""
+        first token from the target and returns it (this synchronises).
+        Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
+        [len(prompt), hidden] bf16 are the target's input rows (image embeddings in the
+        placeholder tokens' places; the draft still embeds the token ids), rope_positions
+        [3, len(prompt)] the rotary positions for models with mrope_section."""
         with torch.cuda.stream(self.stream):
-            return self._add_request(slot, prompt)
+            return self._add_request(slot, prompt, input_embeds, rope_positions)
 
-    def _add_request(self, slot: int, prompt: Sequence[int]) -> int:
+    def _add_request(self, slot: int, prompt: Sequence[int], input_embeds=None,
+                     rope_positions=None) -> int:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
         n = len(prompt)
@@ -243,6 +253,19 @@ class SpecEngine:
         if self.d_kv is not None:
             self.d_kv.ensure_capacity(slot, n + self.k + 2)
         self.prompt_buf[:n].copy_(torch.tensor(list(prompt), dtype=torch.int32))
+        delta = 0
+        if rope_positions is not None:
+            if not self.target.cfg.mrope_section:
+                raise ValueError("rope_positions need a target with mrope_section")
+            if tuple(rope_positions.shape) != (3, n):
+                raise ValueError(f"rope_positions must be [3, {n}]")
+            delta = int(rope_positions.max().item()) + 1 - n
+            rope_positions = rope_positions.to(device=self.device, dtype=torch.int32)
+        if input_embeds is not None:
+            if tuple(input_embeds.shape) != (n, self.target.cfg.hidden):
+                raise ValueError(f"input_embeds must be [{n}, {self.target.cfg.hidden}]")
+            input_embeds = input_embeds.to(device=self.device, dtype=torch.bfloat16)
+        self.rope_delta[slot] = delta
         self._ctx = self._ctx_bucket(n + self.k + 2)
         zl = self.zero_lens[slot:slot + 1]
         for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
@@ -256,8 +279,13 @@ class SpecEngine:
             for c0, c1 in zip(bounds, bounds[1:] + [n]):
                 want = c1 == n and model is self.target
                 view = _KvView(kv, slot)
+                mm = {}
+                if rope_positions is not None and model.cfg.mrope_section:
+                    mm["rope_pos"] = rope_positions[:, c0:c1].contiguous()
+                if input_embeds is not None and model is self.target:
+                    mm["input_embeds"] = input_embeds[c0:c1].contiguous()
                 model.forward(view, self.prompt_buf, 0, c0, zl, c0, 1, c1 - c0,
-                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=wide)
+                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=wide, **mm)
         # first generated token from the last prompt row (a 1-token pass: row 0)
         if self.sampling:
             self._target_full_rows(1)
@@ -291,8 +319,10 @@ class SpecEngine:
             if logits is not None:
                 sub_logits = logits[b0 * q_len:(b0 + nb) * q_len]
             view = _KvView(kv, slot0 + b0)
+            delta = self.rope_delta[slot0 + b0:] if model.cfg.mrope_section else None
             model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens, tok_stride,
-                          tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self._ctx)
+                          tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self._ctx,
+                          rope_delta=delta)
 
     def _enqueue_step(self) -> None:
         """One whole step: propose (k draft passes), score (one target pass),
@@ -504,7 +534,8 @@ class SpecEngine:
                 if slot != last:
                     kv.move_slot(last, slot)
             if slot != last:
-                for t in (self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts):
+                for t in (self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts,
+                          self.rope_delta):
                     t[slot].copy_(t[last])
                 self.host_lens[slot], self.host_gen[slot] = self.host_lens[last], self.host_gen[last]
                 if self.ngram:

@@ -68,7 +68,9 @@ class DecoderModel:
             tp_rank=tp_group.rank if tp_group else 0,
             allreduce=tp_group.allreduce_ptr if tp_group else None,
             allreduce_ctx=tp_group.ctx_ptr if tp_group else None,
-            weight_fp8=int(fp8), lm_head_s=_ptr(weights.lm_head.scale), lm_vocab=cfg.lm_vocab)
+            weight_fp8=int(fp8), lm_head_s=_ptr(weights.lm_head.scale), lm_vocab=cfg.lm_vocab,
+            mrope_section_t=cfg.mrope_section[0] if cfg.mrope_section else 0,
+            mrope_section_h=cfg.mrope_section[1] if cfg.mrope_section else 0)
         self._handle = lib.sd_model_create(C.byref(desc))
         if not self._handle:
             raise _lib.SdError(f"sd_model_create failed: {_lib.last_error()}")
@@ -88,11 +90,28 @@ class DecoderModel:
     def forward(self, kv: PagedKVCache, token_ids: torch.Tensor, tok_stride: int, tok_offset: int,
                 seq_lens: torch.Tensor, pos_offset: int, B: int, q_len: int,
                 logits: Optional[torch.Tensor], max_ctx: Optional[int] = None,
-                wide: Optional[bool] = None) -> None:
+                wide: Optional[bool] = None, input_embeds: Optional[torch.Tensor] = None,
+                rope_pos: Optional[torch.Tensor] = None,
+                rope_delta: Optional[torch.Tensor] = None) -> None:
         """Enqueues one pass over B*q_len token rows on the current stream.
         Token t of sequence b is token_ids[b*tok_stride + tok_offset + t] at
         position seq_lens[b] + pos_offset + t.  `logits` ([B*q_len, vocab] f32)
-        may be None to skip the LM head."""
+        may be None to skip the LM head.  Multimodal prompts: input_embeds (bf16
+        [B*q_len, hidden]) replace the embedding lookup; a model with mrope_section takes
+        its rotary positions from rope_pos (int32 [3, B*q_len]) or, for text after an image,
+        from the cache position + rope_delta[b] (int32 [B])."""
+        rows = B * q_len
+        if input_embeds is not None and (input_embeds.dtype != torch.bfloat16
+                                         or not input_embeds.is_contiguous()
+                                         or tuple(input_embeds.shape) != (rows, self.cfg.hidden)):
+            raise _lib.SdError("input_embeds must be a contiguous bfloat16 [B*q_len, hidden] tensor")
+        if rope_pos is not None and (rope_pos.dtype != torch.int32 or not rope_pos.is_contiguous()
+                                     or tuple(rope_pos.shape) != (3, rows)):
+            raise _lib.SdError("rope_pos must be a contiguous int32 [3, B*q_len] tensor")
+        if rope_delta is not None and (rope_delta.dtype != torch.int32 or rope_delta.numel() < B):
+            raise _lib.SdError("rope_delta must be an int32 tensor of at least B entries")
+        if (rope_pos is not None or rope_delta is not None) and not self.cfg.mrope_section:
+            raise _lib.SdError("rotary positions given to a model without mrope_section")
         if token_ids.dtype != torch.int32 or seq_lens.dtype != torch.int32:
             raise _lib.SdError("token_ids and seq_lens must be int32 device tensors")
         if logits is not None and (logits.dtype != torch.float32 or not logits.is_contiguous()
@@ -106,7 +125,9 @@ class DecoderModel:
                                 tok_stride=tok_stride, tok_offset=tok_offset,
                                 seq_lens=seq_lens.data_ptr(), pos_offset=pos_offset,
                                 max_ctx=max_ctx or self.max_ctx, split_tokens=self.split_tokens,
-                                logits=_ptr(logits), wide=int(self.wide if wide is None else wide))
+                                logits=_ptr(logits), wide=int(self.wide if wide is None else wide),
+                                input_embeds=_ptr(input_embeds), rope_pos=_ptr(rope_pos),
+                                rope_delta=_ptr(rope_delta))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           self.workspace.data_ptr(), self.workspace.numel(),
                                           torch.cuda.current_stream().cuda_stream)

@@ -354,8 +354,27 @@ def linear_wide(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None,
     return out
 
 
+def _rope_positions(rope_pos, rope_delta, mrope_section, rows):
+    """ctypes sd_rope_positions (or None): rope_pos int32 [3, rows], rope_delta int32 [B],
+    mrope_section = (temporal, height, width) frequency counts."""
+    if rope_pos is None and rope_delta is None:
+        return None
+    if mrope_section is None:
+        raise _lib.SdError("rotary positions need mrope_section")
+    if rope_pos is not None:
+        _need(rope_pos, torch.int32, "rope_pos")
+        if tuple(rope_pos.shape) != (3, rows) or not rope_pos.is_contiguous():
+            raise _lib.SdError(f"rope_pos must be a contiguous int32 [3, {rows}] tensor")
+    if rope_delta is not None:
+        _need(rope_delta, torch.int32, "rope_delta")
+    import ctypes as C
+    return C.byref(_lib.RopePositions(pos=_p(rope_pos), delta=_p(rope_delta),
+                                      section_t=int(mrope_section[0]), section_h=int(mrope_section[1])))
+
+
 def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens, pos_offset, B,
-                  q_len, Hq, Hkv, D, workspace=None) -> torch.Tensor:
+                  q_len, Hq, Hkv, D, workspace=None, rope_pos=None, rope_delta=None,
+                  mrope_section=None) -> torch.Tensor:
     """QKV projection + rotary embedding + cache append for up to 256 token rows; returns q."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, EPI_STORE, D)
@@ -368,7 +387,8 @@ def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens,
     _lib.check(_lib.load().sd_qkv_rope_wide(
         _p(Wt.data), _p(Wt.scale), _p(x), x.stride(0), _p(bias), _p(q), Hq * D, _p(rope_cs),
         0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache), _p(block_tables),
-        block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K, _p(workspace),
+        block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
+        _rope_positions(rope_pos, rope_delta, mrope_section, M), _p(workspace),
         workspace.numel(), _stream()), "sd_qkv_rope_wide")
     return q
 
@@ -488,6 +508,18 @@ def verify_from_partials(part_val, part_idx, tok_buf, out_ids, counters, seq_len
         _stream()), "sd_verify_from_partials")
 
 
+def embed_tokens(ids: torch.Tensor, table: torch.Tensor, tiled: bool, hidden: int,
+                 vocab: int) -> torch.Tensor:
+    """Rows of the token embedding table ([vocab, hidden] bf16, row-major or in the PLAIN tile
+    layout of a tied LM head) for int32 ids [n]; returns [n, hidden] bf16."""
+    _need(ids, torch.int32, "ids")
+    n = ids.numel()
+    out = torch.empty(n, hidden, dtype=torch.bfloat16, device=ids.device)
+    _lib.check(_lib.load().sd_embed(_p(ids), 1, 0, _p(table), int(tiled), None, 0, None, 0, _p(out),
+                                    n, 1, hidden, vocab, _stream()), "sd_embed")
+    return out
+
+
 def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None,
                 epilogue=EPI_STORE, out=None) -> torch.Tensor:
     """linear(norm(x)) in one kernel (RMSNorm, or LayerNorm when layer_norm)."""
@@ -506,7 +538,8 @@ def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None
 
 
 def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache, v_cache,
-                  block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D) -> torch.Tensor:
+                  block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D, rope_pos=None,
+                  rope_delta=None, mrope_section=None) -> torch.Tensor:
     """norm -> QKV projection -> rotary -> cache append; returns rotated q [B*q_len, Hq*D]."""
     _need(x, torch.bfloat16, "x")
     _need(block_tables, torch.int32, "block_tables")
@@ -521,5 +554,5 @@ def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache,
         _p(bias), _p(q),
         Hq * D, _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache),
         _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
-        _stream()), "sd_norm_qkv_rope")
+        _rope_positions(rope_pos, rope_delta, mrope_section, M), _stream()), "sd_norm_qkv_rope")
     return q

@@ -100,9 +100,24 @@ def _embed_and_head(embed: torch.Tensor, head, device, fp8: bool = False):
     return embed, _tile_matrix(_dev(head, device), fp8=fp8), False
 
 
+def language_model_state(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """The language model's tensors of a Qwen2-VL style checkpoint under the names of a text
+    checkpoint: "model.language_model.X" -> "model.X", the vision tower ("visual.",
+    "model.visual.") dropped.  Text checkpoints pass through unchanged."""
+    out = {}
+    for name, t in state.items():
+        if name.startswith(("visual.", "model.visual.")):
+            continue
+        if name.startswith("model.language_model."):
+            name = "model." + name[len("model.language_model."):]
+        out[name] = t
+    return out
+
+
 def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cuda",
                     fp8: bool = False) -> ModelWeights:
     cfg.validate()
+    state = language_model_state(state)
 
     def _tile(w, mode=ops.TILE_PLAIN, head_dim=0):  # every layer matrix alike
         return _tile_matrix(w, mode, head_dim, fp8=fp8)
