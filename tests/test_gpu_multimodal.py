@@ -274,3 +274,59 @@ def test_removing_a_request_moves_its_delta():
     while len(out) < 24:
         out.extend(eng.step()[0])
     assert out[:24] == alone
+
+
+def test_worker_runs_pixel_patches_through_the_vision_tower():
+    """execute_model with pixel patches (vision tower on the GPU, bf16) gives the stream of the
+    same prompt fed with the tower's rows, and speculative == autoregressive."""
+    from vllm_omni_draft_amd import multimodal
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                         SpecDecodeConfig, SpecDecodeWorker)
+    from vllm_omni_draft_amd.vision import VisionConfig, VisionTower, patchify
+    vcfg = VisionConfig(depth=2, embed_dim=64, num_heads=4, mlp_ratio=2, hidden_size=VL.hidden,
+                        patch_size=4)
+    gen = torch.Generator().manual_seed(5)
+    E, M = vcfg.embed_dim, vcfg.embed_dim * 4
+    shapes = {"patch_embed.proj.weight": (E, 3, 2, 4, 4), "merger.ln_q.weight": (E,),
+              "merger.ln_q.bias": (E,), "merger.mlp.0.weight": (M, M), "merger.mlp.0.bias": (M,),
+              "merger.mlp.2.weight": (VL.hidden, M), "merger.mlp.2.bias": (VL.hidden,)}
+    for i in range(vcfg.depth):
+        b = f"blocks.{i}."
+        shapes.update({b + "norm1.weight": (E,), b + "norm1.bias": (E,), b + "norm2.weight": (E,),
+                       b + "norm2.bias": (E,), b + "attn.qkv.weight": (3 * E, E),
+                       b + "attn.qkv.bias": (3 * E,), b + "attn.proj.weight": (E, E),
+                       b + "attn.proj.bias": (E,), b + "mlp.fc1.weight": (2 * E, E),
+                       b + "mlp.fc1.bias": (2 * E,), b + "mlp.fc2.weight": (E, 2 * E),
+                       b + "mlp.fc2.bias": (E,)})
+    vstate = {"visual." + k: torch.randn(*shp, generator=gen) * 0.08 + (1.0 if k.endswith("norm1.weight")
+              or k.endswith("norm2.weight") or k.endswith("ln_q.weight") else 0.0) for k, shp in shapes.items()}
+    tower = VisionTower(vcfg, vstate, device="cuda")
+    image = torch.randn(3, 16, 16, generator=gen)
+    patches, grid = patchify(image, vcfg)
+    rows = tower.forward(patches, [grid])
+    assert rows.shape == (multimodal.image_token_count(grid), VL.hidden) and rows.dtype == torch.bfloat16
+    assert torch.isfinite(rows.float()).all() and rows.float().abs().max() > 0
+
+    state = _bf(random_state(VL, seed=41, qkv_bias=True))
+    tw = _product(VL, state, qkv_bias=True)
+    dw = _product(DRAFT, _bf(random_state(DRAFT, seed=42)))
+    ids = [3, 4] + [IMG] * multimodal.image_token_count(grid) + [5, 6, 7]
+
+    def run(k, mm):
+        w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=dw if k else None, num_speculative_tokens=k,
+                                              max_num_seqs=1, max_model_len=120, split_tokens=128,
+                                              vision=tower, image_token_id=IMG))
+        w.init_device()
+        w.load_model()
+        out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata(
+            "r", True, ids, multi_modal_data=mm)])).sampled_token_ids[0]
+        while len(out) < 30:
+            out += w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", False)])).sampled_token_ids[0]
+        return out[:30]
+
+    via_pixels = run(3, {"pixel_values": patches, "image_grid_thw": [grid]})
+    via_rows = run(3, {"image_embeds": rows, "image_grid_thw": [grid]})
+    ar = run(0, {"pixel_values": patches, "image_grid_thw": [grid]})
+    assert via_pixels == via_rows == ar
+    text_only = run(0, None)
+    assert text_only != ar          # the image rows and positions reach the model

@@ -132,3 +132,60 @@ def test_config_reads_mrope_sections_and_checkpoint_names():
           "visual.merger.y": torch.zeros(1), "lm_head.weight": torch.zeros(1)}
     assert sorted(weights.language_model_state(st)) == [
         "lm_head.weight", "model.layers.0.mlp.up_proj.weight", "model.norm.weight"]
+
+
+def _tiny_vision():
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import (Qwen2VisionTransformerPretrainedModel,
+                                                                  Qwen2VLVisionConfig)
+    from vllm_omni_draft_amd.vision import VisionConfig
+    hc = Qwen2VLVisionConfig(depth=2, embed_dim=64, hidden_size=96, num_heads=4, mlp_ratio=2,
+                             in_channels=3, patch_size=4, spatial_merge_size=2, temporal_patch_size=2,
+                             hidden_act="quick_gelu", attn_implementation="eager")
+    torch.manual_seed(3)
+    hf = Qwen2VisionTransformerPretrainedModel(hc).eval()
+    for p in hf.parameters():          # default init leaves LayerNorms trivial: perturb everything
+        p.data.add_(torch.randn_like(p) * 0.05)
+    cfg = VisionConfig(depth=2, embed_dim=64, num_heads=4, mlp_ratio=2, hidden_size=96, patch_size=4)
+    return hf, cfg
+
+
+def test_vision_tower_matches_transformers():
+    from vllm_omni_draft_amd.vision import VisionTower, patchify
+    hf, cfg = _tiny_vision()
+    state = {"visual." + k: v for k, v in hf.state_dict().items()}
+    tower = VisionTower(cfg, state, device="cpu", dtype=torch.float32)
+    gen = torch.Generator().manual_seed(1)
+    images = [torch.randn(3, 16, 24, generator=gen), torch.randn(3, 8, 8, generator=gen)]
+    parts = [patchify(im, cfg) for im in images]
+    patches = torch.cat([p for p, _ in parts])
+    grids = [g for _, g in parts]
+    assert grids == [(1, 4, 6), (1, 2, 2)]
+    got = tower.forward(patches, grids)
+    with torch.no_grad():
+        ref = hf(patches, grid_thw=torch.tensor(grids)).pooler_output
+    assert got.shape == (sum(multimodal.image_token_count(g) for g in grids), 96)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    # a two-frame grid (video): attention stays inside a frame
+    vid = torch.randn(2 * 16, patches.shape[1], generator=gen)
+    got = tower.forward(vid, [(2, 4, 4)])
+    with torch.no_grad():
+        ref = hf(vid, grid_thw=torch.tensor([[2, 4, 4]])).pooler_output
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    with pytest.raises(ValueError):
+        tower.forward(patches[:-1], grids)
+    with pytest.raises(ValueError):
+        VisionTower(cfg, {"visual.patch_embed.proj.weight": torch.zeros(1)}, device="cpu")
+
+
+def test_patchify_matches_the_image_processor_layout():
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
+    from vllm_omni_draft_amd.vision import VisionConfig, patchify
+    cfg = VisionConfig(patch_size=4)
+    img = torch.arange(3 * 16 * 24, dtype=torch.float32).view(3, 16, 24)
+    ref, gh, gw = Qwen2VLImageProcessorPil.patchify(None, img.numpy(), patch_size=4, merge_size=2,
+                                                    temporal_patch_size=2)
+    patches, grid = patchify(img, cfg)
+    assert tuple(grid) == (1, gh, gw)
+    assert torch.equal(patches, torch.from_numpy(ref.copy()))
+    with pytest.raises(ValueError):
+        patchify(torch.zeros(3, 12, 16), cfg)

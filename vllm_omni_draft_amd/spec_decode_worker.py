@@ -48,6 +48,11 @@ class SequenceGroupMetadata:
     is_prompt: bool
     prompt_token_ids: List[int] = field(default_factory=list)
     sampling_params: SamplingParams = field(default_factory=SamplingParams)
+    # Prompts with images (a target with mrope_section): {"image_grid_thw": [(t, h, w), ...]}
+    # plus either "pixel_values" (patch rows for SpecDecodeConfig.vision, image processor
+    # layout) or "image_embeds" (the vision tower's output rows); the prompt holds one run of
+    # placeholder tokens per image.
+    multi_modal_data: Optional[dict] = None
 
 
 @dataclass
@@ -288,6 +293,10 @@ class SpecDecodeConfig:
     # under tensor parallelism each rank holds vocab / tp rows of the LM head and the ranks
     # exchange slice maxima (greedy) or gather rows (sampling) instead of replicating the head
     vocab_parallel_lm_head: bool = True
+    # prompts with images: the vision tower (vision.VisionTower) that turns pixel patches into
+    # input rows of the target, and the tokenizer's placeholder token
+    vision: Optional[object] = None
+    image_token_id: int = 151655
 
 
 class SpecDecodeWorker:
@@ -398,7 +407,7 @@ class SpecDecodeWorker:
             if eng.active >= eng.cfg.max_batch:
                 raise RuntimeError("no free sequence slot (max_num_seqs reached)")
             slot = eng.active
-            first = eng.add_request(slot, g.prompt_token_ids)
+            first = eng.add_request(slot, g.prompt_token_ids, *self._multimodal_inputs(g))
             self._slot_of[g.request_id] = slot
             self._req_at.append(g.request_id)
             out[g.request_id] = [first]
@@ -407,6 +416,23 @@ class SpecDecodeWorker:
             req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
             sampled_token_ids=[out[r] for r in ids],
             spec_decode_metrics=self.metrics.maybe_collect() if self.metrics else None)
+
+    def _multimodal_inputs(self, g: SequenceGroupMetadata):
+        """(input_embeds, rope_positions) of a prompt, (None, None) for plain text."""
+        mm = g.multi_modal_data
+        if not mm:
+            return None, None
+        from . import multimodal
+        c = self.config
+        grids = [tuple(int(v) for v in row) for row in mm["image_grid_thw"]]
+        rows = mm.get("image_embeds")
+        if rows is None:
+            if c.vision is None:
+                raise ValueError("pixel_values need SpecDecodeConfig.vision (a vision tower)")
+            rows = c.vision.forward(mm["pixel_values"], grids)
+        return multimodal.prepare_prompt(g.prompt_token_ids, self.engine.target.weights, rows, grids,
+                                         image_token_id=c.image_token_id,
+                                         spatial_merge=c.vision.cfg.spatial_merge_size if c.vision else 2)
 
     def _run_speculative_decoding_step(self, req: ExecuteModelRequest) -> List[List[int]]:
         """propose -> score -> verify, as one replayed graph when enabled."""
