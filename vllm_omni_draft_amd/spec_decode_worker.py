@@ -407,7 +407,7 @@ class SpecDecodeWorker:
             if eng.active >= eng.cfg.max_batch:
                 raise RuntimeError("no free sequence slot (max_num_seqs reached)")
             slot = eng.active
-            first = eng.add_request(slot, g.prompt_token_ids, *self._multimodal_inputs(g))
+            first = eng.add_request(slot, g.prompt_token_ids, **self._multimodal_inputs(g))
             self._slot_of[g.request_id] = slot
             self._req_at.append(g.request_id)
             out[g.request_id] = [first]
@@ -418,10 +418,11 @@ class SpecDecodeWorker:
             spec_decode_metrics=self.metrics.maybe_collect() if self.metrics else None)
 
     def _multimodal_inputs(self, g: SequenceGroupMetadata):
-        """(input_embeds, rope_positions) of a prompt, (None, None) for plain text."""
+        """add_request's input_embeds and rope_positions of a prompt with images; nothing for
+        plain text."""
         mm = g.multi_modal_data
         if not mm:
-            return None, None
+            return {}
         from . import multimodal
         c = self.config
         grids = [tuple(int(v) for v in row) for row in mm["image_grid_thw"]]
@@ -430,9 +431,10 @@ class SpecDecodeWorker:
             if c.vision is None:
                 raise ValueError("pixel_values need SpecDecodeConfig.vision (a vision tower)")
             rows = c.vision.forward(mm["pixel_values"], grids)
-        return multimodal.prepare_prompt(g.prompt_token_ids, self.engine.target.weights, rows, grids,
-                                         image_token_id=c.image_token_id,
-                                         spatial_merge=c.vision.cfg.spatial_merge_size if c.vision else 2)
+        embeds, pos = multimodal.prepare_prompt(
+            g.prompt_token_ids, self.engine.target.weights, rows, grids, image_token_id=c.image_token_id,
+            spatial_merge=c.vision.cfg.spatial_merge_size if c.vision else 2)
+        return {"input_embeds": embeds, "rope_positions": pos}
 
     def _run_speculative_decoding_step(self, req: ExecuteModelRequest) -> List[List[int]]:
         """propose -> score -> verify, as one replayed graph when enabled."""
