@@ -292,13 +292,21 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    # Rehearsal of the multi-rank flow on a box with one GPU: SD_BENCH_BACKEND=gloo puts the
+    # barrier and the reductions on the CPU, SD_BENCH_DEVICE=0 lets every rank share card 0.
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")
+    local = int(os.environ.get("SD_BENCH_DEVICE", local))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    red_device = device if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if dist is not None:
@@ -350,9 +358,9 @@ def main():
     eng, main_res = spec_run(args.accept_prob, args.steps, args.warmup)
     tokens, dt = main_res["tokens"], main_res["seconds"]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        n = torch.tensor([tokens, int(main_res["exact"])], dtype=torch.float64, device=device)
+        n = torch.tensor([tokens, int(main_res["exact"])], dtype=torch.float64, device=red_device)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         dt, tokens = float(t.item()), float(n[0].item())
         all_exact = int(n[1].item()) == world
