@@ -7,5 +7,5 @@ OUT=$ROOT/gpurun_out/batch_profile
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o batch -- \
-  python3 $ROOT/experiments/bench_batch.py 32 256 > $OUT/bench.log 2>&1
+  python3 $ROOT/experiments/bench_batch.py 32 256 ${DRAFT_ROWS:-auto} > $OUT/bench.log 2>&1
 head -30 $OUT/stats/batch_kernel_stats.csv
