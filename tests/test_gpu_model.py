@@ -441,3 +441,28 @@ def test_disable_by_batch_size_keeps_streams_and_draft_cache(use_graph):
     m = eng.metrics()
     assert m["draft"] > 0 and m["accepted"] == m["draft"]
     assert [o[:40] for o in outs] == ar[:2] and done == ar[2][:len(done)]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_narrow_draft_sub_batches_on_parallel_streams(use_graph):
+    """20 sequences: the narrow draft's passes run as sub-batches of 16 rows on parallel
+    streams (forked and joined inside the step).  The stream equals the autoregressive one and
+    the one with the sub-batches in sequence, and the proposals are the same either way."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    g = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(0, tcfg.vocab, (int(n),), generator=g).tolist()
+               for n in torch.randint(3, 40, (20,), generator=g)]
+    kw = dict(max_batch=20, use_graph=use_graph, rows="wide")
+    ar = _generate(_engine(tw, None, 0, **kw), prompts, 30)
+    results = []
+    for lanes in (4, 1):
+        eng = _engine(tw, dw, 3, draft_rows="narrow", draft_lanes=lanes, **kw)
+        assert len(eng._lanes) == (2 if lanes > 1 else 0)     # 40 rows of the first pass: 3 lanes
+        assert _generate(eng, prompts, 30) == ar
+        results.append(eng.metrics())
+    assert results[0] == results[1]
+    auto = _engine(tw, dw, 3, **kw)
+    assert not auto.draft.wide and auto._lanes      # the default picks this path at 20 sequences

@@ -47,11 +47,17 @@ class EngineConfig:
     # engine that is to reproduce a speculative engine's stream must be given the same one.
     rows: str = "auto"
     # Kernel family of the draft model's passes: "narrow", "wide", "same" as the target's, or
-    # "auto": narrow while one token per sequence fits a narrow pass (max_batch <= 16), else
-    # the target's.  The draft's rounding never shows in the output (only in what gets
-    # proposed), so its family may differ from the target's; measured at 8 sequences the
-    # narrow draft makes the step 18 % shorter, at 32 (two sub-batches per pass) 26 % longer.
+    # "auto": narrow up to 32 sequences (beyond 16 as two sub-batches on parallel streams, see
+    # draft_lanes), else the target's.  The draft's rounding never shows in the output (only
+    # in what gets proposed), so its family may differ from the target's; measured with a
+    # 0.5B draft the narrow draft makes the step 18 % shorter at 8 sequences, 6 % at 24 and
+    # 1 % at 32 (26 % longer there with the sub-batches one after the other).
     draft_rows: str = "auto"
+    # Sub-batches of a narrow draft pass (batches beyond 16 sequences) run on this many HIP
+    # streams at once (forked and joined inside the step, also under graph capture): the small
+    # kernels of a small draft model leave most of the chip idle, so two sub-batches overlap
+    # almost completely.  1 = one after the other.
+    draft_lanes: int = 4
     # Prompt-lookup proposals instead of a draft model (k > 0, draft = None): the last
     # ngram_max..ngram_min tokens of a sequence are searched in its own history and the k
     # tokens after the most recent match are proposed (none if nothing matches).
@@ -103,12 +109,21 @@ class SpecEngine:
         if cfg.draft_rows not in ("auto", "same", "narrow", "wide"):
             raise ValueError("draft_rows must be 'auto', 'same', 'narrow' or 'wide'")
         if cfg.draft_rows == "auto":
-            draft_wide = self.wide and B > MAX_ROWS
+            draft_wide = self.wide and B > 2 * MAX_ROWS
         else:
             draft_wide = self.wide if cfg.draft_rows == "same" else cfg.draft_rows == "wide"
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
                                    wide=draft_wide) if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
+        self._lanes: List[torch.cuda.Stream] = []
+        self._lane_ws: List[torch.Tensor] = []
+        if self.draft is not None and not self.draft.wide and cfg.draft_lanes > 1:
+            n_sub = -(-2 * B // self.draft.max_rows)      # the first pass carries 2 tokens per sequence
+            n = min(cfg.draft_lanes, n_sub)
+            if n > 1:
+                self._lanes = [torch.cuda.Stream(device=dev) for _ in range(n - 1)]
+                self._lane_ws = [self.draft.workspace] + [torch.empty_like(self.draft.workspace)
+                                                          for _ in range(n - 1)]
         self.V = target.cfg.vocab
         pages = PagedKVCache.pages_for(target.cfg, B, self.max_ctx)
         self.t_kv = PagedKVCache(target.cfg, pages, B, self.max_ctx, dev)
@@ -313,16 +328,34 @@ class SpecEngine:
         """One model pass over B sequences x q_len tokens, in sub-batches of at
         most max_rows token rows."""
         per = max(1, model.max_rows // q_len)
-        for b0 in range(0, B, per):
+        starts = list(range(0, B, per))
+        lanes = len(starts) > 1 and model is self.draft and bool(self._lanes)
+        main = torch.cuda.current_stream()
+        if lanes:
+            fork = torch.cuda.Event()
+            fork.record(main)
+        used = set()
+        for i, b0 in enumerate(starts):
             nb = min(per, B - b0)
             sub_logits = None
             if logits is not None:
                 sub_logits = logits[b0 * q_len:(b0 + nb) * q_len]
             view = _KvView(kv, slot0 + b0)
             delta = self.rope_delta[slot0 + b0:] if model.cfg.mrope_section else None
-            model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens, tok_stride,
-                          tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits, self._ctx,
-                          rope_delta=delta)
+            lane = i % len(self._lane_ws) if lanes else 0
+            stream = self._lanes[lane - 1] if lane else main
+            if lane and lane not in used:
+                stream.wait_event(fork)
+                used.add(lane)
+            with torch.cuda.stream(stream):
+                model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens,
+                              tok_stride, tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits,
+                              self._ctx, rope_delta=delta,
+                              workspace=self._lane_ws[lane] if lanes else None)
+        for lane in sorted(used):          # join: the step goes on when every lane is done
+            done = torch.cuda.Event()
+            done.record(self._lanes[lane - 1])
+            main.wait_event(done)
 
     def _enqueue_step(self) -> None:
         """One whole step: propose (k draft passes), score (one target pass),

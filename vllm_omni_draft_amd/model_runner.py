@@ -92,14 +92,19 @@ class DecoderModel:
                 logits: Optional[torch.Tensor], max_ctx: Optional[int] = None,
                 wide: Optional[bool] = None, input_embeds: Optional[torch.Tensor] = None,
                 rope_pos: Optional[torch.Tensor] = None,
-                rope_delta: Optional[torch.Tensor] = None) -> None:
+                rope_delta: Optional[torch.Tensor] = None,
+                workspace: Optional[torch.Tensor] = None) -> None:
         """Enqueues one pass over B*q_len token rows on the current stream.
         Token t of sequence b is token_ids[b*tok_stride + tok_offset + t] at
         position seq_lens[b] + pos_offset + t.  `logits` ([B*q_len, vocab] f32)
         may be None to skip the LM head.  Multimodal prompts: input_embeds (bf16
         [B*q_len, hidden]) replace the embedding lookup; a model with mrope_section takes
         its rotary positions from rope_pos (int32 [3, B*q_len]) or, for text after an image,
-        from the cache position + rope_delta[b] (int32 [B])."""
+        from the cache position + rope_delta[b] (int32 [B]).  workspace: another buffer of
+        the size of self.workspace, for passes that run concurrently on several streams."""
+        ws = self.workspace if workspace is None else workspace
+        if ws.numel() < self.workspace.numel() or ws.dtype != torch.uint8:
+            raise _lib.SdError("workspace must be a uint8 tensor of at least self.workspace's size")
         rows = B * q_len
         if input_embeds is not None and (input_embeds.dtype != torch.bfloat16
                                          or not input_embeds.is_contiguous()
@@ -129,6 +134,6 @@ class DecoderModel:
                                 input_embeds=_ptr(input_embeds), rope_pos=_ptr(rope_pos),
                                 rope_delta=_ptr(rope_delta))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
-                                          self.workspace.data_ptr(), self.workspace.numel(),
+                                          ws.data_ptr(), ws.numel(),
                                           torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "sd_model_forward")
