@@ -2,6 +2,9 @@
 k = 5, B sequences, synthetic weights and teacher-forced acceptance, next to the batched
 autoregressive baseline on the same kernels.
     python experiments/bench_batch.py [B] [prompt_len] [draft_rows: auto | same | narrow | wide] [target] [draft] [fp8]
+Environment: K = proposals per step (default 5); IMAGE = placeholder tokens of one synthetic image
+at the start of every prompt (a target with rotary sections, e.g. qwen2-vl-7b: image rows are
+random, positions come from multimodal.prepare_prompt).
 """
 import os
 import sys
@@ -19,7 +22,8 @@ DRAFT_ROWS = sys.argv[3] if len(sys.argv) > 3 else "auto"
 TARGET = sys.argv[4] if len(sys.argv) > 4 else "qwen2.5-7b"
 DRAFT = sys.argv[5] if len(sys.argv) > 5 else "qwen2.5-0.5b"
 FP8 = len(sys.argv) > 6 and sys.argv[6] == "fp8"
-k, steps, warm, alpha = 5, 24, 4, 0.8
+k, steps, warm, alpha = int(os.environ.get("K", "5")), 24, 4, 0.8
+IMAGE = int(os.environ.get("IMAGE", "0"))
 tcfg = config.preset(TARGET)
 dcfg = config.preset(DRAFT, vocab=tcfg.vocab)  # draft vocabulary padded to the target's
 tw = weights.random_init(tcfg, seed=0, fp8=FP8)
@@ -27,13 +31,26 @@ dw = weights.random_init(dcfg, seed=1, fp8=FP8)
 V = min(tcfg.vocab, dcfg.vocab)
 g = torch.Generator().manual_seed(7)
 prompts = [torch.randint(0, V, (P,), generator=g).tolist() for _ in range(B)]
+extras = [{} for _ in range(B)]
+if IMAGE:
+    from vllm_omni_draft_amd import multimodal  # noqa: E402
+    side = int(IMAGE ** 0.5)
+    assert side * side == IMAGE and tcfg.mrope_section, "IMAGE must be a square; target needs mrope"
+    grid = (1, 2 * side, 2 * side)
+    V = min(V, multimodal.QWEN2_VL_IMAGE_TOKEN_ID)
+    for b in range(B):
+        prompts[b] = [t % V for t in prompts[b]]
+        prompts[b][:IMAGE] = [multimodal.QWEN2_VL_IMAGE_TOKEN_ID] * IMAGE
+        rows_ = (torch.randn(IMAGE, tcfg.hidden, generator=g) * 0.02).to(torch.bfloat16).cuda()
+        emb, pos = multimodal.prepare_prompt(prompts[b], tw, rows_, [grid])
+        extras[b] = dict(input_embeds=emb, rope_positions=pos)
 n_new = (steps + warm) * (k + 1) + 8
 max_seq = P + n_new + 16
 rows = "wide" if B * (k + 1) > 16 else "narrow"
 
 
 def run(eng, n_steps, n_warm):
-    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    outs = [[eng.add_request(i, p, **extras[i])] for i, p in enumerate(prompts)]
     for _ in range(n_warm):
         for o, new in zip(outs, eng.step()):
             o.extend(new)
