@@ -236,3 +236,45 @@ def test_rccl_group_of_one():
     torch.cuda.synchronize()
     assert torch.equal(x, y) and torch.equal(send, recv)
     g.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rccl_collectives_inside_the_step_graph(use_graph):
+    """An RCCL group of one rank under a whole engine: the all-reduces of the row-parallel
+    projections and the all-gather of the vocabulary-parallel head are enqueued (and, with
+    use_graph, captured into the step's graph and replayed); the stream equals the one of the
+    engine without a group."""
+    from vllm_omni_draft_amd import parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=256, n_heads=4, n_kv_heads=2, head_dim=64,
+                      ffn=512, vocab=512, max_pos=256, tie_embeddings=True)
+    dc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64,
+                      ffn=256, vocab=512, max_pos=256)
+    state = {k: v.to(torch.bfloat16) for k, v in random_state(oc, seed=7).items()}
+    cfg = _cfg_of(oc)
+    dw = weights.from_state_dict(_cfg_of(dc), {k: v.to(torch.bfloat16) for k, v in
+                                               random_state(dc, seed=8).items()}, "cuda")
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 60))]
+
+    def run(group):
+        if group is None:
+            tw = weights.from_state_dict(cfg, state, "cuda")
+        else:
+            local, st = weights.shard_state_dict(cfg, state, 1, 0, vocab_parallel=True)
+            assert local.lm_vocab == oc.vocab
+            tw = weights.from_state_dict(local, st, "cuda")
+        eng = SpecEngine(tw, dw, EngineConfig(k=3, max_batch=2, max_seq_len=120, split_tokens=128,
+                                              use_graph=use_graph), tp_group=group)
+        toks = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+        while min(len(t) for t in toks) < 30:
+            for t, new in zip(toks, eng.step()):
+                t.extend(new)
+        return [t[:30] for t in toks], eng
+
+    want, _ = run(None)
+    group = parallel.TensorParallelGroup(0, 1)
+    got, eng = run(group)
+    assert got == want
+    assert eng.vp and (not use_graph or eng._graphs)
+    del eng
+    group.close()

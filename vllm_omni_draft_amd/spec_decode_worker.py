@@ -293,6 +293,9 @@ class SpecDecodeConfig:
     # under tensor parallelism each rank holds vocab / tp rows of the LM head and the ranks
     # exchange slice maxima (greedy) or gather rows (sampling) instead of replicating the head
     vocab_parallel_lm_head: bool = True
+    # replay the step as a graph under tensor parallelism too (the RCCL calls are captured with
+    # the kernels).  Verified with a group of one rank only, hence opt-in.
+    tensor_parallel_graph: bool = False
     # prompts with images: the vision tower (vision.VisionTower) that turns pixel patches into
     # input rows of the target, and the tokenizer's placeholder token
     vision: Optional[object] = None
@@ -352,8 +355,8 @@ class SpecDecodeWorker:
         self.engine = SpecEngine(target, c.draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
-            # collectives are enqueued eagerly: capture of RCCL calls is not exercised here
-            use_graph=c.use_graph and tp == 1, rows=c.rows, draft_rows=c.draft_rows,
+            use_graph=c.use_graph and (tp == 1 or c.tensor_parallel_graph), rows=c.rows,
+            draft_rows=c.draft_rows,
             ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
             acceptance_method=c.spec_decoding_acceptance_method,
