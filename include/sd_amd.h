@@ -192,6 +192,24 @@ int sd_paged_attention(const void* q, int64_t ldq, const void* k_cache,
                        int split_tokens, void* workspace,
                        size_t workspace_bytes, sd_stream_t stream);
 
+/* The same for prompt chunks: every sequence has q_total new tokens, attended
+ * in blocks of q_block tokens (q_block * (Hq/Hkv) <= 64; the last block may be
+ * shorter) by ONE launch: the blocks of a sequence are independent workgroup
+ * columns over the same block table, each with its own causal bound, exactly
+ * as ceil(q_total / q_block) calls of sd_paged_attention with pos_offset
+ * advanced by q_block would compute them.  q and out hold B*q_total rows; the
+ * workspace is sized for B * ceil(q_total / q_block) sequences
+ * (sd_paged_attention_workspace_bytes); out must not be NULL unless q_total ==
+ * q_block.                                                                  */
+int sd_paged_attention_blocked(const void* q, int64_t ldq, const void* k_cache,
+                               const void* v_cache, const int32_t* block_tables,
+                               int max_blocks_per_seq, const int32_t* seq_lens,
+                               int pos_offset, void* out, int64_t ldo, int B,
+                               int q_total, int q_block, int Hq, int Hkv, int D,
+                               float scale, int max_ctx, int split_tokens,
+                               void* workspace, size_t workspace_bytes,
+                               sd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Dense ops of a decoder layer at <= 16 token rows (weight streaming; replaces
  * the per-step model execution inside spec_decode.multi_step_worker and the

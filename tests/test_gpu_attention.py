@@ -180,3 +180,43 @@ def test_projection_from_partials_equals_merge_then_linear(B, ctx_lens, q_len, H
     got = ops.linear_attn_merge(W, ws, seq_lens, 0, B, q_len, Hq, Hkv, D, max_ctx, split, None, res,
                                 ops.EPI_RESIDUAL)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,q_total,q_block", [
+    (32, 8, 128, 40, 16), (28, 4, 128, 31, 9), (8, 1, 128, 17, 8), (14, 2, 64, 64, 9), (4, 2, 64, 5, 5)])
+@pytest.mark.parametrize("split,ctx_lens", [(128, [70, 0]), (256, [333, 18])])
+def test_blocked_chunk_attention_equals_block_by_block_calls(Hq, Hkv, D, q_total, q_block, split,
+                                                              ctx_lens):
+    """A prompt chunk attended in one launch (blocks of q_block tokens as workgroup columns,
+    ragged last block) is bit for bit what one call per block gives, and matches the oracle."""
+    ops = _ops()
+    B = len(ctx_lens)
+    kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_total, Hq, Hkv, D, seed=7)
+    kc, vc, btc = kc.cuda(), vc.cuda(), bt.cuda()
+    q = torch.cat(qs).reshape(B * q_total, Hq * D).cuda()
+    seq_lens = torch.tensor(ctx_lens, dtype=torch.int32).cuda()
+    max_ctx = max(ctx_lens) + q_total
+    got = ops.paged_attention_blocked(q, kc, vc, btc, seq_lens, 0, B, q_total, q_block, Hq, Hkv, D,
+                                      D ** -0.5, max_ctx, split).view(B, q_total, Hq * D)
+    for b in range(B):
+        for t0 in range(0, q_total, q_block):
+            n = min(q_block, q_total - t0)
+            one = ops.paged_attention(q.view(B, q_total, -1)[b, t0:t0 + n].contiguous(), kc, vc,
+                                      btc[b:b + 1].contiguous(), seq_lens[b:b + 1].contiguous(), t0, 1, n,
+                                      Hq, Hkv, D, D ** -0.5, max_ctx, split)
+            assert torch.equal(one, got[b, t0:t0 + n]), (b, t0)
+        pos = [ctx_lens[b] + t for t in range(q_total)]
+        ref = verify_attention(qs[b], ks[b], vs[b], pos, D ** -0.5)
+        torch.testing.assert_close(got[b].float().cpu().view(q_total, Hq, D), ref, rtol=2e-2, atol=2e-2)
+
+
+def test_blocked_attention_rejects_bad_blocks():
+    ops = _ops()
+    from vllm_omni_draft_amd import _lib
+    kc, vc, bt, ks, vs, qs = _setup(1, [10], 8, 4, 2, 64, seed=1)
+    q = torch.cat(qs).reshape(8, 4 * 64).cuda()
+    sl = torch.tensor([10], dtype=torch.int32).cuda()
+    with pytest.raises(_lib.SdError):   # block longer than the chunk
+        ops.paged_attention_blocked(q, kc.cuda(), vc.cuda(), bt.cuda(), sl, 0, 1, 8, 9, 4, 2, 64, 0.125, 18, 128)
+    with pytest.raises(_lib.SdError):   # 40 tokens * 2 heads per KV head > 64 rows
+        ops.paged_attention_blocked(q, kc.cuda(), vc.cuda(), bt.cuda(), sl, 0, 1, 8, 40, 4, 2, 64, 0.125, 18, 128)

@@ -76,6 +76,8 @@ SIGNATURES = {
     "sd_paged_attention_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32, i32]),
     "sd_paged_attention": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32, i32,
                                  i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
+    "sd_paged_attention_blocked": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32,
+                                         i32, i32, i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
     "sd_linear": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_linear": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_qkv_rope": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,

@@ -38,6 +38,10 @@ struct AttnArgs {
   bf16_t* out;
   int64_t ldo;
   int q_len, Hq, Hkv;
+  // A sequence's q_total new tokens are attended in q_blocks blocks of q_len tokens (the last
+  // one may be shorter); grid z = sequence * q_blocks + block.  Ordinary passes: q_total ==
+  // q_len, q_blocks == 1.
+  int q_total, q_blocks;
   float scale_log2;
   int split_tokens, n_splits;
   float* part_o;   // [B, Hkv, n_splits, MT*32, D]
@@ -75,15 +79,18 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int kvh = blockIdx.x, split = blockIdx.y, b = blockIdx.z;
+  const int sb = b / a.q_blocks, qb = b - sb * a.q_blocks;  // sequence, block of its new tokens
+  const int q_len = min(a.q_len, a.q_total - qb * a.q_len);
+  const int row0 = sb * a.q_total + qb * a.q_len;           // token row of the block's first token
   const int G = a.Hq / a.Hkv;
-  const int m_rows = a.q_len * G;
+  const int m_rows = q_len * G;
   const int split_start = split * a.split_tokens;
 
   // Everything whose address does not depend on the sequence length is requested at
   // once: the split's slice of the block table (entries past the sequence's last page are
   // read but never used), the Q^T fragments, and the length itself.  A block-table load
   // issued later, beside the K/V stream, would sit behind it in the in-order load counter.
-  const int32_t* bt = a.block_tables + (size_t)b * a.max_blocks;
+  const int32_t* bt = a.block_tables + (size_t)sb * a.max_blocks;
   const int page0 = split_start >> 4;
   const int n_bt = a.split_tokens / 16 + 8 * NBUF;
   int32_t bt_reg[BT_PER_THREAD];
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
     const int m = mt * 32 + r;
     const bool valid = m < m_rows;
     const int t = valid ? m / G : 0, g = valid ? m % G : 0;
-    const bf16_t* qrow = a.q + (size_t)(b * a.q_len + t) * a.ldq + (size_t)(kvh * G + g) * D;
+    const bf16_t* qrow = a.q + (size_t)(row0 + t) * a.ldq + (size_t)(kvh * G + g) * D;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -107,8 +114,8 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
       qf[mt][s] = v;
     }
   }
-  const int pos0 = a.seq_lens[b] + a.pos_offset;
-  const int kv_len = pos0 + a.q_len;
+  const int pos0 = a.seq_lens[sb] + a.pos_offset + qb * a.q_len;
+  const int kv_len = pos0 + q_len;
   if (split_start >= kv_len) return;
   STAMP(1);
   const int split_end = min(split_start + a.split_tokens, kv_len);
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
     if (direct) {
       const float l = sm_lt[m];
       const int t = m / G, g = m % G;
-      a.out[(size_t)(b * a.q_len + t) * a.ldo + (size_t)(kvh * G + g) * D + d] =
+      a.out[(size_t)(row0 + t) * a.ldo + (size_t)(kvh * G + g) * D + d] =
           (bf16_t)(l > 0.f ? o / l : 0.f);
     } else {
       a.part_o[(part_base + m) * D + d] = o;
@@ -323,10 +330,13 @@ template <int D>
 __global__ __launch_bounds__(D) void attn_merge_kernel(AttnArgs a, int m_pad) {
   const int d = threadIdx.x;
   const int head = blockIdx.x, t = blockIdx.y, b = blockIdx.z;
+  const int sb = b / a.q_blocks, qb = b - sb * a.q_blocks;
+  const int q_len = min(a.q_len, a.q_total - qb * a.q_len);
+  if (t >= q_len) return;
   const int G = a.Hq / a.Hkv;
   const int kvh = head / G, g = head % G;
   const int m = t * G + g;
-  const int kv_len = a.seq_lens[b] + a.pos_offset + a.q_len;
+  const int kv_len = a.seq_lens[sb] + a.pos_offset + qb * a.q_len + q_len;
   const int n_valid = min((kv_len + a.split_tokens - 1) / a.split_tokens, a.n_splits);
   const size_t base = (size_t)(b * a.Hkv + kvh) * a.n_splits;
   float mx = -INFINITY;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(D) void attn_merge_kernel(AttnArgs a, int m_pad) {
       l += f * a.part_ml[row * 2 + 1];
     }
   }
-  a.out[(size_t)(b * a.q_len + t) * a.ldo + (size_t)head * D + d] =
+  a.out[(size_t)(sb * a.q_total + qb * a.q_len + t) * a.ldo + (size_t)head * D + d] =
       (bf16_t)(l > 0.f ? o / l : 0.f);
 }
 
@@ -480,6 +490,26 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
                                   int Hq, int Hkv, int D, float scale, int max_ctx,
                                   int split_tokens, void* workspace, size_t workspace_bytes,
                                   sd_stream_t stream) {
+  return sd_paged_attention_blocked(q, ldq, k_cache, v_cache, block_tables, max_blocks_per_seq,
+                                    seq_lens, pos_offset, out, ldo, B, q_len, q_len, Hq, Hkv, D,
+                                    scale, max_ctx, split_tokens, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_paged_attention_blocked(const void* q, int64_t ldq, const void* k_cache,
+                                          const void* v_cache, const int32_t* block_tables,
+                                          int max_blocks_per_seq, const int32_t* seq_lens,
+                                          int pos_offset, void* out, int64_t ldo, int B,
+                                          int q_total, int q_len, int Hq, int Hkv, int D,
+                                          float scale, int max_ctx, int split_tokens,
+                                          void* workspace, size_t workspace_bytes,
+                                          sd_stream_t stream) {
+  SD_REQUIRE(q_total >= q_len && q_len >= 1, SD_ERR_INVALID,
+             "sd_paged_attention_blocked: need 1 <= q_block (%d) <= q_total (%d)", q_len, q_total);
+  const int q_blocks = (q_total + q_len - 1) / q_len;
+  SD_REQUIRE(out || q_blocks == 1, SD_ERR_INVALID,
+             "sd_paged_attention_blocked: partials-only output needs one block per sequence");
+  SD_REQUIRE((long)B * q_blocks <= 65535, SD_ERR_UNSUPPORTED,
+             "sd_paged_attention_blocked: %ld blocks exceed the grid", (long)B * q_blocks);
   SD_REQUIRE(q && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
              "sd_paged_attention: null pointer");
   SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0, SD_ERR_INVALID,
@@ -511,6 +541,8 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
   a.out = (bf16_t*)out;
   a.ldo = ldo;
   a.q_len = q_len;
+  a.q_total = q_total;
+  a.q_blocks = q_blocks;
   a.Hq = Hq;
   a.Hkv = Hkv;
   a.scale_log2 = scale * 1.4426950408889634f;
@@ -522,7 +554,7 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
              "sd_paged_attention: out == NULL (partials only) needs more than one split");
   const int MT = q_len * G <= 32 ? 1 : 2;
   if (a.n_splits > 1) {
-    const size_t rows = (size_t)B * Hkv * a.n_splits * (MT * 32);
+    const size_t rows = (size_t)B * q_blocks * Hkv * a.n_splits * (MT * 32);
     const size_t need = rows * D * sizeof(float) + rows * 2 * sizeof(float);
     SD_REQUIRE(workspace && workspace_bytes >= need, SD_ERR_WORKSPACE,
                "sd_paged_attention: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -530,8 +562,9 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
     a.part_ml = a.part_o + rows * D;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (D == 128) return MT == 1 ? launch_attn<128, 1>(a, B, st) : launch_attn<128, 2>(a, B, st);
-  return MT == 1 ? launch_attn<64, 1>(a, B, st) : launch_attn<64, 2>(a, B, st);
+  const int Z = B * q_blocks;  // workgroup columns: one per (sequence, block)
+  if (D == 128) return MT == 1 ? launch_attn<128, 1>(a, Z, st) : launch_attn<128, 2>(a, Z, st);
+  return MT == 1 ? launch_attn<64, 1>(a, Z, st) : launch_attn<64, 2>(a, Z, st);
 }
 
 extern "C" int sd_rope_append(void* qkv, const float* rope_cs, int max_pos, void* k_cache,

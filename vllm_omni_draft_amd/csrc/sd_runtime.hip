@@ -241,18 +241,16 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                               llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
                               kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
                               Hq, Hkv, D, H, rpp, wws, w.wide_ws_bytes, stream));
-      // One attention launch covers 64 / (Hq/Hkv) query tokens of a sequence; a longer chunk
-      // of ONE sequence (prefill) is walked in blocks of that many tokens (their K/V is in
-      // the cache already, the causal mask is per row).
+      // One workgroup column covers 64 / (Hq/Hkv) query tokens of a sequence; a longer chunk
+      // (prefill) is attended in blocks of that many tokens by the same launch (their K/V is
+      // in the cache already, the causal mask is per row).
       const int q_blk = 64 / (Hq / Hkv);
-      for (int t0 = 0; t0 < a->q_len; t0 += q_blk) {
-        const int qn = a->q_len - t0 < q_blk ? a->q_len - t0 : q_blk;
-        SD_TRY(sd_paged_attention((const char*)qkv + (size_t)t0 * Hq * D * 2, (int64_t)Hq * D, kc, vc,
-                                  kv->block_tables, kv->max_blocks_per_seq, a->seq_lens,
-                                  a->pos_offset + t0, (char*)attn + (size_t)t0 * Hq * D * 2,
-                                  (int64_t)Hq * D, a->B, qn, Hq, Hkv, D, d.attn_scale, a->max_ctx,
-                                  a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
-      }
+      SD_TRY(sd_paged_attention_blocked(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                                        kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
+                                        (int64_t)Hq * D, a->B, a->q_len,
+                                        a->q_len < q_blk ? a->q_len : q_blk, Hq, Hkv, D,
+                                        d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
+                                        w.attn_ws_bytes, stream));
       SD_TRY(sd_linear_wide(l.o_w, l.o_s, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
                             Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));

@@ -230,6 +230,26 @@ def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, 
     return out
 
 
+def paged_attention_blocked(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_total,
+                            q_block, Hq, Hkv, D, scale, max_ctx, split_tokens=256,
+                            workspace=None) -> torch.Tensor:
+    """Attention of q_total new tokens per sequence in blocks of q_block tokens, one launch."""
+    _need(q, torch.bfloat16, "q")
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    out = torch.empty(B * q_total, Hq * D, dtype=torch.bfloat16, device=q.device)
+    n_blocks = -(-q_total // q_block)
+    need = paged_attention_workspace_bytes(B * n_blocks, q_block, Hq, D, max_ctx, split_tokens)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    _lib.check(_lib.load().sd_paged_attention_blocked(
+        _p(q), q.shape[-1], _p(k_cache), _p(v_cache), _p(block_tables), block_tables.shape[1],
+        _p(seq_lens), pos_offset, _p(out), Hq * D, B, q_total, q_block, Hq, Hkv, D, float(scale),
+        max_ctx, split_tokens, _p(workspace), workspace.numel(), _stream()),
+        "sd_paged_attention_blocked")
+    return out
+
+
 # ---------------------------------------------------------------- dense ops
 TILE_PLAIN, TILE_GATED, TILE_ROTARY = 0, 1, 2
 
