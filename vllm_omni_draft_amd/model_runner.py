@@ -17,7 +17,7 @@ from .weights import ModelWeights
 
 MAX_ROWS = 16        # token rows one forward pass may carry (B * q_len), narrow kernel family
 MAX_ROWS_WIDE = 256  # the same for the wide family (batched draft passes / verify)
-PREFILL_ROWS = 192   # prompt tokens of one sequence per prefill pass (wide family)
+PREFILL_ROWS = 256   # prompt tokens of one sequence per prefill pass (wide family)
 
 
 def _ptr(t):
