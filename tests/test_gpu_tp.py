@@ -30,10 +30,13 @@ class _TwoRankSum:
         self.error = None
 
     def view(self, rank, ptr, n):
-        ws = self.models[rank].workspace
-        off = ptr - ws.data_ptr()
-        assert 0 <= off and off + 2 * n <= ws.numel()
-        return ws[off:off + 2 * n].view(torch.bfloat16)
+        models = self.models[rank]
+        for m in models if isinstance(models, (list, tuple)) else [models]:
+            ws = m.workspace
+            off = ptr - ws.data_ptr()
+            if 0 <= off and off + 2 * n <= ws.numel():
+                return ws[off:off + 2 * n].view(torch.bfloat16)
+        raise AssertionError("the buffer is in none of the rank's workspaces")
 
     def make(self, rank):
         def fn(ptr, n, stream):
@@ -278,3 +281,67 @@ def test_rccl_collectives_inside_the_step_graph(use_graph):
     assert eng.vp and (not use_graph or eng._graphs)
     del eng
     group.close()
+
+
+def test_two_rank_engine_with_sharded_draft():
+    """Target and draft both sharded over two virtual ranks.  With the target's own weights as
+    the draft every proposal is accepted (rows are computed alike in draft and verify passes);
+    with another draft the stream still equals the autoregressive one; the ranks agree."""
+    from vllm_omni_draft_amd import parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=256, n_heads=4, n_kv_heads=2, head_dim=64,
+                      ffn=512, vocab=512, max_pos=256)
+    dc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=2, head_dim=64,
+                      ffn=256, vocab=512, max_pos=256)
+    state = {k: v.to(torch.bfloat16) for k, v in random_state(oc, seed=7).items()}
+    dstate = {k: v.to(torch.bfloat16) for k, v in random_state(dc, seed=8).items()}
+    cfg, dcfg = _cfg_of(oc), _cfg_of(dc)
+    stream = torch.cuda.Stream()
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 60))]
+
+    def run(k, draft):
+        coll = _TwoRankSum()
+        engines = []
+        for r in range(2):
+            local, st = weights.shard_state_dict(cfg, state, 2, r, vocab_parallel=True)
+            tw = weights.from_state_dict(local, st, "cuda")
+            dw = None
+            if k:
+                dlocal, dst = weights.shard_state_dict(*draft, 2, r)
+                dw = weights.from_state_dict(dlocal, dst, "cuda")
+            group = parallel.CallbackAllReduce(r, coll.make(r), world_size=2,
+                                               gather=coll.make_gather(r))
+            eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=2, max_seq_len=120, split_tokens=128,
+                                                  use_graph=False), tp_group=group, draft_tp=bool(k))
+            eng.stream = stream
+            coll.models[r] = [eng.target] + ([eng.draft] if k else [])
+            engines.append(eng)
+        torch.cuda.synchronize()
+        outs = [None, None]
+
+        def worker(r):
+            eng = engines[r]
+            toks = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+            while min(len(t) for t in toks) < 24:
+                for t, new in zip(toks, eng.step()):
+                    t.extend(new)
+            outs[r] = [t[:24] for t in toks]
+
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=120)
+            assert not t.is_alive()
+        torch.cuda.synchronize()
+        assert coll.error is None, coll.error
+        assert outs[0] == outs[1]
+        return outs[0], engines[0].metrics()
+
+    ar, _ = run(0, None)
+    same, m = run(3, (cfg, state))
+    assert same == ar and m["accepted"] == m["draft"] > 0
+    other, m = run(3, (dcfg, dstate))
+    assert other == ar and m["draft"] > 0
+    with pytest.raises(ValueError):
+        SpecEngine(weights.from_state_dict(cfg, state, "cuda"), None, EngineConfig(k=0), draft_tp=True)

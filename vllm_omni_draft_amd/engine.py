@@ -78,10 +78,17 @@ class EngineConfig:
 
 class SpecEngine:
     def __init__(self, target: ModelWeights, draft: Optional[ModelWeights], cfg: EngineConfig,
-                 tp_group=None):
+                 tp_group=None, draft_tp: bool = False):
         """tp_group: the target is this rank's tensor-parallel shard (its two row-parallel
-        projections per layer are summed over the group inside the native forward); the
-        draft is whole.  Every rank runs the same steps on the same inputs."""
+        projections per layer are summed over the group inside the native forward).  The
+        draft is whole on every rank, or with draft_tp this rank's shard over the same group
+        (a draft that is not much smaller than the target's share: replicated, its passes
+        would stream more bytes per GPU than the sharded verify pass).  The draft's LM head is
+        always whole.  Every rank runs the same steps on the same inputs."""
+        if draft_tp and tp_group is None:
+            raise ValueError("draft_tp needs a tp_group")
+        if draft_tp and draft is not None and draft.cfg.lm_vocab:
+            raise ValueError("the draft's LM head is not split: shard it without vocab_parallel")
         if cfg.k < 0 or cfg.k > 7:
             raise ValueError("k must be in 0..7")
         if cfg.acceptance_method not in ("rejection_sampler", "typical_acceptance_sampler"):
@@ -113,11 +120,13 @@ class SpecEngine:
         else:
             draft_wide = self.wide if cfg.draft_rows == "same" else cfg.draft_rows == "wide"
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
-                                   wide=draft_wide) if k > 0 and draft is not None else None)
+                                   wide=draft_wide, tp_group=tp_group if draft_tp else None)
+                      if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self._lanes: List[torch.cuda.Stream] = []
         self._lane_ws: List[torch.Tensor] = []
-        if self.draft is not None and not self.draft.wide and cfg.draft_lanes > 1:
+        # (collectives of one communicator must stay on one stream: no lanes for a sharded draft)
+        if self.draft is not None and not self.draft.wide and cfg.draft_lanes > 1 and not draft_tp:
             n_sub = -(-2 * B // self.draft.max_rows)      # the first pass carries 2 tokens per sequence
             n = min(cfg.draft_lanes, n_sub)
             if n > 1:

@@ -296,6 +296,11 @@ class SpecDecodeConfig:
     # replay the step as a graph under tensor parallelism too (the RCCL calls are captured with
     # the kernels).  Verified with a group of one rank only, hence opt-in.
     tensor_parallel_graph: bool = False
+    # 1: the draft is whole on every rank (no communication in its passes); equal to
+    # tensor_parallel_size: the draft is sharded like the target (upstream's
+    # speculative_draft_tensor_parallel_size).  `draft` is then a (ModelConfig, state_dict)
+    # pair that load_model shards, or this rank's shard.
+    draft_tensor_parallel_size: int = 1
     # prompts with images: the vision tower (vision.VisionTower) that turns pixel patches into
     # input rows of the target, and the tokenizer's placeholder token
     vision: Optional[object] = None
@@ -352,7 +357,17 @@ class SpecDecodeWorker:
                 vp = c.vocab_parallel_lm_head and cfg.vocab % (16 * tp) == 0
                 cfg, state = W.shard_state_dict(cfg, state, tp, self.rank, vocab_parallel=vp)
             target = W.from_state_dict(cfg, state, torch.device("cuda", self.local_rank))
-        self.engine = SpecEngine(target, c.draft, EngineConfig(
+        draft = c.draft
+        if c.draft_tensor_parallel_size not in (1, tp):
+            raise ValueError("draft_tensor_parallel_size must be 1 or tensor_parallel_size")
+        draft_tp = tp > 1 and c.draft_tensor_parallel_size == tp
+        if isinstance(draft, tuple):
+            from . import weights as W
+            dcfg, dstate = draft
+            if draft_tp:
+                dcfg, dstate = W.shard_state_dict(dcfg, dstate, tp, self.rank)
+            draft = W.from_state_dict(dcfg, dstate, torch.device("cuda", self.local_rank))
+        self.engine = SpecEngine(target, draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
             use_graph=c.use_graph and (tp == 1 or c.tensor_parallel_graph), rows=c.rows,
@@ -362,7 +377,7 @@ class SpecDecodeWorker:
             acceptance_method=c.spec_decoding_acceptance_method,
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
             posterior_alpha=c.typical_acceptance_sampler_posterior_alpha),
-            tp_group=getattr(self, "tp_group", None))
+            tp_group=getattr(self, "tp_group", None), draft_tp=draft_tp)
         self._wire()
 
     def _wire(self) -> None:
