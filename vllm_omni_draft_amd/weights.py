@@ -246,7 +246,7 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
                 mlp_norm_w=ones(H), mlp_norm_b=rn(H), up_w=_tile(rn(F, H)), up_b=rn(F),
                 down_w=_tile(rn(H, F)), down_b=rn(H)))
     embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5)
-    embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(cfg.vocab, H),
+    embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(cfg.head_rows, H),
                                            device, fp8)
     w = ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, final_norm_w=ones(H), lm_head=lm_head,
                      layers=layers, fp8=fp8)
