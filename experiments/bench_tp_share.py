@@ -73,7 +73,9 @@ for b in range(B):
     truth[b, :P] = torch.tensor(prompts[b])
     truth[b, P:P + len(ar_out[b])] = torch.tensor(ar_out[b])
 for name, dcfg, draft_tp in (("8B draft replicated", full_d, False),
-                             (f"8B draft sharded TP{TP}", full_d.tp_shard(TP), True)):
+                             (f"8B draft sharded TP{TP}, head whole", full_d.tp_shard(TP), True),
+                             (f"8B draft sharded TP{TP}, head split",
+                              full_d.tp_shard(TP, vocab_parallel=True), True)):
     dw = weights.random_init(dcfg, seed=1)
     eng = engine(k, dw, draft_tp)
     eng.set_synthetic_acceptance(truth.cuda(), alpha, seed=3)

@@ -283,8 +283,10 @@ def test_rccl_collectives_inside_the_step_graph(use_graph):
     group.close()
 
 
-def test_two_rank_engine_with_sharded_draft():
-    """Target and draft both sharded over two virtual ranks.  With the target's own weights as
+@pytest.mark.parametrize("draft_vp,temperature", [(False, 0.0), (True, 0.0), (True, 1.0)])
+def test_two_rank_engine_with_sharded_draft(draft_vp, temperature):
+    """Target and draft both sharded over two virtual ranks (the draft's LM head whole or
+    split by vocabulary like the target's).  With the target's own weights as
     the draft every proposal is accepted (rows are computed alike in draft and verify passes);
     with another draft the stream still equals the autoregressive one; the ranks agree."""
     from vllm_omni_draft_amd import parallel, weights
@@ -299,7 +301,7 @@ def test_two_rank_engine_with_sharded_draft():
     stream = torch.cuda.Stream()
     prompts = [[5, 9, 200, 31, 7], list(range(40, 60))]
 
-    def run(k, draft):
+    def run(k, draft, vp=draft_vp):
         coll = _TwoRankSum()
         engines = []
         for r in range(2):
@@ -307,12 +309,14 @@ def test_two_rank_engine_with_sharded_draft():
             tw = weights.from_state_dict(local, st, "cuda")
             dw = None
             if k:
-                dlocal, dst = weights.shard_state_dict(*draft, 2, r)
+                dlocal, dst = weights.shard_state_dict(*draft, 2, r, vocab_parallel=vp)
+                assert dlocal.head_rows == (256 if vp else 512)
                 dw = weights.from_state_dict(dlocal, dst, "cuda")
             group = parallel.CallbackAllReduce(r, coll.make(r), world_size=2,
                                                gather=coll.make_gather(r))
             eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=2, max_seq_len=120, split_tokens=128,
-                                                  use_graph=False), tp_group=group, draft_tp=bool(k))
+                                                  use_graph=False, temperature=temperature, seed=11),
+                             tp_group=group, draft_tp=bool(k))
             eng.stream = stream
             coll.models[r] = [eng.target] + ([eng.draft] if k else [])
             engines.append(eng)
@@ -338,6 +342,12 @@ def test_two_rank_engine_with_sharded_draft():
         assert outs[0] == outs[1]
         return outs[0], engines[0].metrics()
 
+    if temperature > 0.0:
+        # sampling: the split head gathers the rows the whole head computes: same stream
+        split, m = run(3, (dcfg, dstate))
+        whole, _ = run(3, (dcfg, dstate), vp=False)
+        assert split == whole and m["draft"] > 0
+        return
     ar, _ = run(0, None)
     same, m = run(3, (cfg, state))
     assert same == ar and m["accepted"] == m["draft"] > 0

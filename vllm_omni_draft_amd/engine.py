@@ -83,12 +83,13 @@ class SpecEngine:
         projections per layer are summed over the group inside the native forward).  The
         draft is whole on every rank, or with draft_tp this rank's shard over the same group
         (a draft that is not much smaller than the target's share: replicated, its passes
-        would stream more bytes per GPU than the sharded verify pass).  The draft's LM head is
-        always whole.  Every rank runs the same steps on the same inputs."""
+        would stream more bytes per GPU than the sharded verify pass); its LM head may then be
+        split by vocabulary rows like the target's.  Every rank runs the same steps on the
+        same inputs."""
         if draft_tp and tp_group is None:
             raise ValueError("draft_tp needs a tp_group")
-        if draft_tp and draft is not None and draft.cfg.lm_vocab:
-            raise ValueError("the draft's LM head is not split: shard it without vocab_parallel")
+        if draft is not None and draft.cfg.lm_vocab and not draft_tp:
+            raise ValueError("a vocabulary-parallel draft head needs draft_tp")
         if cfg.k < 0 or cfg.k > 7:
             raise ValueError("k must be in 0..7")
         if cfg.acceptance_method not in ("rejection_sampler", "typical_acceptance_sampler"):
@@ -177,6 +178,16 @@ class SpecEngine:
             self.vp_send = torch.empty(2 * n_rows * ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
             self.vp_recv = torch.empty(n_tp * self.vp_send.numel(), dtype=torch.float32, device=dev)
             self.vp_rows = torch.empty(n_tp * n_rows * Vl, dtype=torch.float32, device=dev)
+        # the same for a sharded draft with a vocabulary-parallel head (buffers shared with the
+        # target's exchange: everything runs on one stream)
+        self.d_vp = self.draft is not None and draft.cfg.lm_vocab > 0
+        self.d_out = self.d_logits
+        if self.d_vp:
+            if not self.vp or draft.cfg.lm_vocab != target.cfg.lm_vocab:
+                raise ValueError("a vocabulary-parallel draft head needs the target's head split "
+                                 "the same way")
+            self.d_out = torch.empty(self.d_logits.shape[0], draft.cfg.lm_vocab, dtype=torch.float32,
+                                     device=dev)
         # Step record {n_emitted, seq_len, tokens}: the last kernel of a step writes it to
         # pinned host memory, so returning a step's tokens takes one stream
         # synchronisation and no copy.
@@ -386,12 +397,15 @@ class SpecEngine:
     # -- the target's logits after a pass of n rows (whole, or one vocabulary slice per rank)
     def _target_partials(self, n: int) -> None:
         """Slice maxima of rows 0..n-1 over the whole vocabulary -> part_val / part_idx."""
-        if not self.vp:
-            ops.argmax_partial(self.t_out[:n], self.part_val, self.part_idx)
+        self._partials(self.t_out, n, self.vp)
+
+    def _partials(self, out: torch.Tensor, n: int, split: bool) -> None:
+        if not split:
+            ops.argmax_partial(out[:n], self.part_val, self.part_idx)
             return
         m = n * ops.ARGMAX_PARTS
         send = self.vp_send[:2 * m]
-        ops.argmax_partial(self.t_out[:n], send[:m].view(n, -1), send[m:].view(torch.int32).view(n, -1))
+        ops.argmax_partial(out[:n], send[:m].view(n, -1), send[m:].view(torch.int32).view(n, -1))
         recv = self.vp_recv[:self.tp.world_size * 2 * m]
         self.tp.all_gather(send, recv)
         ops.argmax_combine(recv, self.tp.world_size, n, self.target.cfg.lm_vocab,
@@ -405,12 +419,14 @@ class SpecEngine:
 
     def _target_full_rows(self, n: int) -> None:
         """Whole logits rows 0..n-1 in t_logits (sampling needs the full distribution)."""
-        if not self.vp:
-            return
+        if self.vp:
+            self._gather_rows(self.t_out, self.t_logits, n)
+
+    def _gather_rows(self, out: torch.Tensor, full: torch.Tensor, n: int) -> None:
         n_tp, Vl = self.tp.world_size, self.target.cfg.lm_vocab
         recv = self.vp_rows[:n_tp * n * Vl]
-        self.tp.all_gather(self.t_out[:n].reshape(-1), recv)
-        self.t_logits[:n].view(n, n_tp, Vl).copy_(recv.view(n_tp, n, Vl).permute(1, 0, 2))
+        self.tp.all_gather(out[:n].reshape(-1), recv)
+        full[:n].view(n, n_tp, Vl).copy_(recv.view(n_tp, n, Vl).permute(1, 0, 2))
 
     def _enqueue_ar_step(self) -> None:
         B = self.active
@@ -465,15 +481,17 @@ class SpecEngine:
         for i in range(k):
             if i == 0:
                 self._forward(self.draft, self.d_kv, self.tok_buf, stride, 0, self.seq_lens, -2, B, 2,
-                              self.d_logits)
+                              self.d_out)
                 off, step = 1, 2
             else:
                 self._forward(self.draft, self.d_kv, self.tok_buf, stride, 1 + i, self.seq_lens,
-                              -1 + i, B, 1, self.d_logits)
+                              -1 + i, B, 1, self.d_out)
                 off, step = 0, 1
+            if self.d_vp and (self.sampling or not fused):
+                self._gather_rows(self.d_out, self.d_logits, B * step)   # whole rows on every rank
             rows = self.d_logits[:B * step]
             if fused:
-                ops.argmax_partial(rows, self.part_val, self.part_idx)
+                self._partials(self.d_out, B * step, self.d_vp)
                 ops.propose_from_partials(self.part_val, self.part_idx, off, step,
                                           self.tok_buf[:B], k, i, self.seq_lens[:B], self.truth,
                                           self.accept_prob, self.accept_seed)

@@ -364,8 +364,9 @@ class SpecDecodeWorker:
         if isinstance(draft, tuple):
             from . import weights as W
             dcfg, dstate = draft
-            if draft_tp:
-                dcfg, dstate = W.shard_state_dict(dcfg, dstate, tp, self.rank)
+            if draft_tp:   # head split like the target's
+                dcfg, dstate = W.shard_state_dict(dcfg, dstate, tp, self.rank,
+                                                  vocab_parallel=target.cfg.lm_vocab > 0)
             draft = W.from_state_dict(dcfg, dstate, torch.device("cuda", self.local_rank))
         self.engine = SpecEngine(target, draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
