@@ -238,10 +238,16 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
         }
         if (RELOAD && mt == MT - 1) load_k(kf[u], tile + 4 * NBUF);
         if (live) {
+          // The running maximum settles after the first tiles; a factor of exactly 1 in every
+          // lane leaves the accumulators as they are, so the wave skips the rescale (same bits).
+          if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) o_acc[mt][dt][i] *= alpha;
+          }
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o_acc[mt][dt][i] *= alpha;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
               o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u][s][dt], pf[s],
