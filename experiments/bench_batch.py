@@ -4,7 +4,8 @@ autoregressive baseline on the same kernels.
     python experiments/bench_batch.py [B] [prompt_len] [draft_rows: auto | same | narrow | wide] [target] [draft] [fp8]
 Environment: K = proposals per step (default 5); IMAGE = placeholder tokens of one synthetic image
 at the start of every prompt (a target with rotary sections, e.g. qwen2-vl-7b: image rows are
-random, positions come from multimodal.prepare_prompt).
+random, positions come from multimodal.prepare_prompt); RAGGED=1: prompt lengths uniform in
+64..prompt_len (seed 7) instead of all equal.
 """
 import os
 import sys
@@ -30,7 +31,9 @@ tw = weights.random_init(tcfg, seed=0, fp8=FP8)
 dw = weights.random_init(dcfg, seed=1, fp8=FP8)
 V = min(tcfg.vocab, dcfg.vocab)
 g = torch.Generator().manual_seed(7)
-prompts = [torch.randint(0, V, (P,), generator=g).tolist() for _ in range(B)]
+lens = ([int(n) for n in torch.randint(64, P + 1, (B,), generator=torch.Generator().manual_seed(7))]
+        if os.environ.get("RAGGED") else [P] * B)
+prompts = [torch.randint(0, V, (n,), generator=g).tolist() for n in lens]
 extras = [{} for _ in range(B)]
 if IMAGE:
     from vllm_omni_draft_amd import multimodal  # noqa: E402
@@ -71,8 +74,9 @@ ar_out, ar_n, ar_dt = run(ar, n_new - 8 - warm, warm)
 print(f"AR   B={B}: {ar_dt / (n_new - 8 - warm) * 1e3:.3f} ms/step, {ar_n / ar_dt:.1f} tok/s", flush=True)
 truth = torch.zeros(B, max_seq, dtype=torch.int32)
 for b in range(B):
-    truth[b, :P] = torch.tensor(prompts[b])
-    truth[b, P:P + len(ar_out[b])] = torch.tensor(ar_out[b])
+    n = len(prompts[b])
+    truth[b, :n] = torch.tensor(prompts[b])
+    truth[b, n:n + len(ar_out[b])] = torch.tensor(ar_out[b])
 del ar
 torch.cuda.empty_cache()
 eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=B, max_seq_len=max_seq, rows=rows,
