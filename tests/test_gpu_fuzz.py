@@ -79,3 +79,47 @@ def test_random_join_leave_schedule(rows, max_batch, k, use_graph, seed):
         assert got[i][:n_new] == want[i], i
     m = eng.metrics()
     assert m["draft"] > 0 and m["emitted"] >= m["accepted"]
+
+
+def test_scheduler_generates_what_each_request_gets_alone():
+    """SpecDecodeScheduler over a real worker: 7 requests through 3 slots, different budgets and
+    an end-of-sequence token; every output is the solo autoregressive stream cut at its stop."""
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    from vllm_omni_draft_amd.scheduler import Request, SpecDecodeScheduler
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
+    rnd = random.Random(9)
+    tw, dw = _weights(TARGET, 50), _weights(DRAFT, 51)
+    prompts = [[rnd.randrange(TARGET.vocab) for _ in range(rnd.randint(2, 50))] for _ in range(7)]
+    solo = SpecEngine(tw, None, EngineConfig(k=0, max_batch=1, max_seq_len=100, split_tokens=128))
+    want = []
+    for p in prompts:
+        solo.reset()
+        out = [solo.add_request(0, p)]
+        while len(out) < 30:
+            out.extend(solo.step()[0])
+        want.append(out[:30])
+    del solo
+    w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=dw, num_speculative_tokens=3, max_num_seqs=3,
+                                          max_model_len=100, split_tokens=128))
+    w.init_device()
+    w.load_model()
+    sched = SpecDecodeScheduler.for_worker(w)
+    budgets = [5, 30, 1, 17, 30, 8, 22]
+    eos = {1: want[1][6], 4: want[4][2]}
+    reqs = [Request(f"q{i}", p, max_tokens=budgets[i], eos_token_id=eos.get(i)) for i, p in enumerate(prompts)]
+    for r in reqs:
+        sched.add_request(r)
+    while sched.has_unfinished():
+        sched.step()
+        assert w.engine.active <= 3
+    sched.drain()
+    assert w.engine.active == 0
+    for i, r in enumerate(reqs):
+        exp = want[i][:budgets[i]]
+        if i in eos:
+            exp = exp[:exp.index(eos[i]) + 1]
+            assert r.finish_reason == ("stop" if len(exp) < budgets[i] or exp[-1] == eos[i] else "length")
+        assert r.output_token_ids == exp, i
+    # a second wave reuses the freed slots and pages
+    again = sched.generate(prompts[:4], max_tokens=6)
+    assert [r.output_token_ids for r in again] == [wnt[:6] for wnt in want[:4]]

@@ -233,3 +233,36 @@ def test_prompt_lookup_matches_longest_most_recent_ngram():
     assert look([4, 4]) == [4]                      # continuation shorter than k
     eng.cfg = EngineConfig(k=3, ngram_max=3, ngram_min=2)
     assert look([1, 9, 2, 9]) == []                 # only a 1-gram matches: below ngram_min
+
+
+def test_scheduler_continuous_batching_and_stop_conditions():
+    from vllm_omni_draft_amd.scheduler import Request, SpecDecodeScheduler
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeWorker
+    eng = FakeEngine()                      # 3 slots; request with first prompt token o emits 100*o + step
+    sched = SpecDecodeScheduler(SpecDecodeWorker(vllm_config=None, engine=eng), max_num_seqs=3,
+                                max_model_len=12)
+    reqs = [Request(f"r{i}", [i + 1, 7, 7], max_tokens=m, eos_token_id=e)
+            for i, (m, e) in enumerate([(3, None), (50, 203), (2, None), (4, None), (50, None)])]
+    for r in reqs:
+        sched.add_request(r)
+    with pytest.raises(KeyError):
+        sched.add_request(Request("r0", [1]))
+    with pytest.raises(ValueError):
+        sched.add_request(Request("big", list(range(12))))
+    finished_order = []
+    while sched.has_unfinished():
+        finished_order += [r.request_id for r in sched.step()]
+        assert eng.active <= 3 and len(sched.running) <= 3
+    sched.drain()
+    assert eng.active == 0 and not sched.running and not sched.waiting
+    out = {r.request_id: r for r in reqs}
+    assert out["r0"].output_token_ids[0] == 100 and len(out["r0"].output_token_ids) == 3
+    assert out["r0"].finish_reason == "length"
+    assert out["r1"].output_token_ids[-1] == 203 and out["r1"].finish_reason == "stop"   # eos, cut there
+    assert len(out["r2"].output_token_ids) == 2
+    assert len(out["r3"].output_token_ids) == 4 and out["r3"].output_token_ids[0] == 400
+    # model length: 3 prompt tokens + 9 generated = 12
+    assert len(out["r4"].output_token_ids) == 9 and out["r4"].finish_reason == "length"
+    assert set(finished_order) == set(out) and finished_order.index("r2") < finished_order.index("r4")
+    # waiting requests entered as slots became free: 5 requests over 3 slots
+    assert sched.steps > 3
