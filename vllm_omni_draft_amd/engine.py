@@ -265,14 +265,22 @@ class SpecEngine:
 
     def add_request(self, slot: int, prompt: Sequence[int],
                     input_embeds: Optional[torch.Tensor] = None,
-                    rope_positions: Optional[torch.Tensor] = None) -> int:
+                    rope_positions: Optional[torch.Tensor] = None,
+                    truth_row: Optional[Sequence[int]] = None) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
         first token from the target and returns it (this synchronises).
         Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
         [len(prompt), hidden] bf16 are the target's input rows (image embeddings in the
         placeholder tokens' places; the draft still embeds the token ids), rope_positions
-        [3, len(prompt)] the rotary positions for models with mrope_section."""
+        [3, len(prompt)] the rotary positions for models with mrope_section.  truth_row
+        (benchmarks with synthetic acceptance, see set_synthetic_acceptance): the request's
+        token stream from position 0, stored in the slot's row of the truth table."""
         with torch.cuda.stream(self.stream):
+            if truth_row is not None:
+                if self.truth is None:
+                    raise ValueError("truth_row needs set_synthetic_acceptance first")
+                row = torch.tensor(list(truth_row)[:self.truth.shape[1]], dtype=torch.int32)
+                self.truth[slot, :row.numel()].copy_(row)
             return self._add_request(slot, prompt, input_embeds, rope_positions)
 
     def _add_request(self, slot: int, prompt: Sequence[int], input_embeds=None,
@@ -594,8 +602,10 @@ class SpecEngine:
                 if slot != last:
                     kv.move_slot(last, slot)
             if slot != last:
-                for t in (self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts,
-                          self.rope_delta):
+                moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta]
+                if self.truth is not None:
+                    moved.append(self.truth)
+                for t in moved:
                     t[slot].copy_(t[last])
                 self.host_lens[slot], self.host_gen[slot] = self.host_lens[last], self.host_gen[last]
                 if self.ngram:
