@@ -266,3 +266,24 @@ def test_scheduler_continuous_batching_and_stop_conditions():
     assert set(finished_order) == set(out) and finished_order.index("r2") < finished_order.index("r4")
     # waiting requests entered as slots became free: 5 requests over 3 slots
     assert sched.steps > 3
+
+
+def test_bench_helpers_and_committed_counter_summary():
+    """The bench's algorithmic-bytes model and its look-up of the committed HBM counters (a kernel
+    renamed without refreshing the profile would silently report traffic = null)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from vllm_omni_draft_amd import config
+    t, d = config.preset("llama-3-8b"), config.preset("llama-3.2-1b")
+    total = bench.step_bytes(t, d, 5, 1024)
+    # target weights once + 5 draft passes + KV of both + logits: 27-29 GB at context 1024
+    assert 27e9 < total < 29.5e9
+    assert bench.step_bytes(t, d, 5, 1024, 8e9, 1e9) < total
+    lin = bench.pmc_traffic("linear_kernel<2, 1, false, false>")
+    attn = bench.pmc_traffic("paged_attn_kernel<128, 1")
+    assert lin is not None and attn is not None
+    assert 1.0 <= lin / 235102208 < 1.1 and 1.0 <= attn / 537657344 < 1.1
+    assert bench.pmc_traffic("no_such_kernel") is None
