@@ -287,3 +287,18 @@ def test_bench_helpers_and_committed_counter_summary():
     assert lin is not None and attn is not None
     assert 1.0 <= lin / 235102208 < 1.1 and 1.0 <= attn / 537657344 < 1.1
     assert bench.pmc_traffic("no_such_kernel") is None
+
+
+def test_worker_refuses_a_request_with_another_temperature():
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SamplingParams,
+                                                        SequenceGroupMetadata, SpecDecodeWorker)
+    eng = FakeEngine()
+    eng.cfg.temperature = 0.0
+    w = SpecDecodeWorker(vllm_config=None, engine=eng)
+    ok = SequenceGroupMetadata("a", True, [1, 2], sampling_params=SamplingParams(temperature=0.0))
+    dflt = SequenceGroupMetadata("b", True, [2, 2])
+    w.execute_model(ExecuteModelRequest([ok, dflt]))
+    hot = SequenceGroupMetadata("c", True, [3, 2], sampling_params=SamplingParams(temperature=0.8))
+    with pytest.raises(ValueError):
+        w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("a", False),
+                                             SequenceGroupMetadata("b", False), hot]))

@@ -35,7 +35,9 @@ from .weights import ModelWeights
 # --------------------------------------------------------------------------- carriers
 @dataclass
 class SamplingParams:
-    temperature: float = 0.0
+    # None: the worker's temperature.  One temperature serves the whole batch (the step is one
+    # captured graph); a request that asks for another one is refused, not silently served.
+    temperature: Optional[float] = None
     max_tokens: int = 16
     seed: Optional[int] = None
     ignore_eos: bool = True
@@ -409,6 +411,12 @@ class SpecDecodeWorker:
             self._finish(rid)
         running = [g for g in execute_model_req.seq_group_metadata_list if not g.is_prompt]
         prompts = [g for g in execute_model_req.seq_group_metadata_list if g.is_prompt]
+        have = getattr(getattr(eng, "cfg", None), "temperature", None)
+        for g in prompts:   # checked before anything runs
+            want = g.sampling_params.temperature
+            if want is not None and have is not None and float(want) != float(have):
+                raise ValueError(f"request {g.request_id} asks for temperature {want}; this worker "
+                                 f"runs every sequence at {have}")
         unknown = [g.request_id for g in running if g.request_id not in self._slot_of]
         if unknown:
             raise KeyError(f"requests {unknown} are not running on this worker")
