@@ -180,3 +180,45 @@ def test_worker_options_keep_the_greedy_stream(option):
     else:
         for r in prompts:
             assert got[r][:20] == want[r], r
+
+
+def test_worker_loads_and_shards_from_state_dicts_with_a_group_of_one():
+    """target and draft given as (config, state dict): load_model builds (and, under tensor
+    parallelism, shards) both itself.  With an RCCL group of one rank, vocabulary-parallel heads
+    and the step graph with the collectives inside, the stream is the plain worker's."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeConfig, SpecDecodeWorker)
+    tcfg = MODELS["llama"]
+    dcfg = OracleConfig(**{**vars(MODELS["llama"]), "n_layers": 1})
+    tstate, dstate = _bf(random_state(tcfg, seed=21)), _bf(random_state(dcfg, seed=23))
+    tw, dw = _product(tcfg, tstate), _product(dcfg, dstate)
+    prompt = [5, 9, 200, 31, 7]
+
+    def run(w):
+        out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", True, prompt)])).sampled_token_ids[0]
+        while len(out) < 24:
+            out += w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", False)])).sampled_token_ids[0]
+        return out[:24]
+
+    want = run(_worker(tw, dw, 3, True, max_num_seqs=1))
+    # tensor_parallel_size 1 through the tuple path
+    w1 = SpecDecodeWorker(SpecDecodeConfig(target=(tw.cfg, tstate), draft=(dw.cfg, dstate),
+                                           num_speculative_tokens=3, max_num_seqs=1, max_model_len=200,
+                                           split_tokens=128))
+    w1.init_device()
+    w1.load_model()
+    assert run(w1) == want
+    # the tensor-parallel engine with a group of one rank, both heads split, graph on
+    from vllm_omni_draft_amd import parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    group = parallel.TensorParallelGroup(0, 1)
+    lt, st = weights.shard_state_dict(tw.cfg, tstate, 1, 0, vocab_parallel=True)
+    ld, sd = weights.shard_state_dict(dw.cfg, dstate, 1, 0, vocab_parallel=True)
+    eng = SpecEngine(weights.from_state_dict(lt, st, "cuda"), weights.from_state_dict(ld, sd, "cuda"),
+                     EngineConfig(k=3, max_batch=1, max_seq_len=200, split_tokens=128),
+                     tp_group=group, draft_tp=True)
+    assert eng.vp and eng.d_vp
+    w2 = SpecDecodeWorker(vllm_config=None, engine=eng)
+    assert run(w2) == want and eng._graphs
+    del w2, eng
+    group.close()
