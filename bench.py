@@ -39,11 +39,15 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 
 
+PMC_FILE = "profiles/r1_pmc_hbm.json"
+
+
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch (read + write) of a kernel from the committed counter summary
-    (profiles/r1_pmc_hbm.json: separate FETCH_SIZE / WRITE_SIZE passes of rocprofv3 over
-    experiments/pmc_*.py, FETCH_SIZE doubled as gfx950 requires), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_hbm.json")
+    """HBM bytes per launch (read + write) of a kernel, NOT measured in this run: read from
+    the committed counter summary PMC_FILE (separate FETCH_SIZE / WRITE_SIZE passes of
+    rocprofv3 over experiments/pmc_*.py, FETCH_SIZE doubled as gfx950 requires), or None.
+    The bench line names the file as `traffic_source`."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), *PMC_FILE.split("/"))
     try:
         with open(path) as f:
             ks = json.load(f)["kernels"]
@@ -177,6 +181,7 @@ def kernel_roofline(eng, tw, rows, reps=3):
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": pmc_traffic("linear_kernel<2, 1, false, false>") if rows == 6 and w.scale is None else None,
+            "traffic_source": PMC_FILE,
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
@@ -196,6 +201,10 @@ def attention_roofline(device, k):
                      dtype=torch.uint8, device=device)
     run = lambda: ops.paged_attention(q, kc, vc, bt, sl, 0, B, q_len, Hq, Hkv, D, D ** -0.5,
                                       ctx + q_len, 4096, workspace=ws)
+    # Checked before it is timed: two sequences get K/V of known logical content (written into
+    # their pages in the cache layout), and the launch's output rows for them are compared with
+    # the CPU oracle's attention, one KV-head group each.
+    checked = _check_attention(run, kc, vc, bt, q, (0, B - 1), ctx, q_len, Hq, Hkv, D)
     for _ in range(3):
         run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -211,7 +220,42 @@ def attention_roofline(device, k):
     return {"kernel": "paged_attn_kernel<D=128> + merge, B=32 ctx=4096 q_len=%d, 4096 keys per workgroup" % q_len,
             "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("paged_attn_kernel<128, 1"),
+            "traffic_source": PMC_FILE, "checked": checked,
             "bytes_per_launch": kv_bytes, "avg_us": round(us, 2)}
+
+
+def _check_attention(run, kc, vc, bt, q, seqs, ctx, q_len, Hq, Hkv, D):
+    """Output rows of the timed attention launch against oracle.attention (the checker, on the
+    CPU) for the sequences `seqs`.  Raises on a mismatch; returns True."""
+    from oracle.attention import verify_attention
+    dev = q.device
+    n, G = ctx + q_len, Hq // Hkv
+    pos = torch.arange(n, device=dev)
+    slot = pos % 16
+    vslot = (slot & 3) | (((slot >> 3) & 1) << 2) | (((slot >> 2) & 1) << 3)
+    d = torch.arange(D, device=dev)
+    k_idx = (d // 8)[None, :] * 128 + slot[:, None] * 8 + (d % 8)[None, :]
+    v_idx = d[None, :] * 16 + vslot[:, None]
+    h = torch.arange(Hkv, device=dev)
+    logical = {}
+    for b in seqs:
+        k = (torch.randn(n, Hkv, D, device=dev) * 0.5).to(torch.bfloat16)
+        v = (torch.randn(n, Hkv, D, device=dev) * 0.5).to(torch.bfloat16)
+        page = bt[b].long()[pos // 16]
+        kc[page[:, None, None], h[None, :, None], k_idx[:, None, :]] = k
+        vc[page[:, None, None], h[None, :, None], v_idx[:, None, :]] = v
+        logical[b] = (k.cpu(), v.cpu())
+    out = run()
+    torch.cuda.synchronize()
+    out = out.float().cpu().view(-1, q_len, Hq, D)
+    qc = q.float().cpu().view(-1, q_len, Hq, D)
+    for i, b in enumerate(seqs):
+        kh = (3 * i + 1) % Hkv                        # one KV-head group per checked sequence
+        k, v = logical[b]
+        ref = verify_attention(qc[b][:, kh * G:(kh + 1) * G], k[:, kh:kh + 1], v[:, kh:kh + 1],
+                               [ctx + t for t in range(q_len)], D ** -0.5)
+        torch.testing.assert_close(out[b][:, kh * G:(kh + 1) * G], ref, rtol=2e-2, atol=2e-2)
+    return True
 
 
 def cpu_baseline(args, tokens_per_step, budget_s=30.0):

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle.attention import unpack_pages, verify_attention
-from tests.gpu_util import pack_cache, rb
+from tests.gpu_util import pack_cache, pack_cache_fast, rb
 
 pytestmark = pytest.mark.gpu
 
@@ -30,9 +30,12 @@ def _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed, shuffle=True):
         n = ctx_lens[b] + q_len
         k = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
         v = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
-        kb, vb = pack_cache(k, v, bt[b], num_pages)
-        used = bt[b].long()
-        kc[used], vc[used] = kb[used], vb[used]
+        if n > 600 or B > 4:
+            pack_cache_fast(kc, vc, k, v, bt[b])
+        else:
+            kb, vb = pack_cache(k, v, bt[b], num_pages)
+            used = bt[b].long()
+            kc[used], vc[used] = kb[used], vb[used]
         ks.append(k); vs.append(v)
         qs.append(torch.randn(q_len, Hq, D, generator=g).to(torch.bfloat16))
     return kc, vc, bt, ks, vs, qs
@@ -68,6 +71,99 @@ def test_paged_attention_matches_oracle(B, ctx_lens, q_len, Hq, Hkv, D, split):
         pos = [ctx_lens[b] + t for t in range(q_len)]
         ref = verify_attention(qs[b], ks[b], vs[b], pos, D ** -0.5)
         torch.testing.assert_close(out[b], ref, rtol=2e-2, atol=2e-2)
+
+
+def _arm(B, q_len, Hq, Hkv, D, max_ctx, split):
+    """The paged_attn_kernel<D, MT, NBUF, BT_PER_THREAD, RELOAD> instantiation a call takes
+    (the dispatch of launch_attn in csrc/sd_attention.hip, restated)."""
+    MT = 1 if q_len * (Hq // Hkv) <= 32 else 2
+    nbuf = {(64, 1): 4, (64, 2): 2, (128, 1): 3, (128, 2): 1}[(D, MT)]
+    tpw = split // 128
+    n_splits = max(1, -(-max_ctx // split))
+    if tpw <= nbuf:
+        return (D, MT, tpw, 1, False)
+    if MT == 1 and B * Hkv * n_splits >= 512:
+        return (D, MT, 1, 1 if split // 16 + 8 <= 256 else 4, True)
+    return (D, MT, nbuf, 1 if split // 16 + 8 * nbuf <= 256 else 4, True)
+
+
+def _ragged(B, lo, hi, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(lo, hi, (B,), generator=g).tolist()
+
+
+# Every dispatch arm of launch_attn against the oracle: ring (RELOAD) kernels at every depth,
+# four block-table entries per thread (splits beyond ~3.5k keys), the one-tile ring with two
+# workgroups per CU (>= 512 workgroups), lengths that end in the middle of a split and of a
+# 32-key tile.  (The non-ring arms with splits of 128 / 256 keys are in CASES above.)
+ARM_CASES = [
+    # B, ctx_lens, q_len, Hq, Hkv, D, split
+    (1, [1000], 6, 32, 8, 128, 384),                # <128,1,3,1,F>
+    (2, [1500, 333], 6, 32, 8, 128, 512),           # <128,1,3,1,T>: ring of 3, several splits
+    (2, [2300, 1029], 6, 32, 8, 128, 1024),         # <128,1,3,1,T>
+    (2, [4100, 777], 6, 32, 8, 128, 4096),          # <128,1,3,4,T>: 4 table entries per thread
+    (64, _ragged(64, 30, 700, 1) , 6, 16, 8, 128, 1024),   # <128,1,1,1,T>: 512 workgroups
+    (64, _ragged(64, 30, 500, 2)[:63] + [4200], 6, 16, 8, 128, 4096),  # <128,1,1,4,T>: 1024 wgs
+    (1, [1300], 6, 28, 4, 128, 512),                # <128,2,1,1,T>: two M tiles, one-tile ring
+    (1, [4200], 6, 28, 4, 128, 4096),               # <128,2,1,4,T>
+    (2, [900, 100], 2, 32, 8, 64, 384),             # <64,1,3,1,F>
+    (2, [1100, 515], 2, 32, 8, 64, 512),            # <64,1,4,1,F>
+    (2, [2100, 640], 2, 32, 8, 64, 1024),           # <64,1,4,1,T>
+    (1, [4300], 1, 32, 8, 64, 4096),                # <64,1,4,4,T>
+    (64, _ragged(64, 30, 600, 3), 2, 32, 8, 64, 1024),     # <64,1,1,1,T>
+    (64, _ragged(64, 30, 400, 4)[:63] + [4150], 2, 32, 8, 64, 4096),   # <64,1,1,4,T>
+    (1, [1000], 6, 14, 2, 64, 256),                 # <64,2,2,1,F>
+    (1, [1200], 6, 14, 2, 64, 512),                 # <64,2,2,1,T>
+    (1, [4200], 6, 14, 2, 64, 4096),                # <64,2,2,4,T>
+]
+
+ALL_ARMS = {
+    (128, 1, 1, 1, False), (128, 1, 2, 1, False), (128, 1, 3, 1, False), (128, 1, 3, 1, True),
+    (128, 1, 3, 4, True), (128, 1, 1, 1, True), (128, 1, 1, 4, True),
+    (128, 2, 1, 1, False), (128, 2, 1, 1, True), (128, 2, 1, 4, True),
+    (64, 1, 1, 1, False), (64, 1, 2, 1, False), (64, 1, 3, 1, False), (64, 1, 4, 1, False),
+    (64, 1, 4, 1, True), (64, 1, 4, 4, True), (64, 1, 1, 1, True), (64, 1, 1, 4, True),
+    (64, 2, 1, 1, False), (64, 2, 2, 1, False), (64, 2, 2, 1, True), (64, 2, 2, 4, True),
+}
+
+
+def _arm_of_case(c):
+    B, ctx_lens, q_len, Hq, Hkv, D, split = c
+    return _arm(B, q_len, Hq, Hkv, D, max(ctx_lens) + q_len, split)
+
+
+def _arm_id(c):
+    D, MT, nbuf, btp, reload_ = _arm_of_case(c)
+    return f"attn<{D},{MT},{nbuf},{btp},{'ring' if reload_ else 'whole'}>-B{c[0]}-split{c[6]}"
+
+
+def test_every_dispatch_arm_has_an_oracle_case():
+    extra = [(1, [260], 6, 28, 4, 128, 128), (1, [300], 6, 14, 2, 64, 128)]   # two-tile, 128-key splits
+    got = {_arm_of_case(c) for c in CASES + ARM_CASES + extra}
+    assert got == ALL_ARMS, (ALL_ARMS - got, got - ALL_ARMS)
+
+
+@pytest.mark.parametrize("case", ARM_CASES + [(1, [300], 6, 14, 2, 64, 128)], ids=_arm_id)
+def test_paged_attention_arm_matches_oracle(case):
+    B, ctx_lens, q_len, Hq, Hkv, D, split = case
+    ops = _ops()
+    kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed=sum(ctx_lens) % 1000 + split)
+    q = torch.cat(qs).reshape(B * q_len, Hq * D).cuda()
+    seq_lens = torch.tensor(ctx_lens, dtype=torch.int32).cuda()
+    max_ctx = max(ctx_lens) + q_len
+    out = ops.paged_attention(q, kc.cuda(), vc.cuda(), bt.cuda(), seq_lens, 0, B, q_len, Hq, Hkv, D,
+                              D ** -0.5, max_ctx, split)
+    torch.cuda.synchronize()
+    out = out.float().cpu().view(B, q_len, Hq, D)
+    # the oracle on every sequence of a small batch, on a spread of sequences of a large one
+    # (always the longest and the shortest)
+    order = sorted(range(B), key=lambda b: ctx_lens[b])
+    check = range(B) if B <= 4 else sorted({order[0], order[-1], order[B // 2], 0, B - 1, 17, 40})
+    for b in check:
+        pos = [ctx_lens[b] + t for t in range(q_len)]
+        ref = verify_attention(qs[b], ks[b], vs[b], pos, D ** -0.5)
+        torch.testing.assert_close(out[b], ref, rtol=2e-2, atol=2e-2)
+    assert torch.isfinite(out).all()
 
 
 @pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (28, 4, 128), (8, 1, 128), (14, 2, 64)])

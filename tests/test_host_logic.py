@@ -302,3 +302,19 @@ def test_worker_refuses_a_request_with_another_temperature():
     with pytest.raises(ValueError):
         w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("a", False),
                                              SequenceGroupMetadata("b", False), hot]))
+
+
+def test_fast_cache_packer_equals_the_elementwise_one():
+    """tests/gpu_util.pack_cache_fast (used for long sequences in the GPU attention tests)
+    writes exactly the layout of the element-by-element pack_cache."""
+    from tests.gpu_util import pack_cache, pack_cache_fast
+    g = torch.Generator().manual_seed(0)
+    for Hkv, D, n in ((2, 64, 37), (3, 128, 50)):
+        pages = (n + 15) // 16 + 2
+        bt = torch.randperm(pages, generator=g)[:(n + 15) // 16].to(torch.int32)
+        k = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
+        v = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
+        kc, vc = pack_cache(k, v, bt, pages)
+        kf, vf = torch.zeros_like(kc), torch.zeros_like(vc)
+        pack_cache_fast(kf, vf, k, v, bt)
+        assert torch.equal(kc, kf) and torch.equal(vc, vf)

@@ -22,6 +22,8 @@
 // split always goes to wave j%4, waves and splits are merged in index order.
 // So a token scored as one of k+1 verify rows gets bit-identical output to the
 // same token scored alone.
+#include <mutex>
+
 #include "sd_common.h"
 
 namespace {
@@ -415,16 +417,17 @@ size_t attn_lds_bytes(int split_tokens) {
 template <int D, int MT, int NBUF, int BTP, bool RELOAD>
 int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
   const size_t lds = attn_lds_bytes<D, MT, NBUF>(a.split_tokens);
-  static bool attr_set = false;  // raise the dynamic-LDS limit once per process
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(
+  // raise the dynamic-LDS limit once per instantiation and process (host threads may race here)
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute(
         reinterpret_cast<const void*>(paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      sd_set_error("sd_paged_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SD_ERR_HIP;
-    }
-    attr_set = true;
+  });
+  if (attr_err != hipSuccess) {
+    sd_set_error("sd_paged_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    return SD_ERR_HIP;
   }
   hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>), dim3(a.Hkv, a.n_splits, B), dim3(256),
                      lds, stream, a);

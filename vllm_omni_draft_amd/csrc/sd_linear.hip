@@ -17,6 +17,8 @@
 // into one accumulator tile; the 8 wave tiles are then added in wave order
 // through LDS.  That order is a function of K alone, so a token row gets the
 // same bits whether it runs alone (decode) or beside k other rows (verify).
+#include <mutex>
+
 #include "sd_common.h"
 
 namespace {
@@ -495,15 +497,16 @@ int choose_kc(int M, int K, int norm) {
 template <int EPI, int NORM, bool HALF, bool W8>
 int launch_w(LinArgs& a, hipStream_t st) {
   const size_t lds = lin_lds_bytes(a.M, a.KC, NORM);
-  static bool attr_set = false;  // once per instantiation and process
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM, HALF, W8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      sd_set_error("sd_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SD_ERR_HIP;
-    }
-    attr_set = true;
+  // once per instantiation and process (host threads may race here)
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_kernel<EPI, NORM, HALF, W8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_err != hipSuccess) {
+    sd_set_error("sd_linear: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    return SD_ERR_HIP;
   }
   // Up to two workgroups per CU (LDS permitting), each walking a strided tile list.
   const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;  // 16 waves per CU

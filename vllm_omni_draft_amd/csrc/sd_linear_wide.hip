@@ -16,6 +16,8 @@
 // as f32 [split][row][tile row] and wide_epilogue_kernel adds the splits in index order and
 // applies the epilogue, so a row's arithmetic depends on (N, K) only: never on how many rows
 // share the pass.
+#include <mutex>
+
 #include "sd_common.h"
 
 namespace {
@@ -420,15 +422,16 @@ size_t wide_ws_bytes(int M, int n_tiles, int K) {
 template <int MT, int EPI, int TPW, bool W8>
 int launch_gemm_w(const WideArgs& a, int S, hipStream_t st) {
   const size_t lds = (size_t)2 * MT * 16 * kXLD * sizeof(bf16_t);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI, TPW, W8>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) {
-      sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-      return SD_ERR_HIP;
-    }
-    attr_set = true;
+  // once per instantiation and process (host threads may race here)
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_kernel<MT, EPI, TPW, W8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_err != hipSuccess) {
+    sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    return SD_ERR_HIP;
   }
   const int groups = (a.n_tiles + a.group_tiles - 1) / a.group_tiles;
   hipLaunchKernelGGL((wide_gemm_kernel<MT, EPI, TPW, W8>), dim3(groups, S), dim3(kWideThreads), lds,
