@@ -19,7 +19,20 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
+# Diagnostic build with in-kernel timestamps (experiments/*_stamps.py load it through SD_AMD_LIB);
+# never loaded by the package on its own.
+STAMP_DIR := build/stamps
+STAMP_LIB := $(STAMP_DIR)/libsd_amd_stamps.so
+STAMP_OBJS := $(patsubst $(CSRC)/%.hip,$(STAMP_DIR)/%.o,$(SRCS))
+$(STAMP_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
+	@mkdir -p $(STAMP_DIR)
+	$(HIPCC) $(FLAGS) -DSD_ATTN_STAMPS -DSD_LIN_STAMPS -c $< -o $@
+$(STAMP_LIB): $(STAMP_OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(STAMP_OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+stamps: $(STAMP_LIB)
+
 clean:
 	rm -f $(OBJS) $(LIB)
+	rm -rf $(STAMP_DIR)
 
-.PHONY: all clean
+.PHONY: all clean stamps

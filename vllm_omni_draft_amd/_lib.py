@@ -129,6 +129,11 @@ SIGNATURES = {
 
 
 def lib_path() -> str:
+    """The in-tree library; SD_AMD_LIB names another build of the same sources (the
+    timestamp-instrumented one of `make stamps`, for experiments/)."""
+    override = os.environ.get("SD_AMD_LIB")
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
