@@ -210,6 +210,25 @@ int sd_paged_attention_blocked(const void* q, int64_t ldq, const void* k_cache,
                                void* workspace, size_t workspace_bytes,
                                sd_stream_t stream);
 
+/* sd_paged_attention for callers that cannot allocate or hold a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in
+ * the reference: it exists for those callers only.  Same arguments and bit-identical
+ * results, minus the workspace: the split partials go to a SD_STATIC_SCRATCH_BYTES array
+ * inside the library's code object (one copy per GPU, held until the process ends).  The
+ * call allocates nothing (no hipMalloc / hipFree); `out` must not be NULL; shapes whose
+ * partials ([B, Hkv, n_splits, m_pad, D + 2] f32) exceed the array return
+ * SD_ERR_WORKSPACE.  Every call on a GPU shares that GPU's array: calls that overlap on
+ * one GPU (two streams, two host threads) race; calls on one stream are safe.  The first
+ * call on a device looks the array's address up (hipGetSymbolAddress): make it outside
+ * stream capture.                                                              */
+#define SD_STATIC_SCRATCH_BYTES (16u << 20)
+int sd_paged_attention_static(const void* q, int64_t ldq, const void* k_cache,
+                              const void* v_cache, const int32_t* block_tables,
+                              int max_blocks_per_seq, const int32_t* seq_lens,
+                              int pos_offset, void* out, int64_t ldo, int B, int q_len,
+                              int Hq, int Hkv, int D, float scale, int max_ctx,
+                              int split_tokens, sd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Dense ops of a decoder layer at <= 16 token rows (weight streaming; replaces
  * the per-step model execution inside spec_decode.multi_step_worker and the

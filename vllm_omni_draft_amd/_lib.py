@@ -78,6 +78,10 @@ SIGNATURES = {
                                  i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
     "sd_paged_attention_blocked": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32,
                                          i32, i32, i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
+    "sd_paged_attention_static": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32,
+                                        i32, i32, C.c_float, i32, i32, vp]),
+    "sd_paged_attention_static": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32,
+                                        i32, i32, C.c_float, i32, i32, vp]),
     "sd_linear": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_linear": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_qkv_rope": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,

@@ -576,6 +576,67 @@ extern "C" int sd_paged_attention_blocked(const void* q, int64_t ldq, const void
   return MT == 1 ? launch_attn<64, 1>(a, Z, st) : launch_attn<64, 2>(a, Z, st);
 }
 
+// ------------------------------------------------------------------ allocation-free form
+// The split partials of sd_paged_attention_static live in this array instead of a caller's
+// workspace.  Every GPU the library runs on holds its own copy until the process ends.  In
+// host code the name is only a handle for hipGetSymbolAddress: the device address it yields
+// (one per device) is what kernels and memory calls are given.
+static __device__ __align__(256) unsigned char scratch[SD_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch`, per device
+
+int static_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  SD_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, SD_ERR_HIP,
+             "sd_paged_attention_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {  // first call on this device, which is the current one
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    SD_REQUIRE(e == hipSuccess && p, SD_ERR_HIP,
+               "sd_paged_attention_static: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+               hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return SD_OK;
+}
+}  // namespace
+
+extern "C" int sd_paged_attention_static(const void* q, int64_t ldq, const void* k_cache,
+                                         const void* v_cache, const int32_t* block_tables,
+                                         int max_blocks_per_seq, const int32_t* seq_lens,
+                                         int pos_offset, void* out, int64_t ldo, int B, int q_len,
+                                         int Hq, int Hkv, int D, float scale, int max_ctx,
+                                         int split_tokens, sd_stream_t stream) {
+  SD_REQUIRE(out, SD_ERR_INVALID,
+             "sd_paged_attention_static: out must not be NULL (the partials stay inside the library)");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && max_ctx >= 1 &&
+                 split_tokens >= 128 && (D == 64 || D == 128),
+             SD_ERR_INVALID, "sd_paged_attention_static: bad shape");
+  const int n_splits = n_splits_for(max_ctx, split_tokens);
+  if (n_splits > 1) {
+    const size_t m_pad = q_len * (Hq / Hkv) <= 32 ? 32 : 64;
+    const size_t need = (size_t)B * Hkv * n_splits * m_pad * (D + 2) * sizeof(float);
+    SD_REQUIRE(need <= SD_STATIC_SCRATCH_BYTES, SD_ERR_WORKSPACE,
+               "sd_paged_attention_static: %zu bytes of split partials (B=%d Hkv=%d splits=%d) exceed "
+               "the built-in scratch of %zu bytes: use sd_paged_attention with a workspace",
+               need, B, Hkv, n_splits, (size_t)SD_STATIC_SCRATCH_BYTES);
+  }
+  void* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != SD_OK) return rc;
+  // Nothing in the scratch must start at zero: every partial a merge reads was written by
+  // the same call's attention launch (splits past a sequence's length are never read).
+  return sd_paged_attention_blocked(q, ldq, k_cache, v_cache, block_tables, max_blocks_per_seq,
+                                    seq_lens, pos_offset, out, ldo, B, q_len, q_len, Hq, Hkv, D, scale,
+                                    max_ctx, split_tokens, ws, SD_STATIC_SCRATCH_BYTES, stream);
+}
+
 extern "C" int sd_rope_append(void* qkv, const float* rope_cs, int max_pos, void* k_cache,
                               void* v_cache, const int32_t* block_tables,
                               int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,

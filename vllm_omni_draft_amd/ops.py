@@ -230,6 +230,30 @@ def paged_attention(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, 
     return out
 
 
+STATIC_SCRATCH_BYTES = 16 << 20
+
+
+def paged_attention_static(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_len, Hq,
+                           Hkv, D, scale, max_ctx, split_tokens, out: torch.Tensor,
+                           ldq=None) -> torch.Tensor:
+    """paged_attention without a workspace and without any allocation: the split partials
+    live in an array inside the library; `out` ([B*q_len, Hq*D] bf16) is the caller's.  Calls
+    that overlap on one GPU race (they share the array)."""
+    _need(q, torch.bfloat16, "q")
+    _need(out, torch.bfloat16, "out")
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    if out.numel() < B * q_len * Hq * D:
+        raise _lib.SdError("paged_attention_static: out too small")
+    if ldq is None:
+        ldq = q.shape[-1] if q.dim() == 2 else Hq * D
+    _lib.check(_lib.load().sd_paged_attention_static(
+        _p(q), ldq, _p(k_cache), _p(v_cache), _p(block_tables), block_tables.shape[1],
+        _p(seq_lens), pos_offset, _p(out), Hq * D, B, q_len, Hq, Hkv, D, float(scale), max_ctx,
+        split_tokens, _stream()), "sd_paged_attention_static")
+    return out
+
+
 def paged_attention_blocked(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_total,
                             q_block, Hq, Hkv, D, scale, max_ctx, split_tokens=256,
                             workspace=None) -> torch.Tensor:
