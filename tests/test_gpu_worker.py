@@ -222,3 +222,144 @@ def test_worker_loads_and_shards_from_state_dicts_with_a_group_of_one():
     assert run(w2) == want and eng._graphs
     del w2, eng
     group.close()
+
+
+def _llama_pair():
+    tcfg = MODELS["llama"]
+    dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})
+    return (_product(tcfg, _bf(random_state(tcfg, seed=21))),
+            _product(dcfg, _bf(random_state(dcfg, seed=22))))
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_v1_scheduler_output_path_gives_the_autoregressive_streams(use_graph):
+    """The worker driven the way the reference's workers are driven
+    (execute_model(scheduler_output, delay_capture), /root/reference/src/qwen_image_gen/worker.py:47):
+    new requests, cached requests, a request that joins and one that is finished mid-flight."""
+    from tests.test_host_logic import _NewRequestData, _sched
+    tw, dw = _llama_pair()
+    prompts = {"r0": [5, 9, 200, 31, 7], "r1": list(range(40, 73)), "r2": [3, 3, 3]}
+    want = {r: _generate(_engine(tw, None, 0), [p], 30)[0] for r, p in prompts.items()}
+    w = _worker(tw, dw, 3, use_graph)
+    got = {r: [] for r in prompts}
+
+    def take(out):
+        assert out.logprobs is None and len(out.pooler_output) == len(out.req_ids)
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            assert 1 <= len(toks) <= 4
+            got[r].extend(toks)
+
+    N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0, "max_tokens": 30})
+    take(w.execute_model(_sched(new=[N("r0"), N("r1")]), delay_capture=False))
+    running, step, finished = ["r0", "r1"], 0, []
+    while min(len(got[r]) for r in ("r1", "r2")) < 30:
+        new = [N("r2")] if step == 2 else []
+        if step == 6:
+            running.remove("r0")
+            finished = ["r0"]
+        take(w.execute_model(_sched(new=new, cached=running, finished=finished,
+                                    old_layout=bool(step & 1))))
+        finished = []
+        if step == 2:
+            running.append("r2")
+        step += 1
+    assert len(got["r0"]) >= 7
+    for r in prompts:
+        n = min(30, len(got[r]))
+        assert got[r][:n] == want[r][:n], r
+
+
+class _StubProposer:
+    """A proposer made outside the worker: it knows the target's true stream and proposes a
+    continuation of `lens[r]` tokens for request r, with an error injected at position
+    `wrong_at[r]` (None: none)."""
+
+    def __init__(self, want, prompts, k):
+        self.want, self.prompts, self.k = want, prompts, k
+        self.done = {}          # request -> tokens emitted so far
+        self.order = []
+        self.plan = {}          # request -> (len, wrong_at)
+        self.calls = 0
+
+    def get_spec_proposals(self, execute_model_req, seq_ids_with_bonus_token_in_last_step):
+        from vllm_omni_draft_amd.spec_decode_worker import SpeculativeProposals
+        self.calls += 1
+        B, k = len(self.order), self.k
+        ids = torch.zeros(B, k, dtype=torch.int64)
+        lens = torch.zeros(B, dtype=torch.int32)
+        for b, r in enumerate(self.order):
+            n, wrong = self.plan[r]
+            cont = list(self.want[r][self.done[r]:self.done[r] + n])
+            if wrong is not None and wrong < len(cont):
+                cont[wrong] = (cont[wrong] + 1) % 256
+            lens[b] = len(cont)
+            ids[b, :len(cont)] = torch.tensor(cont, dtype=torch.int64)
+        return SpeculativeProposals(ids.cuda(), None, lens.cuda())
+
+
+def test_a_foreign_proposer_plugs_into_the_scorer():
+    """MQAScorer.score_proposals verifies proposals it did not make: full, ragged, empty and
+    partly wrong continuations; the emitted streams are the target's autoregressive ones and
+    every step emits exactly (accepted prefix + 1) tokens."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeConfig, SpecDecodeWorker)
+    tw, _ = _llama_pair()
+    k = 4
+    prompts = {"a": [5, 9, 200, 31, 7], "b": list(range(40, 73)), "c": [3, 3, 3]}
+    want = {r: _generate(_engine(tw, None, 0), [p], 40)[0] for r, p in prompts.items()}
+    stub = _StubProposer(want, prompts, k)
+    w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=None, num_speculative_tokens=k,
+                                          external_proposals=True, max_num_seqs=3, max_model_len=200,
+                                          split_tokens=128), proposer=stub)
+    w.init_device()
+    w.load_model()
+    out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata(r, True, p)
+                                               for r, p in prompts.items()]))
+    got = {r: list(t) for r, t in zip(out.req_ids, out.sampled_token_ids)}
+    stub.order = list(prompts)
+    plans = [{"a": (4, None), "b": (2, None), "c": (0, None)},      # full, ragged, empty
+             {"a": (4, 1), "b": (4, 0), "c": (3, 2)},               # wrong at 1, at 0, at 2
+             {"a": (1, None), "b": (4, 3), "c": (4, None)}]
+    for step in range(9):
+        stub.plan = plans[step % 3]
+        stub.done = {r: len(got[r]) for r in prompts}
+        out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata(r, False) for r in prompts]))
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            n, wrong = stub.plan[r]
+            assert len(toks) == (n if wrong is None else min(wrong, n)) + 1, (step, r, toks)
+            got[r].extend(toks)
+    assert stub.calls == 9
+    for r in prompts:
+        assert got[r] == want[r][:len(got[r])], r
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_scheduler_supplied_spec_tokens_are_verified(use_graph):
+    """A V1 scheduler output's scheduled_spec_decode_tokens (proposals made by the engine above
+    the worker) are what an external_proposals worker verifies in that step."""
+    from tests.test_host_logic import _NewRequestData, _sched
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
+    tw, _ = _llama_pair()
+    k = 3
+    prompts = {"a": [5, 9, 200, 31, 7], "b": list(range(40, 73))}
+    want = {r: _generate(_engine(tw, None, 0), [p], 40)[0] for r, p in prompts.items()}
+    w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=None, num_speculative_tokens=k,
+                                          external_proposals=True, max_num_seqs=2, max_model_len=200,
+                                          split_tokens=128, use_graph=use_graph))
+    w.init_device()
+    w.load_model()
+    out = w.execute_model(_sched(new=[_NewRequestData(r, p) for r, p in prompts.items()]))
+    got = {r: list(t) for r, t in zip(out.req_ids, out.sampled_token_ids)}
+    for step in range(8):
+        spec = {}
+        if step % 4 != 3:                                   # every fourth step carries no proposals
+            spec["a"] = want["a"][len(got["a"]):len(got["a"]) + k]
+        if step % 2 == 0:
+            spec["b"] = [(t + 1) % 256 for t in want["b"][len(got["b"]):len(got["b"]) + 2]]
+        out = w.execute_model(_sched(cached=list(prompts), spec=spec))
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            want_n = (k + 1) if (r == "a" and "a" in spec) else 1
+            assert len(toks) == want_n, (step, r, toks)
+            got[r].extend(toks)
+    for r in prompts:
+        assert got[r] == want[r][:len(got[r])], r

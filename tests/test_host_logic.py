@@ -318,3 +318,117 @@ def test_fast_cache_packer_equals_the_elementwise_one():
         kf, vf = torch.zeros_like(kc), torch.zeros_like(vc)
         pack_cache_fast(kf, vf, k, v, bt)
         assert torch.equal(kc, kf) and torch.equal(vc, vf)
+
+
+# ---- the V1 step contract (fields as transcribed at /root/reference/src/doc/engine_core.md:280-313)
+from dataclasses import dataclass as _dc, field as _field
+from typing import Any as _Any, Optional as _Opt
+
+
+@_dc
+class _NewRequestData:
+    req_id: str
+    prompt_token_ids: list
+    sampling_params: _Any = None
+    mm_inputs: list = _field(default_factory=list)
+    block_ids: list = _field(default_factory=list)
+    num_computed_tokens: int = 0
+
+
+@_dc
+class _CachedRequestData:
+    req_ids: list
+    resumed_from_preemption: list = _field(default_factory=list)
+    new_token_ids: list = _field(default_factory=list)
+    new_block_ids: list = _field(default_factory=list)
+    num_computed_tokens: list = _field(default_factory=list)
+
+
+@_dc
+class _SchedulerOutput:
+    scheduled_new_reqs: list
+    scheduled_cached_reqs: _Any
+    num_scheduled_tokens: dict
+    total_num_scheduled_tokens: int
+    scheduled_spec_decode_tokens: dict = _field(default_factory=dict)
+    scheduled_encoder_inputs: dict = _field(default_factory=dict)
+    num_common_prefix_blocks: list = _field(default_factory=list)
+    finished_req_ids: set = _field(default_factory=set)
+    free_encoder_mm_hashes: list = _field(default_factory=list)
+    structured_output_request_ids: dict = _field(default_factory=dict)
+    grammar_bitmask: _Opt[_Any] = None
+    kv_connector_metadata: _Opt[_Any] = None
+
+
+def _sched(new=(), cached=(), finished=(), spec=None, old_layout=False):
+    n_tok = {r.req_id: len(r.prompt_token_ids) for r in new}
+    n_tok.update({r: 1 for r in cached})
+    c = ([type("C", (), {"req_id": r})() for r in cached] if old_layout
+         else _CachedRequestData(list(cached)))
+    return _SchedulerOutput(list(new), c, n_tok, sum(n_tok.values()),
+                            scheduled_spec_decode_tokens=spec or {}, finished_req_ids=set(finished))
+
+
+def test_worker_accepts_the_v1_scheduler_output():
+    """execute_model(scheduler_output, delay_capture) as the reference's workers are called
+    (/root/reference/src/qwen_image_gen/worker.py:47-51); the result carries every field of
+    ModelRunnerOutput (/root/reference/src/doc/engine_core.md:316-340)."""
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeWorker
+    eng = FakeEngine()
+    w = SpecDecodeWorker(vllm_config=None, local_rank=0, rank=0, distributed_init_method="",
+                         is_driver_worker=True, engine=eng)
+    N = lambda rid, tok: _NewRequestData(rid, [tok, 1, 2], sampling_params={"temperature": None})
+    out = w.execute_model(_sched(new=[N("a", 1), N("b", 2)]), delay_capture=False)
+    assert out.req_ids == ["a", "b"] and out.sampled_token_ids == [[100], [200]]
+    assert out.req_id_to_index == {"a": 0, "b": 1}
+    for name in ("logprobs", "prompt_logprobs_dict", "pooler_output", "kv_connector_output",
+                 "num_nans_in_logits"):
+        assert hasattr(out, name)
+    assert out.logprobs is None and out.pooler_output == [None, None]
+    assert out.prompt_logprobs_dict == {"a": None, "b": None}
+    # running requests first (the scheduler's order), a new prompt joins, both cached layouts
+    out = w.execute_model(_sched(new=[N("c", 3)], cached=["b", "a"]))
+    assert out.req_ids == ["b", "a", "c"] and out.sampled_token_ids == [[201, 201], [101], [300]]
+    out = w.execute_model(_sched(cached=["c", "b"], finished=["a"], old_layout=True))
+    assert eng.owners == [3, 2] and out.sampled_token_ids == [[302], [202, 202]]
+    # a finished id the worker never saw is ignored, as upstream's runners do
+    out = w.execute_model(_sched(cached=["b", "c"], finished=["never-seen"]))
+    assert out.req_ids == ["b", "c"]
+    with pytest.raises(ValueError, match="chunked prefill"):
+        so = _sched(new=[N("d", 4)], cached=["b", "c"])
+        so.num_scheduled_tokens["d"] = 2
+        w.execute_model(so)
+    with pytest.raises(ValueError, match="makes its own"):        # proposals for a worker with a draft
+        w.execute_model(_sched(cached=["b", "c"], spec={"b": [1, 2]}))
+    with pytest.raises(TypeError):
+        w.execute_model(object())
+
+
+def test_a_refused_step_loses_no_tokens():
+    """One running request plus one bad prompt: the step raises BEFORE the running sequence is
+    stepped, so a caller that drops the bad request and retries gets every token."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SamplingParams,
+                                                        SequenceGroupMetadata, SpecDecodeWorker)
+    eng = FakeEngine()
+    eng.cfg.max_seq_len = 8
+    eng.cfg.temperature = 0.0
+    w = SpecDecodeWorker(vllm_config=None, engine=eng)
+    P = lambda rid, toks, **kw: SequenceGroupMetadata(rid, True, toks, SamplingParams(**kw))
+    R = lambda rid: SequenceGroupMetadata(rid, False)
+    w.execute_model(ExecuteModelRequest([P("a", [1, 1])]))
+    bad = [P("long", list(range(8))),                   # prompt + 1 > max_seq_len
+           P("empty", []),
+           P("hot", [2, 2], temperature=0.7),           # another temperature
+           P("seeded", [2, 2], seed=11),                # per-request seed
+           P("a", [2, 2])]                              # already running
+    for g in bad:
+        with pytest.raises((ValueError, KeyError)):
+            w.execute_model(ExecuteModelRequest([R("a"), g]))
+        assert eng.steps == 0 and eng.active == 1       # nothing ran, nothing was admitted
+    with pytest.raises(KeyError):                       # listed twice
+        w.execute_model(ExecuteModelRequest([R("a"), R("a")]))
+    with pytest.raises(RuntimeError):                   # too many prompts for the free slots
+        w.execute_model(ExecuteModelRequest([R("a")] + [P(f"p{i}", [3, 3]) for i in range(3)]))
+    assert eng.steps == 0 and eng.active == 1
+    out = w.execute_model(ExecuteModelRequest([R("a"), P("b", [2, 2])]))
+    assert out.sampled_token_ids == [[101], [200]] and eng.steps == 1

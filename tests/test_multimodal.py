@@ -53,6 +53,9 @@ def test_mrope_positions_reject_inconsistent_prompts():
     with pytest.raises(ValueError):
         multimodal.mrope_positions([IMG, 3, IMG], IMG, [(1, 2, 2)])         # run without a grid
     with pytest.raises(ValueError):
+        ids, grids = _prompt([2, (5, 4, 4), 3])                              # a clip: more frames than
+        multimodal.mrope_positions(ids, IMG, grids)                          # merged rows / columns
+    with pytest.raises(ValueError):
         multimodal.image_token_count((1, 3, 4))
 
 

@@ -63,6 +63,10 @@ class EngineConfig:
     # tokens after the most recent match are proposed (none if nothing matches).
     ngram_max: int = 0
     ngram_min: int = 1
+    # Proposals made outside the engine (k > 0, draft = None, ngram_max = 0): the caller hands
+    # every step up to k tokens per sequence (set_external_proposals / step(proposals=...)),
+    # the engine only verifies them.  A sequence without proposals gets one target token.
+    external_proposals: bool = False
     # With more than this many running sequences a step does not speculate (0 = always
     # speculate): one target token per sequence, and one draft pass that only keeps the
     # draft's KV cache in step (upstream's speculative_disable_by_batch_size).
@@ -96,8 +100,11 @@ class SpecEngine:
             raise ValueError(f"unknown acceptance_method {cfg.acceptance_method!r}")
         self.typical = cfg.acceptance_method == "typical_acceptance_sampler"
         self.ngram = cfg.k > 0 and draft is None and cfg.ngram_max > 0
-        if cfg.k > 0 and draft is None and not self.ngram:
-            raise ValueError("k > 0 needs a draft model (or ngram_max > 0 for prompt lookup)")
+        self.external = cfg.k > 0 and draft is None and cfg.external_proposals and not self.ngram
+        self.host_props = self.ngram or self.external     # proposals are uploaded by the host
+        if cfg.k > 0 and draft is None and not self.host_props:
+            raise ValueError("k > 0 needs a draft model (or ngram_max > 0 for prompt lookup, or "
+                             "external_proposals)")
         if self.ngram and not 1 <= cfg.ngram_min <= cfg.ngram_max:
             raise ValueError("need 1 <= ngram_min <= ngram_max")
         if draft is not None and draft.cfg.vocab != target.cfg.vocab:
@@ -139,8 +146,10 @@ class SpecEngine:
         self.t_kv = PagedKVCache(target.cfg, pages, B, self.max_ctx, dev)
         self.d_kv = (PagedKVCache(draft.cfg, pages, B, self.max_ctx, dev)
                      if self.draft is not None else None)
+        self._pending_props: Optional[List[List[int]]] = None
         if self.ngram:
             self.history: List[List[int]] = [[] for _ in range(B)]   # prompt + emitted tokens
+        if self.host_props:
             self.ext_props = torch.zeros(B, k, **dict(dtype=torch.int32, device=dev))
             self.prop_lens = torch.zeros(B, **dict(dtype=torch.int32, device=dev))
             self._props_host = torch.zeros(B, k, dtype=torch.int32).pin_memory()
@@ -149,7 +158,8 @@ class SpecEngine:
         i32 = dict(dtype=torch.int32, device=dev)
         self.seq_lens = torch.zeros(B, **i32)
         self.tok_buf = torch.zeros(B, k + 2, **i32)
-        self.gen_tokens = torch.zeros(B, cfg.gen_capacity, **i32)
+        # every token a sequence can generate fits (a multi-step read-back slices this buffer)
+        self.gen_tokens = torch.zeros(B, max(cfg.gen_capacity, self.max_ctx), **i32)
         self.gen_counts = torch.zeros(B, **i32)
         self.counters = torch.zeros(3, dtype=torch.int64, device=dev)
         self.zero_lens = torch.zeros(B, **i32)
@@ -395,7 +405,7 @@ class SpecEngine:
         if self._spec_disabled():
             self._enqueue_no_spec_step()
             return
-        if self.ngram:
+        if self.host_props:
             self._enqueue_lookup_proposals()
         else:
             self._enqueue_propose(fused)
@@ -565,7 +575,7 @@ class SpecEngine:
     def _enqueue_accept(self, fused: bool = False) -> None:
         """Acceptance (rejection sampling or greedy match) and the state update."""
         B, k = self.active, self.k
-        lens = self.prop_lens[:B] if self.ngram else None
+        lens = self.prop_lens[:B] if self.host_props else None
         if fused:
             ops.verify_from_partials(self.part_val, self.part_idx, self.tok_buf[:B],
                                      self.out_ids[:B], self.counters, self.seq_lens[:B],
@@ -619,12 +629,31 @@ class SpecEngine:
         """Fresh uniforms for the coming step, drawn on the device (no host work, no sync)."""
         ops.fill_uniforms(self.u_all, self.cfg.seed, self.u_counter)
 
-    def step(self, sync: bool = True) -> Optional[List[List[int]]]:
+    def set_external_proposals(self, proposals: Optional[Sequence[Sequence[int]]]) -> None:
+        """Proposals of the coming step, one token list (at most k are used) per active
+        sequence, in slot order; None or an empty list proposes nothing for a sequence."""
+        if not self.external:
+            raise RuntimeError("this engine makes its own proposals (EngineConfig.external_proposals "
+                               "is for engines without a draft model)")
+        if proposals is not None:
+            if len(proposals) != self.active:
+                raise ValueError(f"{len(proposals)} proposal lists for {self.active} sequences")
+            proposals = [[] if p is None else [int(t) for t in p] for p in proposals]
+            for p in proposals:
+                if any(t < 0 or t >= self.V for t in p):
+                    raise ValueError("proposed token outside the vocabulary")
+        self._pending_props = proposals
+
+    def step(self, sync: bool = True,
+             proposals: Optional[Sequence[Sequence[int]]] = None) -> Optional[List[List[int]]]:
         """Runs one step for every active sequence.  With sync=True returns the
         tokens each sequence emitted in this step (the V1 worker contract:
-        sampled_token_ids, one variable-length list per request)."""
+        sampled_token_ids, one variable-length list per request).  proposals: see
+        set_external_proposals."""
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before a synchronous step")
+        if proposals is not None:
+            self.set_external_proposals(proposals)
         with torch.cuda.stream(self.stream):
             return self._step(sync)
 
@@ -650,9 +679,13 @@ class SpecEngine:
         # contexts on the single-split path (no partials, no merge kernel).  The split
         # boundaries stay at fixed absolute positions, so results do not depend on the bound.
         self._ctx = self._ctx_bucket()
-        if self.ngram:
+        if self.host_props:
+            pending, self._pending_props = self._pending_props, None
             for b in range(B):
-                cont = self._lookup(self.history[b])
+                if self.ngram:
+                    cont = self._lookup(self.history[b])
+                else:
+                    cont = list(pending[b])[:k] if pending is not None else []
                 self._lens_host[b] = len(cont)
                 for j in range(k):
                     self._props_host[b, j] = cont[j] if j < len(cont) else 0
@@ -710,8 +743,8 @@ class SpecEngine:
         arrive one call late; flush() returns the last step's.  Every step depends on device
         state only; the host's length bounds (pages, context bucket) allow for the step in
         flight.  Not with prompt lookup (its proposals come from the tokens read back)."""
-        if self.ngram:
-            raise RuntimeError("step_overlapped: prompt-lookup proposals need each step's tokens")
+        if self.host_props:
+            raise RuntimeError("step_overlapped: host-made proposals need each step's tokens")
         with torch.cuda.stream(self.stream):
             if self.active == 0:
                 return []
@@ -757,6 +790,17 @@ class SpecEngine:
             lib.sd_graph_destroy(g)
         self._graphs.clear()
 
+    def close(self) -> None:
+        """Destroys the captured step graphs (also on garbage collection)."""
+        try:
+            self._drop_graphs()
+        except Exception:
+            pass
+
+    def __del__(self):
+        if getattr(self, "_graphs", None):
+            self.close()
+
     def read_back(self) -> List[List[int]]:
         """Synchronises and returns the tokens emitted since the last read-back."""
         with torch.cuda.stream(self.stream):
@@ -783,7 +827,7 @@ class SpecEngine:
         out: List[List[int]] = []
         for b in range(B):
             lo, hi = self.host_gen[b], counts[b]
-            toks = self.gen_tokens[b, lo:min(hi, self.cfg.gen_capacity)].tolist() if hi > lo else []
+            toks = self.gen_tokens[b, lo:min(hi, self.gen_tokens.shape[1])].tolist() if hi > lo else []
             out.append(toks)
             self.host_gen[b] = hi
             self.host_lens[b] = lens[b]

@@ -34,7 +34,11 @@ def mrope_positions(token_ids: Sequence[int], image_token_id: int,
 
     Text tokens count up on all three components.  The tokens of an image whose patch grid is
     (t, h, w) take temporal position start + frame, height start + row, width start + column
-    of the merged grid; the text after it continues at start + max(h, w) / merge."""
+    of the merged grid; the text after it continues at start + max(h, w) / merge, as the image
+    path of transformers' Qwen2VLModel.get_rope_index in this image does (checked bit for bit in
+    tests/test_multimodal.py).  That rule ignores the temporal extent, so a grid with more frames
+    than merged rows and columns (a video clip, whose positions older transformers releases
+    continued one past the largest of the three components) is refused rather than guessed."""
     ids = list(token_ids)
     n = len(ids)
     pos = torch.zeros(3, n, dtype=torch.int32)
@@ -58,7 +62,10 @@ def mrope_positions(token_ids: Sequence[int], image_token_id: int,
         pos[0, i:i + cnt] = (tt.reshape(-1) + cur).int()
         pos[1, i:i + cnt] = (hh.reshape(-1) + cur).int()
         pos[2, i:i + cnt] = (ww.reshape(-1) + cur).int()
-        cur += max(h, w) // spatial_merge
+        if t > max(gh, gw):
+            raise ValueError(f"grid {(t, h, w)}: {t} frames exceed the merged grid's extent "
+                             f"{max(gh, gw)}; video clips are not supported")
+        cur += max(gh, gw)
         i += cnt
     if gi != len(grids):
         raise ValueError("fewer runs of image tokens than image grids")

@@ -38,7 +38,12 @@ class SamplingParams:
     # None: the worker's temperature.  One temperature serves the whole batch (the step is one
     # captured graph); a request that asks for another one is refused, not silently served.
     temperature: Optional[float] = None
+    # Stop conditions belong to the caller's scheduler (scheduler.SpecDecodeScheduler enforces
+    # max_tokens and the end-of-sequence token); the worker emits tokens until a request is
+    # listed as finished, like a V1 model runner.
     max_tokens: int = 16
+    # A per-request seed is refused: the uniforms of a step are drawn on the device from one
+    # counter-based stream per worker (SpecDecodeConfig.seed), not per request.
     seed: Optional[int] = None
     ignore_eos: bool = True
 
@@ -62,6 +67,9 @@ class ExecuteModelRequest:
     seq_group_metadata_list: List[SequenceGroupMetadata]
     num_lookahead_slots: int = 0
     finished_requests_ids: List[str] = field(default_factory=list)
+    # request_id -> proposed continuation (at most k tokens) made outside this worker, for a
+    # worker built with SpecDecodeConfig.external_proposals (no draft model): verified this step
+    external_proposals: Optional[Dict[str, List[int]]] = None
 
 
 @dataclass
@@ -84,10 +92,74 @@ class SpeculativeScores:
 
 @dataclass
 class ModelRunnerOutput:
+    """What a V1 worker returns from execute_model: the fields of
+    /root/reference/src/doc/engine_core.md:316-340, in that order.  This worker fills the
+    request index and the variable-length token lists; it computes no log-probabilities,
+    pooled outputs or KV-connector output (None / empty, as a model runner that was not
+    asked for them returns)."""
     req_ids: List[str]
     req_id_to_index: Dict[str, int]
     sampled_token_ids: List[List[int]]
+    logprobs: Optional[object] = None
+    prompt_logprobs_dict: Dict[str, Optional[object]] = field(default_factory=dict)
+    pooler_output: List[Optional[torch.Tensor]] = field(default_factory=list)
+    kv_connector_output: Optional[object] = None
+    num_nans_in_logits: Optional[Dict[str, int]] = None
+    # not a V1 field: acceptance counters of this worker, when a collection interval elapsed
     spec_decode_metrics: Optional[SpecDecodeWorkerMetrics] = None
+
+
+def _get(obj, name, default=None):
+    """Field `name` of a dataclass-like object or of a dict."""
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+def request_from_scheduler_output(so) -> "ExecuteModelRequest":
+    """ExecuteModelRequest from a V1 SchedulerOutput (duck-typed on the fields transcribed at
+    /root/reference/src/doc/engine_core.md:280-313): `scheduled_new_reqs` become prompts
+    (req_id, prompt_token_ids, sampling_params, and mm_inputs / mm_kwargs when they carry
+    image_grid_thw), `scheduled_cached_reqs` running requests (one object with `req_ids`, or a
+    list of objects with `req_id`: both layouts exist upstream), `finished_req_ids` is passed
+    through, `scheduled_spec_decode_tokens` (req_id -> proposed token ids) become the step's
+    external proposals.  Running requests come first, in the scheduler's order."""
+    new = list(_get(so, "scheduled_new_reqs", None) or [])
+    cached = _get(so, "scheduled_cached_reqs", None)
+    if cached is None:
+        cached_ids: List[str] = []
+    elif _get(cached, "req_ids", None) is not None:
+        cached_ids = list(_get(cached, "req_ids"))
+    else:
+        cached_ids = [_get(c, "req_id") for c in cached]
+    n_tok = _get(so, "num_scheduled_tokens", None) or {}
+    metas = [SequenceGroupMetadata(rid, False) for rid in cached_ids]
+    for r in new:
+        rid = _get(r, "req_id")
+        prompt = list(_get(r, "prompt_token_ids", None) or [])
+        if rid in n_tok and n_tok[rid] != len(prompt):
+            raise ValueError(f"request {rid}: {n_tok[rid]} of {len(prompt)} prompt tokens scheduled; "
+                             "this worker prefills a prompt in one step (no chunked prefill)")
+        if _get(r, "num_computed_tokens", 0):
+            raise ValueError(f"request {rid}: prefix-cached prompt tokens are not supported")
+        sp = _get(r, "sampling_params", None)
+        params = SamplingParams(temperature=_get(sp, "temperature", None),
+                                max_tokens=_get(sp, "max_tokens", 16) or 16,
+                                seed=_get(sp, "seed", None),
+                                ignore_eos=bool(_get(sp, "ignore_eos", True))) if sp is not None \
+            else SamplingParams()
+        mm = None
+        for cand in (_get(r, "mm_inputs", None), _get(r, "mm_kwargs", None)):
+            items = cand if isinstance(cand, (list, tuple)) else [cand]
+            for item in items:
+                if item is not None and _get(item, "image_grid_thw", None) is not None:
+                    mm = item if isinstance(item, dict) else {
+                        k: _get(item, k) for k in ("image_grid_thw", "pixel_values", "image_embeds")
+                        if _get(item, k, None) is not None}
+        metas.append(SequenceGroupMetadata(rid, True, prompt, params, multi_modal_data=mm))
+    spec = _get(so, "scheduled_spec_decode_tokens", None) or {}
+    return ExecuteModelRequest(metas, finished_requests_ids=list(_get(so, "finished_req_ids", None) or []),
+                               external_proposals={rid: list(t) for rid, t in spec.items()} or None)
 
 
 # --------------------------------------------------------------------------- components
@@ -162,6 +234,26 @@ class NGramProposer(SpeculativeProposer):
             proposal_lens=eng.prop_lens[:B], no_proposals=(B == 0))
 
 
+class ExternalProposer(SpeculativeProposer):
+    """Proposals that arrive with the step (ExecuteModelRequest.external_proposals, or a V1
+    scheduler output's scheduled_spec_decode_tokens): the engine uploaded them in
+    prepare_step; this hands out the views, like NGramProposer."""
+
+    def __init__(self, engine: SpecEngine):
+        self.engine = engine
+
+    def get_spec_proposals(self, execute_model_req=None,
+                           seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
+        eng = self.engine
+        B = eng.active
+        with torch.cuda.stream(eng.stream):
+            eng._enqueue_lookup_proposals()
+        return SpeculativeProposals(
+            proposal_token_ids=eng.draft_ids[:B],
+            proposal_probs=eng.d_probs[:B] if eng.sampling else None,
+            proposal_lens=eng.prop_lens[:B], no_proposals=(B == 0))
+
+
 class MQAScorer(SpeculativeScorer):
     """Scores all k+1 positions of every sequence in ONE target pass: the k+1
     query tokens of a sequence share each KV page read (no batch expansion)."""
@@ -169,10 +261,36 @@ class MQAScorer(SpeculativeScorer):
     def __init__(self, engine: SpecEngine):
         self.engine = engine
 
+    def _take_proposals(self, proposals: SpeculativeProposals) -> None:
+        """Copies proposals that were not made by this engine's own proposer (their token ids
+        are not the engine's buffer) into the token window and the proposal lengths."""
+        eng = self.engine
+        B, k = eng.active, eng.k
+        ids = proposals.proposal_token_ids
+        if ids.data_ptr() == eng.draft_ids.data_ptr():
+            return                                  # the engine's own proposals: already in place
+        if not getattr(eng, "host_props", False):
+            raise ValueError("this engine proposes with its draft model; proposals made elsewhere "
+                             "need a worker built with external_proposals (no draft model)")
+        if tuple(ids.shape) != (B, k) or proposals.proposal_lens.numel() != B:
+            raise ValueError(f"proposals must be [{B}, {k}] token ids with {B} lengths")
+        if eng.sampling and proposals.proposal_probs is None:
+            raise ValueError("sampling needs the proposals' probability rows (one-hot for "
+                             "deterministic proposers)")
+        eng.ext_props[:B].copy_(ids.to(device=eng.device, dtype=torch.int32))
+        eng.prop_lens[:B].copy_(proposals.proposal_lens.to(device=eng.device, dtype=torch.int32)
+                                .clamp_(0, k))
+        ops.set_proposals(eng.ext_props[:B], eng.tok_buf[:B], k)
+        ops.gather_proposals(eng.tok_buf[:B], eng.draft_ids[:B], k)
+        if eng.sampling:
+            eng.d_probs[:B].copy_(proposals.proposal_probs.to(device=eng.device, dtype=torch.float32))
+
     def score_proposals(self, execute_model_req=None, proposals=None) -> SpeculativeScores:
         eng = self.engine
         B, k = eng.active, eng.k
         with torch.cuda.stream(eng.stream):
+            if proposals is not None:
+                self._take_proposals(proposals)
             eng._enqueue_score()
         logits = eng.t_logits[:B * (k + 1)].view(B, k + 1, eng.V)
         if eng.sampling:
@@ -276,6 +394,10 @@ class SpecDecodeConfig:
     # without a draft model: prompt-lookup proposals from n-grams of these sizes
     ngram_prompt_lookup_max: int = 0
     ngram_prompt_lookup_min: int = 1
+    # without a draft model and without prompt lookup: proposals come with every step
+    # (ExecuteModelRequest.external_proposals / scheduled_spec_decode_tokens) or from the
+    # `proposer` object given to the worker; the engine only verifies
+    external_proposals: bool = False
     max_num_seqs: int = 1
     max_model_len: int = 2048
     temperature: float = 0.0
@@ -318,7 +440,10 @@ class SpecDecodeWorker:
 
     def __init__(self, vllm_config, local_rank: int = 0, rank: int = 0,
                  distributed_init_method: Optional[str] = None, is_driver_worker: bool = True,
-                 engine: Optional[SpecEngine] = None):
+                 engine: Optional[SpecEngine] = None,
+                 proposer: Optional[SpeculativeProposer] = None):
+        """proposer: a SpeculativeProposer made elsewhere (any object with get_spec_proposals);
+        needs external_proposals.  Its proposals are verified by the scorer every step."""
         cfg = getattr(vllm_config, "spec_decode_config", vllm_config)
         self.config: SpecDecodeConfig = cfg
         self.local_rank, self.rank = local_rank, rank
@@ -327,6 +452,7 @@ class SpecDecodeWorker:
         self.engine: Optional[SpecEngine] = engine
         self.proposer_worker: Optional[MultiStepWorker] = None
         self.proposer: Optional[SpeculativeProposer] = None
+        self._foreign_proposer = proposer
         self.scorer: Optional[SpeculativeScorer] = None
         self.metrics: Optional[AsyncMetricsCollector] = None
         self._slot_of: Dict[str, int] = {}
@@ -376,6 +502,7 @@ class SpecDecodeWorker:
             use_graph=c.use_graph and (tp == 1 or c.tensor_parallel_graph), rows=c.rows,
             draft_rows=c.draft_rows,
             ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
+            external_proposals=c.external_proposals,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
             acceptance_method=c.spec_decoding_acceptance_method,
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
@@ -384,7 +511,15 @@ class SpecDecodeWorker:
         self._wire()
 
     def _wire(self) -> None:
-        if getattr(self.engine, "ngram", False):
+        if self._foreign_proposer is not None:
+            if not getattr(self.engine, "external", False):
+                raise ValueError("a proposer object needs external_proposals (and no draft model)")
+            self.proposer_worker = None
+            self.proposer = self._foreign_proposer
+        elif getattr(self.engine, "external", False):
+            self.proposer_worker = None
+            self.proposer = ExternalProposer(self.engine)
+        elif getattr(self.engine, "ngram", False):
             self.proposer_worker = None
             self.proposer = NGramProposer(self.engine)
         else:
@@ -403,45 +538,91 @@ class SpecDecodeWorker:
             raise ValueError("the cache was sized at load time; cannot grow it")
 
     # -- one step -----------------------------------------------------------------
-    def execute_model(self, execute_model_req: ExecuteModelRequest) -> ModelRunnerOutput:
-        """Runs one step: running sequences get a speculative step (1..k+1 tokens
-        each), new prompts are prefilled in both models and get their first token."""
+    def execute_model(self, scheduler_output, delay_capture: bool = False) -> ModelRunnerOutput:
+        """Runs one step: running sequences get a speculative step (1..k+1 tokens each), new
+        prompts are prefilled in both models and get their first token.
+
+        scheduler_output: a V1 SchedulerOutput as the reference's workers receive it
+        (/root/reference/src/qwen_image_gen/worker.py:47-51; fields at
+        /root/reference/src/doc/engine_core.md:280-313, read by request_from_scheduler_output),
+        or the V0-shaped ExecuteModelRequest of this module.  delay_capture is accepted for
+        signature compatibility: step graphs are captured on first use of a batch shape anyway.
+
+        Every request of the step is checked before anything runs: a refused step leaves the
+        running sequences where they were (no token is produced and then dropped)."""
+        req = scheduler_output
+        if not isinstance(req, ExecuteModelRequest):
+            if _get(req, "scheduled_new_reqs", None) is None and _get(req, "scheduled_cached_reqs", None) is None:
+                raise TypeError("execute_model takes a SchedulerOutput (scheduled_new_reqs / "
+                                "scheduled_cached_reqs / finished_req_ids) or an ExecuteModelRequest")
+            req = request_from_scheduler_output(req)
         eng = self.engine
-        for rid in execute_model_req.finished_requests_ids:
-            self._finish(rid)
-        running = [g for g in execute_model_req.seq_group_metadata_list if not g.is_prompt]
-        prompts = [g for g in execute_model_req.seq_group_metadata_list if g.is_prompt]
+        metas = req.seq_group_metadata_list
+        running = [g for g in metas if not g.is_prompt]
+        prompts = [g for g in metas if g.is_prompt]
+        finished = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._slot_of]
+
+        # ---- validation (nothing has run yet)
         have = getattr(getattr(eng, "cfg", None), "temperature", None)
-        for g in prompts:   # checked before anything runs
-            want = g.sampling_params.temperature
-            if want is not None and have is not None and float(want) != float(have):
-                raise ValueError(f"request {g.request_id} asks for temperature {want}; this worker "
-                                 f"runs every sequence at {have}")
+        max_len = getattr(getattr(eng, "cfg", None), "max_seq_len", None)
+        seen = set()
+        for g in metas:
+            if g.request_id in seen:
+                raise KeyError(f"request {g.request_id} is listed twice")
+            seen.add(g.request_id)
+        for g in prompts:
+            sp = g.sampling_params
+            if sp.temperature is not None and have is not None and float(sp.temperature) != float(have):
+                raise ValueError(f"request {g.request_id} asks for temperature {sp.temperature}; this "
+                                 f"worker runs every sequence at {have}")
+            if sp.seed is not None:
+                raise ValueError(f"request {g.request_id} asks for a per-request seed; this worker "
+                                 "draws from one stream per worker (SpecDecodeConfig.seed)")
+            if g.request_id in self._slot_of and g.request_id not in finished:
+                raise KeyError(f"request {g.request_id} is already running")
+            n = len(g.prompt_token_ids)
+            if n < 1 or (max_len is not None and n + 1 > max_len):
+                raise ValueError(f"request {g.request_id}: prompt of {n} tokens outside 1..{max_len}")
         unknown = [g.request_id for g in running if g.request_id not in self._slot_of]
         if unknown:
             raise KeyError(f"requests {unknown} are not running on this worker")
-        if len(running) != eng.active:
-            raise ValueError(f"{eng.active} sequences are running but the step names {len(running)}: "
+        gone = [g.request_id for g in running if g.request_id in finished]
+        if gone:
+            raise ValueError(f"requests {gone} are listed as running and as finished")
+        n_after = eng.active - len(finished)
+        if len(running) != n_after:
+            raise ValueError(f"{n_after} sequences are running but the step names {len(running)}: "
                              "list every running request or finish it")
+        if n_after + len(prompts) > eng.cfg.max_batch:
+            raise RuntimeError("no free sequence slot (max_num_seqs reached)")
+        ext = req.external_proposals
+        if ext is not None and not getattr(eng, "external", False):
+            raise ValueError("the step carries proposals (external_proposals / "
+                             "scheduled_spec_decode_tokens) but this worker makes its own")
+        # multimodal inputs (vision tower included) are prepared before the step as well
+        mm_inputs = {g.request_id: self._multimodal_inputs(g) for g in prompts}
+
+        # ---- the step
+        for rid in finished:
+            self._finish(rid)
         out: Dict[str, List[int]] = {}
         if running:
-            emitted = self._run_speculative_decoding_step(execute_model_req)
+            if ext is not None:
+                eng.set_external_proposals([ext.get(r, []) for r in self._req_at])
+            emitted = self._run_speculative_decoding_step(req)
             for slot, toks in enumerate(emitted):
                 out[self._req_at[slot]] = toks
         for g in prompts:
-            if g.request_id in self._slot_of:
-                raise KeyError(f"request {g.request_id} is already running")
-            if eng.active >= eng.cfg.max_batch:
-                raise RuntimeError("no free sequence slot (max_num_seqs reached)")
             slot = eng.active
-            first = eng.add_request(slot, g.prompt_token_ids, **self._multimodal_inputs(g))
+            first = eng.add_request(slot, g.prompt_token_ids, **mm_inputs[g.request_id])
             self._slot_of[g.request_id] = slot
             self._req_at.append(g.request_id)
             out[g.request_id] = [first]
-        ids = [g.request_id for g in execute_model_req.seq_group_metadata_list]
+        ids = [g.request_id for g in metas]
         return ModelRunnerOutput(
             req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
             sampled_token_ids=[out[r] for r in ids],
+            prompt_logprobs_dict={r: None for r in ids}, pooler_output=[None] * len(ids),
             spec_decode_metrics=self.metrics.maybe_collect() if self.metrics else None)
 
     def _multimodal_inputs(self, g: SequenceGroupMetadata):
@@ -466,7 +647,7 @@ class SpecDecodeWorker:
     def _run_speculative_decoding_step(self, req: ExecuteModelRequest) -> List[List[int]]:
         """propose -> score -> verify, as one replayed graph when enabled."""
         eng = self.engine
-        if eng.cfg.use_graph or eng._spec_disabled():
+        if self._foreign_proposer is None and (eng.cfg.use_graph or eng._spec_disabled()):
             return eng.step()
         eng.prepare_step()
         proposals = self.proposer.get_spec_proposals(req, frozenset())
