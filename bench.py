@@ -387,14 +387,18 @@ def main():
         eng = SpecEngine(tw, draft or dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
                                               draft_split_tokens=args.draft_split_tokens,
                                               use_graph=not args.no_graph, gen_capacity=n_truth + 64))
-        eng.set_synthetic_acceptance(truth_dev, alpha, seed=99 + rank)
+        # A fixed cyclic schedule decides how many proposals each step accepts (the timed
+        # region covers whole cycles, so its accept-len is the schedule's mean, run after run);
+        # the warm-up steps shift the cycle's start.
+        eng.set_synthetic_acceptance(truth_dev, alpha, seed=-warmup, pattern_len=min(steps, 64))
         toks, n_timed, dt, prefill = run_generation(eng, prompt, steps, warmup, barrier, overlapped)
         n_cmp = min(len(toks), len(ar_tokens))
         exact = toks[:n_cmp] == ar_tokens[:n_cmp]
         m = eng.metrics()
         res = {"tokens": n_timed, "seconds": dt, "prefill_s": prefill, "exact": exact,
-               "accept_len": m["accepted"] / max(m["draft"] // k, 1),
-               "emitted_per_step": m["emitted"] / max(m["draft"] // k, 1),
+               "pattern": list(eng.accept_pattern),
+               "accept_len": n_timed / steps - 1.0,          # timed steps only
+               "emitted_per_step": n_timed / steps,
                "draft_acceptance_rate": m["accepted"] / max(m["draft"], 1),
                "system_efficiency": m["emitted"] / max((m["draft"] // k) * (k + 1), 1)}
         return eng, res
@@ -472,8 +476,10 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": "fp8 weights (e4m3, per-row scales), bf16 activations, f32 accumulation" if fp8 else "bf16",
-        "data": f"synthetic ({data_kind}; random-token prompt; draft proposals replaced by the "
-                f"target's own greedy token with probability {args.accept_prob})",
+        "data": f"synthetic ({data_kind}; random-token prompt; acceptance imposed by a fixed cyclic "
+                f"schedule with the per-step accepted counts independent acceptances of probability "
+                f"{args.accept_prob} would give: real Llama-3-8B/1B acceptance is unknown here, no "
+                f"weights on the box)",
         "config": {"workload": f"{args.target} target + {args.draft} draft, k={k}, batch 1 per GPU, "
                                f"prompt {args.prompt_len}, TP=1 (BASELINE.json configs[1])",
                    "accept_prob": args.accept_prob, "parallelism": f"dp{world} (independent replicas)",
@@ -483,6 +489,12 @@ def main():
                                                   if ovl else " (after every step)")},
         "other_read_back_mode": other_mode,
         "bf16_target_fp8_draft": fp8_draft,
+        "accept_schedule": {"accepted_per_step": main_res["pattern"],
+                            "mean": round(sum(main_res["pattern"]) / len(main_res["pattern"]), 4),
+                            "expected_at_accept_prob": round(sum(args.accept_prob ** i for i in range(1, k + 1)), 4),
+                            "note": "deterministic (sd_debug_force_proposals): ms_per_step and "
+                                    "accept_len below belong together; value = (accept_len + 1) / "
+                                    "ms_per_step"},
         "accept_len": round(main_res["accept_len"], 3),
         "emitted_per_step": round(main_res["emitted_per_step"], 3),
         "draft_acceptance_rate": round(main_res["draft_acceptance_rate"], 4),

@@ -534,14 +534,9 @@ int sd_tp_allgather(const void* send, void* recv, size_t bytes_per_rank, void* c
  *   tok_buf  [B, k+2] i32 = {t[n-2], t[n-1], d_1 .. d_k}
  * ---------------------------------------------------------------------- */
 
-/* Writes proposal ids (i64 -> i32) into tok_buf[:, 2 + step]; optionally
- * overrides each with `truth[b, n + step]` with probability accept_prob
- * (counter-based hash of seed, b, position) — a synthetic-acceptance control
- * for benchmarking with random weights; truth == NULL disables it.         */
-int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, int step,
-                      const int32_t* seq_lens, const int32_t* truth,
-                      int64_t truth_stride, float accept_prob, uint32_t seed,
-                      int B, sd_stream_t stream);
+/* Writes proposal ids (i64 -> i32) into tok_buf[:, 2 + step].                */
+int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, int step, int B,
+                      sd_stream_t stream);
 
 /* Writes externally made proposals [B, k] i32 (an n-gram / prompt-lookup
  * proposer, which needs no draft model) into tok_buf[:, 2:2+k]; entries past a
@@ -596,10 +591,7 @@ int sd_argmax_from_partials(const float* part_val, const int32_t* part_idx,
 
 int sd_propose_from_partials(const float* part_val, const int32_t* part_idx,
                              int row_offset, int row_step, int32_t* tok_buf,
-                             int k, int step, const int32_t* seq_lens,
-                             const int32_t* truth, int64_t truth_stride,
-                             float accept_prob, uint32_t seed, int B,
-                             sd_stream_t stream);
+                             int k, int step, int B, sd_stream_t stream);
 int sd_verify_from_partials(const float* part_val, const int32_t* part_idx,
                             int32_t* tok_buf, const int32_t* proposal_lens,
                             int64_t* out_ids, int64_t* counters,
@@ -607,6 +599,22 @@ int sd_verify_from_partials(const float* part_val, const int32_t* part_idx,
                             int64_t gen_stride, int gen_capacity,
                             int32_t* gen_counts, int32_t* step_out, int B,
                             int k, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Benchmark instrumentation (not part of the product path; no counterpart upstream).
+ * With randomly initialised weights a draft model never agrees with its target, so a
+ * benchmark imposes the acceptance: after the draft's k passes this overwrites the proposals
+ * in tok_buf[:, 2:2+k] so that exactly pattern[step_counter[b] % pattern_len] of them are
+ * accepted (the first a become truth[b, seq_lens[b] + i], proposal a a token that is not the
+ * true one), then step_counter[b] += 1.  truth [B, truth_stride] i32 holds the target's own
+ * greedy stream by absolute position; pattern is a HOST array of pattern_len <=
+ * SD_DEBUG_PATTERN_MAX entries; step_counter [B] i32 (device) makes replays of a captured
+ * step walk through the pattern.  Deterministic: a run's accept-len is the pattern's mean. */
+#define SD_DEBUG_PATTERN_MAX 64
+int sd_debug_force_proposals(int32_t* tok_buf, int k, const int32_t* seq_lens,
+                             const int32_t* truth, int64_t truth_stride,
+                             const uint8_t* pattern, int pattern_len,
+                             int32_t* step_counter, int vocab, int B, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Stream capture helpers (one spec step = one hipGraph launch).

@@ -123,3 +123,57 @@ def test_scheduler_generates_what_each_request_gets_alone():
     # a second wave reuses the freed slots and pages
     again = sched.generate(prompts[:4], max_tokens=6)
     assert [r.output_token_ids for r in again] == [wnt[:6] for wnt in want[:4]]
+
+
+@pytest.mark.parametrize("rows", ["narrow", "wide"])
+def test_scheduled_streams_match_the_oracle_golden(rows):
+    """The caller side of the hot path against the ORACLE, not against another run of the
+    same kernels: the golden prompts (tests/golden/e2e_tiny.json, written by the CPU oracle)
+    go through SpecDecodeScheduler with 3 slots and staggered arrival (requests wait, join
+    running batches, leave, slots are reused); every stream must equal the oracle's tokens up
+    to the oracle's first near-tie."""
+    import json
+    import os
+    from oracle.models import OracleLM
+    from tests.test_gpu_model import _bf, _product
+    from vllm_omni_draft_amd.scheduler import Request, SpecDecodeScheduler
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
+    with open(os.path.join(os.path.dirname(__file__), "golden", "e2e_tiny.json")) as f:
+        g = json.load(f)
+    tcfg, dcfg = OracleConfig(**g["target"]), OracleConfig(**g["draft"])
+    ts, ds = _bf(random_state(tcfg, g["target_seed"])), _bf(random_state(dcfg, g["draft_seed"]))
+    w = SpecDecodeWorker(SpecDecodeConfig(target=_product(tcfg, ts), draft=_product(dcfg, ds),
+                                          num_speculative_tokens=g["k"], max_num_seqs=3,
+                                          max_model_len=128, split_tokens=128, rows=rows))
+    w.init_device()
+    w.load_model()
+    sched = SpecDecodeScheduler.for_worker(w)
+    reqs = [Request(f"g{i}", list(c["prompt"]), max_tokens=len(c["tokens"]))
+            for i, c in enumerate(g["cases"])]
+    arrivals = {0: [0, 1], 1: [2, 3], 3: [4], 6: [5, 6, 7]}       # step -> requests that arrive
+    step = 0
+    while sched.has_unfinished() or step <= max(arrivals):
+        for i in arrivals.get(step, []):
+            sched.add_request(reqs[i])
+        sched.step()
+        step += 1
+        assert step < 400
+    sched.drain()
+    assert w.engine.active == 0
+    lm = OracleLM(tcfg, ts, bf16_acts=True)
+    n_tokens = n_match = 0
+    for r, case in zip(reqs, g["cases"]):
+        assert r.finish_reason == "length" and len(r.output_token_ids) == len(case["tokens"])
+        seq, cache = list(case["prompt"]), lm.new_cache()
+        logits = lm.forward(seq, 0, cache)[-1]
+        for i, want in enumerate(case["tokens"]):
+            if r.output_token_ids[i] != want:      # only legitimate at a near-tie of the oracle
+                top2 = torch.topk(logits, 2).values
+                margin = (top2[0] - top2[1]).item() / logits.abs().max().item()
+                assert margin < 0.03, (r.request_id, i, r.output_token_ids[i], want, margin)
+                break
+            n_match += 1
+            logits = lm.forward([want], len(seq), cache)[-1]
+            seq.append(want)
+        n_tokens += len(case["tokens"])
+    assert n_match >= 0.6 * n_tokens, (n_match, n_tokens)

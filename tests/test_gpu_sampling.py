@@ -257,7 +257,7 @@ def test_argmax_partials_ties_and_strided_rows(V):
     ref = sampling.argmax_rows(x.cpu().numpy())
     # draft side: rows 1, 3, 5 (the q_len = 2 first pass reads every other row)
     tok_buf = torch.zeros(3, 7, dtype=torch.int32, device="cuda")
-    ops.propose_from_partials(pv, pi, 1, 2, tok_buf, 5, 4, None)
+    ops.propose_from_partials(pv, pi, 1, 2, tok_buf, 5, 4)
     assert tok_buf[:, 6].tolist() == [int(ref[1]), int(ref[3]), int(ref[5])]
     assert tok_buf[:, :6].abs().sum().item() == 0
     # k = 0 verification is plain decoding: every row emits its argmax
@@ -272,24 +272,49 @@ def test_argmax_partials_ties_and_strided_rows(V):
     assert tb[:, 1].tolist() == [int(v) for v in ref]
 
 
-def test_store_proposal_forcing_is_the_same_in_both_paths():
+def test_store_proposal_is_the_same_in_both_paths():
     ops = _ops()
     B, k, V = 8, 5, 4096
     gen = torch.Generator(device="cuda").manual_seed(5)
     x = torch.randn(B, V, generator=gen, device="cuda")
-    truth = torch.randint(0, V, (B, 64), generator=gen, device="cuda").to(torch.int32)
-    seq_lens = torch.arange(10, 10 + B, dtype=torch.int32, device="cuda")
     pv, pi = _partials(ops, x)
-    forced = 0
-    rows = torch.arange(B, device="cuda")
     for step in range(k):
         a = torch.zeros(B, k + 2, dtype=torch.int32, device="cuda")
         b = torch.zeros(B, k + 2, dtype=torch.int32, device="cuda")
-        ops.store_proposal(ops.argmax_rows(x), a, k, step, seq_lens, truth, 0.5, 1234)
-        ops.propose_from_partials(pv, pi, 0, 1, b, k, step, seq_lens, truth, 0.5, 1234)
+        ops.store_proposal(ops.argmax_rows(x), a, k, step)
+        ops.propose_from_partials(pv, pi, 0, 1, b, k, step)
         assert torch.equal(a, b)
-        forced += (a[:, 2 + step] == truth[rows, (seq_lens + step).long()]).sum().item()
-    assert 8 <= forced <= 32     # 40 draws at probability 0.5
+        assert torch.equal(a[:, 2 + step].long(), x.argmax(dim=1))
+
+
+def test_debug_force_proposals_follows_its_schedule():
+    """The benchmark control: proposals 0..a-1 become the true tokens, proposal a a token that
+    is not the true one, later ones are left alone; a walks cyclically through the pattern."""
+    ops = _ops()
+    B, k, V = 4, 5, 1000
+    gen = torch.Generator(device="cuda").manual_seed(6)
+    truth = torch.randint(0, V, (B, 64), generator=gen, device="cuda").to(torch.int32)
+    seq_lens = torch.tensor([10, 11, 12, 13], dtype=torch.int32, device="cuda")
+    ctr = torch.tensor([0, 1, 2, 3], dtype=torch.int32, device="cuda")   # sequences out of phase
+    pattern = [5, 0, 3, 1, 4]
+    for rnd in range(7):
+        tb = torch.full((B, k + 2), -7, dtype=torch.int32, device="cuda")
+        ops.debug_force_proposals(tb, k, seq_lens, truth, pattern, ctr, V)
+        torch.cuda.synchronize()
+        for b in range(B):
+            a = pattern[(b + rnd) % len(pattern)]
+            n = int(seq_lens[b])
+            for i in range(k):
+                want = int(truth[b, n + i])
+                got = int(tb[b, 2 + i])
+                if i < a:
+                    assert got == want
+                elif i == a:
+                    assert got == (want + 1) % V
+                else:
+                    assert got == -7
+        assert tb[:, :2].eq(-7).all()
+    assert ctr.tolist() == [7, 8, 9, 10]
 
 
 def test_fill_uniforms_is_uniform_and_advances():

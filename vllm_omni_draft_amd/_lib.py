@@ -101,7 +101,8 @@ SIGNATURES = {
     "sd_model_workspace_bytes": (C.c_size_t, [vp, i32, i32, i32]),
     "sd_model_forward": (i32, [vp, C.POINTER(KvCacheDesc), C.POINTER(ForwardArgs), vp,
                                C.c_size_t, vp]),
-    "sd_store_proposal": (i32, [vp, vp, i32, i32, vp, vp, i64, C.c_float, C.c_uint32, i32, vp]),
+    "sd_store_proposal": (i32, [vp, vp, i32, i32, i32, vp]),
+    "sd_debug_force_proposals": (i32, [vp, i32, vp, vp, i64, C.c_char_p, i32, vp, i32, i32, vp]),
     "sd_gather_proposals": (i32, [vp, vp, i32, i32, vp]),
     "sd_set_proposals": (i32, [vp, vp, i32, i32, vp]),
     "sd_advance_state": (i32, [vp, vp, vp, vp, i64, i32, vp, vp, i32, i32, vp]),
@@ -121,8 +122,7 @@ SIGNATURES = {
     "sd_rejection_sample_split": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "sd_fill_uniforms": (i32, [vp, i32, C.c_uint64, vp, vp]),
     "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),
-    "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, vp, vp, i64, C.c_float,
-                                       C.c_uint32, i32, vp]),
+    "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, vp]),
     "sd_verify_from_partials": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, i32,
                                       vp]),
     "sd_graph_begin": (i32, [vp]),

@@ -659,32 +659,37 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   return x;
 }
 
-// The proposal of sequence b at draft step `step`, or (synthetic acceptance control) the
-// true token of that position with probability accept_prob.
-__device__ __forceinline__ int32_t forced_proposal(int32_t tok, int b, int step,
-                                                   const int32_t* __restrict__ seq_lens,
-                                                   const int32_t* __restrict__ truth,
-                                                   int64_t truth_stride, float accept_prob,
-                                                   uint32_t seed) {
-  if (truth) {
-    const int pos = seq_lens[b] + step;  // position the proposal would occupy
-    const uint32_t h = mix32(mix32(seed ^ (uint32_t)b * 0x9e3779b9u) + (uint32_t)pos);
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    if (u < accept_prob && pos < truth_stride) tok = truth[(size_t)b * truth_stride + pos];
-  }
-  return tok;
-}
-
 __global__ void store_proposal_kernel(const int64_t* __restrict__ ids,
-                                      int32_t* __restrict__ tok_buf, int k, int step,
-                                      const int32_t* __restrict__ seq_lens,
-                                      const int32_t* __restrict__ truth,
-                                      int64_t truth_stride, float accept_prob,
-                                      uint32_t seed, int B) {
+                                      int32_t* __restrict__ tok_buf, int k, int step, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  tok_buf[(size_t)b * (k + 2) + 2 + step] =
-      forced_proposal((int32_t)ids[b], b, step, seq_lens, truth, truth_stride, accept_prob, seed);
+  tok_buf[(size_t)b * (k + 2) + 2 + step] = (int32_t)ids[b];
+}
+
+// Benchmark control (sd_debug_force_proposals): overwrites the k proposals of sequence b so
+// that exactly a = pattern[step_counter[b] % len] of them will be accepted: proposals 0..a-1
+// become the true tokens of their positions, proposal a (if a < k) a token that is certainly
+// not the true one; later proposals keep what the draft model made.
+struct ForcePattern {
+  uint8_t n_accept[SD_DEBUG_PATTERN_MAX];
+  int len;
+};
+__global__ void force_proposals_kernel(int32_t* __restrict__ tok_buf, int k,
+                                       const int32_t* __restrict__ seq_lens,
+                                       const int32_t* __restrict__ truth, int64_t truth_stride,
+                                       ForcePattern pat, int32_t* __restrict__ step_counter,
+                                       int vocab, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int t = step_counter[b];
+  step_counter[b] = t + 1;
+  const int a = min((int)pat.n_accept[t % pat.len], k);
+  const int n = seq_lens[b];  // position of proposal 0
+  for (int i = 0; i <= a && i < k; ++i) {
+    if (n + i >= truth_stride) break;
+    const int32_t tok = truth[(size_t)b * truth_stride + n + i];
+    tok_buf[(size_t)b * (k + 2) + 2 + i] = i < a ? tok : (tok + 1) % vocab;
+  }
 }
 
 // Applies the emitted tokens o[0..k] (-1 padded) of sequence b to the device state and
@@ -834,14 +839,10 @@ __global__ __launch_bounds__(SD_WAVE) void argmax_from_partials_kernel(
 
 __global__ __launch_bounds__(SD_WAVE) void propose_from_partials_kernel(
     const float* __restrict__ part_val, const int32_t* __restrict__ part_idx, int row_offset,
-    int row_step, int32_t* __restrict__ tok_buf, int k, int step,
-    const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ truth, int64_t truth_stride,
-    float accept_prob, uint32_t seed) {
+    int row_step, int32_t* __restrict__ tok_buf, int k, int step) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int id = wave_argmax_finish(part_val, part_idx, row_offset + b * row_step, lane);
-  if (lane == 0)
-    tok_buf[(size_t)b * (k + 2) + 2 + step] =
-        forced_proposal(id, b, step, seq_lens, truth, truth_stride, accept_prob, seed);
+  if (lane == 0) tok_buf[(size_t)b * (k + 2) + 2 + step] = id;
 }
 
 // Greedy verification straight from the target's argmax partials: wave j finishes row j
@@ -1068,17 +1069,35 @@ extern "C" int sd_fill_uniforms(float* out, int n, uint64_t seed, uint64_t* coun
   return SD_OK;
 }
 
-extern "C" int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, int step,
-                                 const int32_t* seq_lens, const int32_t* truth,
-                                 int64_t truth_stride, float accept_prob, uint32_t seed,
-                                 int B, sd_stream_t stream) {
-  SD_REQUIRE(ids && tok_buf && seq_lens && B >= 0 && k >= 1 && step >= 0 && step < k,
+extern "C" int sd_store_proposal(const int64_t* ids, int32_t* tok_buf, int k, int step, int B,
+                                 sd_stream_t stream) {
+  SD_REQUIRE(ids && tok_buf && B >= 0 && k >= 1 && step >= 0 && step < k,
              SD_ERR_INVALID, "sd_store_proposal: bad arguments (B=%d k=%d step=%d)", B, k, step);
   if (B == 0) return SD_OK;
   hipLaunchKernelGGL(store_proposal_kernel, dim3((B + 63) / 64), dim3(64), 0,
-                     (hipStream_t)stream, ids, tok_buf, k, step, seq_lens, truth,
-                     truth_stride, accept_prob, seed, B);
+                     (hipStream_t)stream, ids, tok_buf, k, step, B);
   SD_CHECK_LAUNCH("sd_store_proposal");
+  return SD_OK;
+}
+
+extern "C" int sd_debug_force_proposals(int32_t* tok_buf, int k, const int32_t* seq_lens,
+                                        const int32_t* truth, int64_t truth_stride,
+                                        const uint8_t* pattern, int pattern_len,
+                                        int32_t* step_counter, int vocab, int B,
+                                        sd_stream_t stream) {
+  SD_REQUIRE(tok_buf && seq_lens && truth && pattern && step_counter && B >= 0 && k >= 1 &&
+                 vocab >= 2 && truth_stride >= 1,
+             SD_ERR_INVALID, "sd_debug_force_proposals: bad arguments (B=%d k=%d)", B, k);
+  SD_REQUIRE(pattern_len >= 1 && pattern_len <= SD_DEBUG_PATTERN_MAX, SD_ERR_INVALID,
+             "sd_debug_force_proposals: pattern length %d outside 1..%d", pattern_len,
+             SD_DEBUG_PATTERN_MAX);
+  if (B == 0) return SD_OK;
+  ForcePattern pat;
+  for (int i = 0; i < SD_DEBUG_PATTERN_MAX; ++i) pat.n_accept[i] = i < pattern_len ? pattern[i] : 0;
+  pat.len = pattern_len;
+  hipLaunchKernelGGL(force_proposals_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                     tok_buf, k, seq_lens, truth, truth_stride, pat, step_counter, vocab, B);
+  SD_CHECK_LAUNCH("sd_debug_force_proposals");
   return SD_OK;
 }
 
@@ -1161,17 +1180,13 @@ extern "C" int sd_argmax_from_partials(const float* part_val, const int32_t* par
 
 extern "C" int sd_propose_from_partials(const float* part_val, const int32_t* part_idx,
                                         int row_offset, int row_step, int32_t* tok_buf, int k,
-                                        int step, const int32_t* seq_lens, const int32_t* truth,
-                                        int64_t truth_stride, float accept_prob, uint32_t seed,
-                                        int B, sd_stream_t stream) {
+                                        int step, int B, sd_stream_t stream) {
   SD_REQUIRE(part_val && part_idx && tok_buf && B >= 0 && k >= 1 && step >= 0 && step < k &&
                  row_offset >= 0 && row_step >= 1, SD_ERR_INVALID,
              "sd_propose_from_partials: bad arguments (B=%d k=%d step=%d)", B, k, step);
-  SD_REQUIRE(!truth || seq_lens, SD_ERR_INVALID, "sd_propose_from_partials: truth without seq_lens");
   if (B == 0) return SD_OK;
   hipLaunchKernelGGL(propose_from_partials_kernel, dim3(B), dim3(SD_WAVE), 0, (hipStream_t)stream,
-                     part_val, part_idx, row_offset, row_step, tok_buf, k, step, seq_lens, truth,
-                     truth_stride, accept_prob, seed);
+                     part_val, part_idx, row_offset, row_step, tok_buf, k, step);
   SD_CHECK_LAUNCH("sd_propose_from_partials");
   return SD_OK;
 }

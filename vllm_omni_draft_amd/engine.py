@@ -80,6 +80,25 @@ class EngineConfig:
     posterior_alpha: float = 0.3
 
 
+def acceptance_pattern(accept_prob: float, k: int, length: int = 16, rotate: int = 0) -> List[int]:
+    """A cyclic schedule of accepted proposals per step, `length` entries in 0..k, whose counts
+    follow the distribution independent acceptances of probability accept_prob give
+    (P(a) = p^a (1 - p) for a < k, p^k for a = k; largest-remainder rounding), spread evenly
+    over the cycle.  Deterministic: the mean accept-len of a run over whole cycles is the
+    pattern's mean."""
+    p = min(max(float(accept_prob), 0.0), 1.0)
+    probs = [p ** a * (1.0 - p) for a in range(k)] + [p ** k]
+    want = [q * length for q in probs]
+    counts = [int(w) for w in want]
+    for a in sorted(range(k + 1), key=lambda a: want[a] - counts[a], reverse=True)[:length - sum(counts)]:
+        counts[a] += 1
+    # spread every value evenly over the cycle: value a sits at fractions (j + 0.5) / count
+    slots = sorted((((j + 0.5) / counts[a], -a), a) for a in range(k + 1) for j in range(counts[a]))
+    pat = [a for _, a in slots]
+    r = rotate % length
+    return pat[r:] + pat[:r]
+
+
 class SpecEngine:
     def __init__(self, target: ModelWeights, draft: Optional[ModelWeights], cfg: EngineConfig,
                  tp_group=None, draft_tp: bool = False):
@@ -230,8 +249,8 @@ class SpecEngine:
             self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * (k + 1)), dev)
         # synthetic acceptance control (benchmarks with random weights)
         self.truth: Optional[torch.Tensor] = None
-        self.accept_prob = 0.0
-        self.accept_seed = 0
+        self.accept_pattern: List[int] = []
+        self.force_ctr = torch.zeros(B, dtype=torch.int32, device=dev)
         self.active = 0                       # sequences currently in the batch
         self.host_lens: List[int] = [0] * B   # upper bound of seq_lens known to the host
         self.host_gen: List[int] = [0] * B
@@ -261,16 +280,28 @@ class SpecEngine:
         self.counters.zero_()
         self.active = 0
 
-    def set_synthetic_acceptance(self, truth: Optional[torch.Tensor], accept_prob: float,
-                                 seed: int = 0) -> None:
-        """truth [B, L] int32: token at every absolute position of the stream the
-        target would emit; each proposal is replaced by the true token with
-        probability accept_prob.  None switches the control off."""
+    def set_synthetic_acceptance(self, truth: Optional[torch.Tensor], accept_prob: float = 0.0,
+                                 seed: int = 0, pattern: Optional[Sequence[int]] = None,
+                                 pattern_len: int = 16) -> None:
+        """Benchmark control for runs with random weights (sd_debug_force_proposals; not part
+        of the product path).  truth [B, L] int32: the token at every absolute position of the
+        stream the target would emit.  After the draft's passes the proposals are overwritten
+        so that a fixed, cyclic schedule decides how many are accepted in each step: `pattern`
+        (accepted proposals per step), or the schedule acceptance_pattern(accept_prob, k,
+        pattern_len) whose counts follow what independent acceptances of probability
+        accept_prob would give (seed rotates its start).  None switches the control off."""
         if truth is not None and (truth.dtype != torch.int32 or truth.dim() != 2):
             raise ValueError("truth must be an int32 [B, L] tensor")
+        if truth is not None and self.draft is None:
+            raise ValueError("synthetic acceptance overrides a draft model's proposals")
         self.truth = truth
-        self.accept_prob = float(accept_prob)
-        self.accept_seed = int(seed)
+        if truth is not None:
+            pat = list(pattern) if pattern is not None else acceptance_pattern(
+                accept_prob, self.k, pattern_len, rotate=seed)
+            if not 1 <= len(pat) <= ops.DEBUG_PATTERN_MAX or any(not 0 <= a <= self.k for a in pat):
+                raise ValueError("pattern: 1..64 entries in 0..k")
+            self.accept_pattern = pat
+        self.force_ctr.zero_()
         self._drop_graphs()
 
     def add_request(self, slot: int, prompt: Sequence[int],
@@ -511,8 +542,7 @@ class SpecEngine:
             if fused:
                 self._partials(self.d_out, B * step, self.d_vp)
                 ops.propose_from_partials(self.part_val, self.part_idx, off, step,
-                                          self.tok_buf[:B], k, i, self.seq_lens[:B], self.truth,
-                                          self.accept_prob, self.accept_seed)
+                                          self.tok_buf[:B], k, i)
                 continue
             if self.sampling:
                 ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
@@ -522,8 +552,10 @@ class SpecEngine:
                                 out=self.ids_tmp, row_offset=i, row_step=k, scratch=self.samp_scratch)
             else:
                 ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
-            ops.store_proposal(self.ids_tmp[:B], self.tok_buf[:B], k, i, self.seq_lens[:B],
-                               self.truth, self.accept_prob, self.accept_seed)
+            ops.store_proposal(self.ids_tmp[:B], self.tok_buf[:B], k, i)
+        if self.truth is not None:    # benchmark control: impose the acceptance schedule
+            ops.debug_force_proposals(self.tok_buf[:B], k, self.seq_lens[:B], self.truth,
+                                      self.accept_pattern, self.force_ctr[:B], self.V)
         if not fused:
             ops.gather_proposals(self.tok_buf[:B], self.draft_ids[:B], k)
 
@@ -612,7 +644,8 @@ class SpecEngine:
                 if slot != last:
                     kv.move_slot(last, slot)
             if slot != last:
-                moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta]
+                moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta,
+                         self.force_ctr]
                 if self.truth is not None:
                     moved.append(self.truth)
                 for t in moved:

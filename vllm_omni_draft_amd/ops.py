@@ -461,12 +461,25 @@ def fill_uniforms(out: torch.Tensor, seed: int, counter: torch.Tensor) -> None:
 
 
 # ---------------------------------------------------------------- step glue
-def store_proposal(ids, tok_buf, k, step, seq_lens, truth=None, accept_prob=0.0, seed=0) -> None:
+def store_proposal(ids, tok_buf, k, step) -> None:
     B = tok_buf.shape[0]
-    _lib.check(_lib.load().sd_store_proposal(
-        _p(ids), _p(tok_buf), k, step, _p(seq_lens), _p(truth),
-        0 if truth is None else truth.shape[1], float(accept_prob), int(seed) & 0xFFFFFFFF, B,
-        _stream()), "sd_store_proposal")
+    _lib.check(_lib.load().sd_store_proposal(_p(ids), _p(tok_buf), k, step, B, _stream()),
+               "sd_store_proposal")
+
+
+DEBUG_PATTERN_MAX = 64
+
+
+def debug_force_proposals(tok_buf, k, seq_lens, truth, pattern, step_counter, vocab) -> None:
+    """Benchmark control: overwrite the proposals in tok_buf so that pattern[step_counter[b] %
+    len(pattern)] of them are accepted (see sd_debug_force_proposals)."""
+    _need(truth, torch.int32, "truth")
+    _need(step_counter, torch.int32, "step_counter")
+    B = tok_buf.shape[0]
+    pat = bytes(int(a) for a in pattern)
+    _lib.check(_lib.load().sd_debug_force_proposals(
+        _p(tok_buf), k, _p(seq_lens), _p(truth), truth.shape[1], pat, len(pat), _p(step_counter),
+        int(vocab), B, _stream()), "sd_debug_force_proposals")
 
 
 def set_proposals(proposals, tok_buf, k) -> None:
@@ -533,13 +546,11 @@ def argmax_from_partials(part_val, part_idx, R: int, out=None) -> torch.Tensor:
     return out
 
 
-def propose_from_partials(part_val, part_idx, row_offset, row_step, tok_buf, k, step, seq_lens,
-                          truth=None, accept_prob=0.0, seed=0) -> None:
+def propose_from_partials(part_val, part_idx, row_offset, row_step, tok_buf, k, step) -> None:
     B = tok_buf.shape[0]
     _lib.check(_lib.load().sd_propose_from_partials(
-        _p(part_val), _p(part_idx), row_offset, row_step, _p(tok_buf), k, step, _p(seq_lens),
-        _p(truth), 0 if truth is None else truth.shape[1], float(accept_prob),
-        int(seed) & 0xFFFFFFFF, B, _stream()), "sd_propose_from_partials")
+        _p(part_val), _p(part_idx), row_offset, row_step, _p(tok_buf), k, step, B, _stream()),
+        "sd_propose_from_partials")
 
 
 def verify_from_partials(part_val, part_idx, tok_buf, out_ids, counters, seq_lens, gen_tokens,
