@@ -11,7 +11,15 @@ EXTRA ?=
 # depths, ...) must give a row the same bits.
 FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function $(EXTRA)
 
-all: $(LIB)
+# The CPU build of the same C ABI (C++ / OpenMP): its own library, loaded only when the host
+# code is told to (SD_AMD_BACKEND=cpu); the GPU library never falls back to it.
+CPU_LIB := vllm_omni_draft_amd/libsd_cpu.so
+CXX ?= g++
+
+all: $(LIB) $(CPU_LIB)
+
+$(CPU_LIB): vllm_omni_draft_amd/csrc_cpu/sd_cpu.cpp include/sd_amd.h
+	$(CXX) -O3 -std=c++17 -fPIC -shared -fopenmp -mavx2 -mfma -Wall -o $@ $<
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@
@@ -32,7 +40,7 @@ $(STAMP_LIB): $(STAMP_OBJS)
 stamps: $(STAMP_LIB)
 
 clean:
-	rm -f $(OBJS) $(LIB)
+	rm -f $(OBJS) $(LIB) $(CPU_LIB)
 	rm -rf $(STAMP_DIR)
 
 .PHONY: all clean stamps

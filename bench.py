@@ -81,6 +81,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--layers", type=int, default=0, help="debug only: truncate both models")
+    ap.add_argument("--cpu-baseline-worker", action="store_true",
+                    help="internal: the child process of the cpu_baseline leg (SD_AMD_BACKEND=cpu)")
+    ap.add_argument("--cpu-budget", type=float, default=25.0)
     return ap.parse_args()
 
 
@@ -258,79 +261,69 @@ def _check_attention(run, kc, vc, bt, q, seqs, ctx, q_len, Hq, Hkv, D):
     return True
 
 
-def cpu_baseline(args, tokens_per_step, budget_s=30.0):
-    """The CPU oracle (oracle/, torch CPU kernels) on the same model shapes:
-    k draft passes + one (k+1)-row verify pass per step, bf16 weights, random
-    KV of the prompt length.  Bounded: at most 2 steps or ~budget_s."""
-    from oracle.models import KVCache, OracleConfig, OracleLM
-    from vllm_omni_draft_amd import config as pc
-    torch.manual_seed(0)
-    pool = (torch.randn(1 << 24) * 0.02).to(torch.bfloat16)
+def cpu_baseline(budget_s=25.0):
+    """The CPU leg: this repository's own CPU build of the C ABI (libsd_cpu.so, C++/OpenMP)
+    driven by the same SpecDecodeWorker, on BASELINE.json configs[0] shapes (OPT-125m target and
+    draft, k = 3, greedy, batch 8, seeded random weights), in a child process (the backend is a
+    per-process choice) on this box's host cores.  The reference has no CPU speculative-decoding
+    path of its own to time (its dependency's CPU backend is not installed).  Bounded: about
+    budget_s seconds of steps."""
+    import subprocess
+    env = dict(os.environ, SD_AMD_BACKEND="cpu")
+    env.pop("SD_AMD_LIB", None)
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    env["OMP_NUM_THREADS"] = str(cores)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+                        "--cpu-budget", str(budget_s)], env=env, capture_output=True, text=True,
+                       timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError(f"cpu baseline worker failed: {r.stderr[-500:]}")
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["cores"] = cores
+    return out
 
-    def cheap(shape):
-        n = 1
-        for s in shape:
-            n *= s
-        reps = (n + pool.numel() - 1) // pool.numel()
-        return pool.repeat(reps)[:n].view(*shape)
 
-    def build(name):
-        c = pc.preset(name, **({"n_layers": args.layers} if args.layers else {}))
-        oc = OracleConfig(arch=c.arch, n_layers=c.n_layers, hidden=c.hidden, n_heads=c.n_heads,
-                          n_kv_heads=c.n_kv_heads, head_dim=c.head_dim, ffn=c.ffn, vocab=c.vocab,
-                          norm_eps=c.norm_eps, rope_theta=c.rope_theta, rope_scaling=c.rope_scaling,
-                          max_pos=args.prompt_len + 64, tie_embeddings=c.tie_embeddings)
-        H, D, Hq, Hkv, F = oc.hidden, oc.head_dim, oc.n_heads, oc.n_kv_heads, oc.ffn
-        st = {"model.embed_tokens.weight": cheap((oc.vocab, H)), "model.norm.weight": cheap((H,))}
-        if not oc.tie_embeddings:
-            st["lm_head.weight"] = cheap((oc.vocab, H))
-        for i in range(oc.n_layers):
-            lp = f"model.layers.{i}."
-            st[lp + "input_layernorm.weight"] = cheap((H,))
-            st[lp + "post_attention_layernorm.weight"] = cheap((H,))
-            st[lp + "self_attn.q_proj.weight"] = cheap((Hq * D, H))
-            st[lp + "self_attn.k_proj.weight"] = cheap((Hkv * D, H))
-            st[lp + "self_attn.v_proj.weight"] = cheap((Hkv * D, H))
-            st[lp + "self_attn.o_proj.weight"] = cheap((H, Hq * D))
-            st[lp + "mlp.gate_proj.weight"] = cheap((F, H))
-            st[lp + "mlp.up_proj.weight"] = cheap((F, H))
-            st[lp + "mlp.down_proj.weight"] = cheap((H, F))
-        lm = OracleLM(oc, st, bf16_acts=False, compute_dtype=torch.bfloat16)
-        cache = KVCache(oc.n_layers)
-        for i in range(oc.n_layers):
-            cache.k[i] = torch.randn(args.prompt_len, Hkv, D) * 0.5
-            cache.v[i] = torch.randn(args.prompt_len, Hkv, D) * 0.5
-        return lm, cache
-
-    k, n = args.k, args.prompt_len
-    target, t_cache = build(args.target)
-    draft, d_cache = build(args.draft)
-    steps, t_total = 0, 0.0
-    with torch.no_grad():
-        while steps < 2 and t_total < budget_s:
-            t0 = time.perf_counter()
-            toks = [1, 2]
-            pos = n - 1
-            for i in range(k):
-                lg = draft.forward(toks, pos, d_cache)[-1]
-                pos += len(toks)
-                toks = [int(torch.argmax(lg))]
-            lg = target.forward([1] + [2] * k, n, t_cache)
-            _ = torch.argmax(lg, dim=-1)
-            t_cache.truncate(n)
-            d_cache.truncate(n - 1)
-            t_total += time.perf_counter() - t0
-            steps += 1
-    step_s = t_total / steps
-    return {"value": round(tokens_per_step / step_s, 3), "unit": "tokens/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} speculative step(s) of the same shapes ({args.target} + {args.draft}, "
-                      f"k={k}, batch 1, ctx {n}, bf16 weights) on the torch-CPU oracle, "
-                      f"{step_s:.2f} s/step; tokens/step ({tokens_per_step:.2f}) taken from the GPU run"}
+def cpu_baseline_worker(budget_s):
+    """Runs inside the child process (SD_AMD_BACKEND=cpu); prints one JSON line."""
+    from vllm_omni_draft_amd import _lib, config, weights
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeConfig, SpecDecodeWorker)
+    assert _lib.backend() == "cpu"
+    cfg = config.preset("opt-125m", max_pos=512)
+    w = weights.random_init(cfg, seed=125, device="cpu")
+    k, B, n_prompt = 3, 8, 128
+    worker = SpecDecodeWorker(SpecDecodeConfig(target=w, draft=w, num_speculative_tokens=k,
+                                               max_num_seqs=B, max_model_len=400, rows="narrow"))
+    worker.init_device()
+    worker.load_model()
+    g = torch.Generator().manual_seed(1234)
+    prompts = {f"r{i}": torch.randint(0, cfg.vocab, (n_prompt,), generator=g).tolist() for i in range(B)}
+    t0 = time.perf_counter()
+    worker.execute_model(ExecuteModelRequest([SequenceGroupMetadata(r, True, p) for r, p in prompts.items()]))
+    prefill_s = time.perf_counter() - t0
+    running = ExecuteModelRequest([SequenceGroupMetadata(r, False) for r in prompts])
+    worker.execute_model(running)            # warm-up step
+    steps = tokens = 0
+    t0 = time.perf_counter()
+    while steps < 3 or (time.perf_counter() - t0 < budget_s and steps < 60):
+        out = worker.execute_model(running)
+        tokens += sum(len(t) for t in out.sampled_token_ids)
+        steps += 1
+    dt = time.perf_counter() - t0
+    print(json.dumps({
+        "value": round(tokens / dt, 2), "unit": "tokens/s", "cores": None,
+        "kind": "port (own C-ABI CPU backend: libsd_cpu.so, C++/OpenMP, behind the same SpecDecodeWorker)",
+        "sample": f"{steps} speculative steps of BASELINE.json configs[0] shapes (opt-125m target + "
+                  f"opt-125m draft with the same seeded random weights, k={k}, greedy, batch {B}, "
+                  f"prompt {n_prompt}): {dt / steps:.3f} s/step, {tokens / steps / B:.2f} tokens per step "
+                  f"and sequence (every proposal accepted: draft == target), prefill {prefill_s:.1f} s"}))
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args.cpu_budget)
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -465,9 +458,9 @@ def main():
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
         try:
-            cpu = cpu_baseline(args, main_res["emitted_per_step"])
+            cpu = cpu_baseline()
         except Exception as e:  # the baseline is a report item, never the product path
-            cpu = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(),
+            cpu = {"value": None, "unit": "tokens/s", "cores": None,
                    "kind": "port", "sample": f"failed: {type(e).__name__}: {e}"}
 
     line = {

@@ -1,0 +1,141 @@
+"""Cases for the CPU build of the C ABI (libsd_cpu.so).  Run in a process of their own with
+SD_AMD_BACKEND=cpu (tests/test_cpu_backend.py starts it): the backend is a per-process choice.
+The checker is the CPU oracle, as for the GPU library."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sampling
+from oracle.models import OracleConfig, OracleLM, random_state
+from oracle.spec_decode import ar_generate
+
+
+def _bf(state):
+    return {k: v.to(torch.bfloat16).float() for k, v in state.items()}
+
+
+def _product(oc, state):
+    from vllm_omni_draft_amd import config, weights
+    cfg = config.create_model_config(
+        None, arch=oc.arch, n_layers=oc.n_layers, hidden=oc.hidden, n_heads=oc.n_heads,
+        n_kv_heads=oc.n_kv_heads, head_dim=oc.head_dim, ffn=oc.ffn, vocab=oc.vocab,
+        norm_eps=oc.norm_eps, rope_theta=oc.rope_theta, max_pos=oc.max_pos,
+        tie_embeddings=oc.tie_embeddings)
+    return weights.from_state_dict(cfg, state, "cpu")
+
+
+def test_backend_is_the_cpu_library():
+    from vllm_omni_draft_amd import _lib, ops
+    assert _lib.backend() == "cpu" and _lib.lib_path().endswith("libsd_cpu.so")
+    cus, name = ops.device_info()
+    assert name == "cpu" and cus >= 1
+    with pytest.raises(_lib.SdError):          # what the CPU build does not provide says so
+        _lib.check(_lib.load().sd_graph_begin(None), "sd_graph_begin")
+
+
+@pytest.mark.parametrize("arch", ["opt", "llama"])
+def test_forward_logits_match_the_oracle(arch):
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    oc = (OracleConfig(arch="opt", n_layers=2, hidden=192, n_heads=3, n_kv_heads=3, head_dim=64, ffn=384,
+                       vocab=272, max_pos=128, tie_embeddings=True) if arch == "opt" else
+          OracleConfig(arch="llama", n_layers=2, hidden=128, n_heads=4, n_kv_heads=2, head_dim=64, ffn=256,
+                       vocab=256, max_pos=128))
+    st = _bf(random_state(oc, seed=3))
+    w = _product(oc, st)
+    model = DecoderModel(w, max_ctx=128, split_tokens=128)
+    kv = PagedKVCache(w.cfg, 16, 1, 128, "cpu")
+    tokens = [5, 9, 200, 31, 7, 7, 100, 42, 1, 2, 3]
+    kv.ensure_capacity(0, len(tokens))
+    tok = torch.tensor(tokens, dtype=torch.int32)
+    zero = torch.zeros(1, dtype=torch.int32)
+    outs, c0 = [], 0
+    for q in (6, 1, 4):                      # prompt chunk, a decode token, a verify-like pass
+        lg = torch.empty(q, oc.vocab, dtype=torch.float32)
+        model.forward(kv, tok, 0, c0, zero, c0, 1, q, lg, 128)
+        outs.append(lg)
+        c0 += q
+    got = torch.cat(outs)
+    lm = OracleLM(oc, st, bf16_acts=True)
+    ref = lm.forward(tokens, 0, lm.new_cache())
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 0.03 * scale
+    assert (got.argmax(dim=1) == ref.argmax(dim=1)).float().mean().item() > 0.8
+
+
+def test_acceptance_entry_points_match_the_oracle():
+    from vllm_omni_draft_amd import ops
+    rng = np.random.default_rng(0)
+    B, k, V = 5, 4, 64
+    p = rng.dirichlet(np.ones(V) * 0.3, size=(B, k + 1)).astype(np.float32)
+    q = rng.dirichlet(np.ones(V) * 0.3, size=(B, k)).astype(np.float32)
+    q64 = q.astype(np.float64)
+    ids = np.stack([[rng.choice(V, p=q64[b, i] / q64[b, i].sum()) for i in range(k)]
+                    for b in range(B)]).astype(np.int64)
+    bonus = rng.integers(0, V, size=B).astype(np.int64)
+    ua, ur = rng.random((B, k), dtype=np.float32), rng.random((B, k + 1), dtype=np.float32)
+    lens = np.array([4, 2, 0, 4, 3], dtype=np.int32)
+    ref, ctr = sampling.rejection_sample(p, bonus, q, ids, ua, ur, lens)
+    counters = torch.zeros(3, dtype=torch.int64)
+    t = torch.from_numpy
+    got = ops.rejection_sample(t(p), t(bonus), t(q), t(ids), t(ua), t(ur), t(lens), counters)
+    assert np.array_equal(got.numpy(), ref) and counters.tolist() == list(ctr)
+    tids = p.argmax(axis=2).astype(np.int64)
+    gref, gctr = sampling.greedy_verify(tids, ids, lens)
+    counters.zero_()
+    assert np.array_equal(ops.greedy_verify(t(tids), t(ids), t(lens), counters).numpy(), gref)
+    assert counters.tolist() == list(gctr)
+    x = rng.standard_normal((6, 1000)).astype(np.float32)
+    assert ops.argmax_rows(t(x)).tolist() == sampling.argmax_rows(x).tolist()
+    pv = torch.empty(6, 64)
+    pi = torch.empty(6, 64, dtype=torch.int32)
+    ops.argmax_partial(t(x), pv, pi)
+    assert ops.argmax_from_partials(pv, pi, 6).tolist() == sampling.argmax_rows(x).tolist()
+
+
+def test_config1_plumbing_opt125m_shapes_through_the_worker():
+    """BASELINE.json configs[0]: facebook/opt-125m target + opt-125m draft (the same weights),
+    k = 3, greedy, batch 8, one process, no GPU.  The draft IS the target, so every proposal is
+    accepted: accept-len == k exactly (a known answer), and the streams are the greedy
+    autoregressive streams of the CPU oracle."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeConfig, SpecDecodeWorker)
+    oc = OracleConfig(arch="opt", n_layers=12, hidden=768, n_heads=12, n_kv_heads=12, head_dim=64,
+                      ffn=3072, vocab=50272, max_pos=256, tie_embeddings=True)
+    st = _bf(random_state(oc, seed=125))
+    w = _product(oc, st)
+    worker = SpecDecodeWorker(SpecDecodeConfig(target=w, draft=w, num_speculative_tokens=3,
+                                               max_num_seqs=8, max_model_len=96, split_tokens=128,
+                                               rows="narrow"))
+    worker.init_device()
+    worker.load_model()
+    g = torch.Generator().manual_seed(1234)
+    prompts = {f"r{i}": torch.randint(0, oc.vocab, (int(n),), generator=g).tolist()
+               for i, n in enumerate(torch.randint(4, 24, (8,), generator=g))}
+    out = worker.execute_model(ExecuteModelRequest(
+        [SequenceGroupMetadata(r, True, p) for r, p in prompts.items()]))
+    got = {r: list(t) for r, t in zip(out.req_ids, out.sampled_token_ids)}
+    for _ in range(3):
+        out = worker.execute_model(ExecuteModelRequest(
+            [SequenceGroupMetadata(r, False) for r in prompts]))
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            assert len(toks) == 4, (r, toks)            # k accepted + the bonus token
+            got[r].extend(toks)
+    m = worker.metrics.maybe_collect(force=True)
+    assert m.accept_len == 3.0 and m.draft_acceptance_rate == 1.0
+    lm = OracleLM(oc, st, bf16_acts=True)
+    n_match = n_all = 0
+    for r in list(prompts)[:3]:                         # the oracle is slow at this vocabulary
+        ref = ar_generate(lm, prompts[r], len(got[r]))
+        seq, cache = list(prompts[r]), lm.new_cache()
+        logits = lm.forward(seq, 0, cache)[-1]
+        for i, want in enumerate(ref):
+            if got[r][i] != want:                       # only legitimate at a near-tie of the oracle
+                top2 = torch.topk(logits, 2).values
+                assert (top2[0] - top2[1]).item() / logits.abs().max().item() < 0.03, (r, i)
+                break
+            n_match += 1
+            logits = lm.forward([want], len(seq), cache)[-1]
+            seq.append(want)
+        n_all += len(ref)
+    assert n_match >= 0.6 * n_all, (n_match, n_all)

@@ -549,3 +549,46 @@ def test_narrow_draft_sub_batches_on_parallel_streams(use_graph):
     assert results[0] == results[1]
     auto = _engine(tw, dw, 3, **kw)
     assert not auto.draft.wide and auto._lanes      # the default picks this path at 20 sequences
+
+
+def test_config1_opt125m_target_and_draft_known_answer():
+    """BASELINE.json configs[0] on the GPU library: OPT-125m shapes, the same weights as target
+    and draft, k = 3, greedy, batch 8.  Known answer: every proposal is accepted (accept-len ==
+    k exactly, 4 tokens per step and sequence); the streams are the oracle's greedy
+    autoregressive streams up to its first near-tie."""
+    oc = OracleConfig(arch="opt", n_layers=12, hidden=768, n_heads=12, n_kv_heads=12, head_dim=64,
+                      ffn=3072, vocab=50272, max_pos=256, tie_embeddings=True)
+    st = _bf(random_state(oc, seed=125))
+    w = _product(oc, st)
+    g = torch.Generator().manual_seed(1234)
+    prompts = [torch.randint(0, oc.vocab, (int(n),), generator=g).tolist()
+               for n in torch.randint(4, 24, (8,), generator=g)]
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    eng = SpecEngine(w, w, EngineConfig(k=3, max_batch=8, max_seq_len=96, split_tokens=128))
+    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    for _ in range(4):
+        for o, new in zip(outs, eng.step()):
+            assert len(new) == 4, new
+            o.extend(new)
+    m = eng.metrics()
+    assert m["accepted"] == m["draft"] == 8 * 4 * 3 and m["emitted"] == 8 * 4 * 4
+    # the same streams from an autoregressive engine of the same kernel family
+    ar = SpecEngine(w, None, EngineConfig(k=0, max_batch=8, max_seq_len=96, split_tokens=128,
+                                          rows="wide" if eng.wide else "narrow"))
+    assert _generate(ar, prompts, 17) == [o[:17] for o in outs]
+    lm = OracleLM(oc, st, bf16_acts=True)
+    n_match = n_all = 0
+    for p, got in list(zip(prompts, outs))[:3]:         # the oracle is slow at this vocabulary
+        seq, cache = list(p), lm.new_cache()
+        logits = lm.forward(seq, 0, cache)[-1]
+        for i in range(len(got)):
+            want = int(torch.argmax(logits))
+            if got[i] != want:                          # only legitimate at a near-tie of the oracle
+                top2 = torch.topk(logits, 2).values
+                assert (top2[0] - top2[1]).item() / logits.abs().max().item() < 0.03, i
+                break
+            n_match += 1
+            logits = lm.forward([want], len(seq), cache)[-1]
+            seq.append(want)
+        n_all += len(got)
+    assert n_match >= 0.6 * n_all, (n_match, n_all)

@@ -132,13 +132,27 @@ SIGNATURES = {
 }
 
 
+def backend() -> str:
+    """"gpu" (libsd_amd.so, gfx950; the default) or "cpu" (libsd_cpu.so, the C++/OpenMP build of
+    the same ABI for hosts without a GPU), chosen for the whole process by SD_AMD_BACKEND before
+    the first call.  The choice is explicit: a missing GPU library is an error, never a reason
+    to load the other one."""
+    b = os.environ.get("SD_AMD_BACKEND", "gpu").lower()
+    if b not in ("gpu", "cpu"):
+        raise SdError(f"SD_AMD_BACKEND must be 'gpu' or 'cpu', not {b!r}")
+    return b
+
+
 def lib_path() -> str:
-    """The in-tree library; SD_AMD_LIB names another build of the same sources (the
-    timestamp-instrumented one of `make stamps`, for experiments/)."""
+    """The in-tree library of the chosen backend; SD_AMD_LIB names another build of the GPU
+    sources (the timestamp-instrumented one of `make stamps`, for experiments/)."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    if backend() == "cpu":
+        return os.path.join(here, "libsd_cpu.so")
     override = os.environ.get("SD_AMD_LIB")
     if override:
         return os.path.abspath(override)
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    return os.path.join(here, _LIB_NAME)
 
 
 def load() -> C.CDLL:
@@ -148,8 +162,8 @@ def load() -> C.CDLL:
         return _lib
     path = lib_path()
     if not os.path.exists(path):
-        raise SdError(f"{path} is missing: build it with `make` (hipcc --offload-arch=gfx950); "
-                      "this package has no CPU or PyTorch fallback")
+        raise SdError(f"{path} is missing: build it with `make` (hipcc --offload-arch=gfx950; "
+                      "g++ for the CPU build); nothing falls back to another library or to PyTorch")
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported

@@ -24,7 +24,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from . import _lib, ops
+from . import _lib, _rt, ops
 from .kv_cache import PagedKVCache
 from .model_runner import MAX_ROWS, DecoderModel
 from .weights import ModelWeights
@@ -153,7 +153,8 @@ class SpecEngine:
         self._lanes: List[torch.cuda.Stream] = []
         self._lane_ws: List[torch.Tensor] = []
         # (collectives of one communicator must stay on one stream: no lanes for a sharded draft)
-        if self.draft is not None and not self.draft.wide and cfg.draft_lanes > 1 and not draft_tp:
+        if (self.draft is not None and not self.draft.wide and cfg.draft_lanes > 1 and not draft_tp
+                and _rt.on_gpu()):
             n_sub = -(-2 * B // self.draft.max_rows)      # the first pass carries 2 tokens per sequence
             n = min(cfg.draft_lanes, n_sub)
             if n > 1:
@@ -171,8 +172,8 @@ class SpecEngine:
         if self.host_props:
             self.ext_props = torch.zeros(B, k, **dict(dtype=torch.int32, device=dev))
             self.prop_lens = torch.zeros(B, **dict(dtype=torch.int32, device=dev))
-            self._props_host = torch.zeros(B, k, dtype=torch.int32).pin_memory()
-            self._lens_host = torch.zeros(B, dtype=torch.int32).pin_memory()
+            self._props_host = _rt.pin(torch.zeros(B, k, dtype=torch.int32))
+            self._lens_host = _rt.pin(torch.zeros(B, dtype=torch.int32))
 
         i32 = dict(dtype=torch.int32, device=dev)
         self.seq_lens = torch.zeros(B, **i32)
@@ -225,7 +226,7 @@ class SpecEngine:
         # Multimodal rotary embedding: rotary position of a generated token = its cache
         # position + the delta its prompt's image tokens left behind (0 for text prompts)
         self.rope_delta = torch.zeros(B, dtype=torch.int32, device=dev)
-        self._records = torch.full((2, B, k + 3), -1, dtype=torch.int32).pin_memory()
+        self._records = _rt.pin(torch.full((2, B, k + 3), -1, dtype=torch.int32))
         self._parity = 0
         self._inflight = None   # (event, record parity, sequences) of a step not yet read back
         self._steps_pending = 0               # steps enqueued since the last read-back
@@ -257,12 +258,12 @@ class SpecEngine:
         self._graphs: dict = {}               # (B, k, truth?, ctx bucket) -> captured step
         self._ctx = self.max_ctx              # context bound the passes are enqueued with
         # stream capture is not allowed on the legacy default stream
-        self.stream = torch.cuda.Stream(device=dev)
-        torch.cuda.synchronize(dev)  # buffers above were filled on the default stream
+        self.stream = _rt.new_stream(dev)
+        _rt.synchronize(dev)  # buffers above were filled on the default stream
 
     # ------------------------------------------------------------------ requests
     def reset(self) -> None:
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             self._reset()
 
     def _reset(self) -> None:
@@ -316,7 +317,7 @@ class SpecEngine:
         [3, len(prompt)] the rotary positions for models with mrope_section.  truth_row
         (benchmarks with synthetic acceptance, see set_synthetic_acceptance): the request's
         token stream from position 0, stored in the slot's row of the truth table."""
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             if truth_row is not None:
                 if self.truth is None:
                     raise ValueError("truth_row needs set_synthetic_acceptance first")
@@ -399,7 +400,7 @@ class SpecEngine:
         per = max(1, model.max_rows // q_len)
         starts = list(range(0, B, per))
         lanes = len(starts) > 1 and model is self.draft and bool(self._lanes)
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream() if lanes else None
         if lanes:
             fork = torch.cuda.Event()
             fork.record(main)
@@ -416,7 +417,7 @@ class SpecEngine:
             if lane and lane not in used:
                 stream.wait_event(fork)
                 used.add(lane)
-            with torch.cuda.stream(stream):
+            with _rt.stream_ctx(stream if lanes else None):
                 model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens,
                               tok_stride, tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits,
                               self._ctx, rope_delta=delta,
@@ -633,7 +634,7 @@ class SpecEngine:
         that active sequences stay contiguous (synchronises)."""
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             last = self.active - 1
             if not 0 <= slot <= last:
                 raise ValueError(f"slot {slot} is not active")
@@ -655,7 +656,7 @@ class SpecEngine:
                     self.history[slot] = self.history[last]
             self.host_lens[last] = self.host_gen[last] = 0
             self.active = last
-            torch.cuda.synchronize(self.device)
+            _rt.synchronize(self.device)
 
     # ------------------------------------------------------------------ stepping
     def _refresh_uniforms(self) -> None:
@@ -687,13 +688,13 @@ class SpecEngine:
             raise RuntimeError("flush() the step in flight before a synchronous step")
         if proposals is not None:
             self.set_external_proposals(proposals)
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             return self._step(sync)
 
     def prepare_step(self) -> None:
         """Host work that must precede a step's kernels: cache pages for the
         tokens the step may write, fresh uniforms (sampling)."""
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             self._prepare_step()
 
     def _prepare_step(self) -> None:
@@ -730,7 +731,7 @@ class SpecEngine:
     def finish_step(self) -> List[List[int]]:
         """After a step's kernels were enqueued piecewise: reads the emitted
         tokens back (synchronises)."""
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             for b in range(self.active):
                 self.host_lens[b] += self.k + 1
             self._steps_pending += 1
@@ -741,14 +742,14 @@ class SpecEngine:
         if B == 0:
             return [] if sync else None
         self._prepare_step()
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = ops._stream()
         lib = _lib.load()
-        if self.cfg.use_graph:
+        if self.cfg.use_graph and _rt.on_gpu():   # (the CPU build has no stream capture)
             key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity)
             g = self._graphs.get(key)
             if g is None:
                 self._enqueue_step()          # eager warm-up step (also a real step)
-                torch.cuda.synchronize()
+                _rt.synchronize()
                 g = C.c_void_p()
                 _lib.check(lib.sd_graph_begin(stream), "sd_graph_begin")
                 try:
@@ -778,7 +779,9 @@ class SpecEngine:
         flight.  Not with prompt lookup (its proposals come from the tokens read back)."""
         if self.host_props:
             raise RuntimeError("step_overlapped: host-made proposals need each step's tokens")
-        with torch.cuda.stream(self.stream):
+        if not _rt.on_gpu():
+            raise RuntimeError("step_overlapped needs the GPU library (the CPU build is synchronous)")
+        with _rt.stream_ctx(self.stream):
             if self.active == 0:
                 return []
             prev = self._inflight
@@ -791,7 +794,7 @@ class SpecEngine:
 
     def flush(self) -> Optional[List[List[int]]]:
         """Tokens of the step still in flight after step_overlapped (None if there is none)."""
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             prev, self._inflight = self._inflight, None
             return None if prev is None else self._collect(prev, 0)
 
@@ -836,7 +839,7 @@ class SpecEngine:
 
     def read_back(self) -> List[List[int]]:
         """Synchronises and returns the tokens emitted since the last read-back."""
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             return self._read_back()
 
     def _read_back(self) -> List[List[int]]:
@@ -844,7 +847,7 @@ class SpecEngine:
         pending, self._steps_pending = self._steps_pending, 0
         if pending == 1:
             # the step's last kernel left its record in pinned host memory
-            torch.cuda.current_stream().synchronize()
+            _rt.sync_current_stream()
             rec = self._records[self._parity, :B].tolist()
             out = []
             for b in range(B):
@@ -869,7 +872,7 @@ class SpecEngine:
         return out
 
     def metrics(self) -> dict:
-        with torch.cuda.stream(self.stream):
+        with _rt.stream_ctx(self.stream):
             acc, emit, draft = self.counters.tolist()
         return {"accepted": acc, "emitted": emit, "draft": draft}
 

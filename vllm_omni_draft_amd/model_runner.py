@@ -10,7 +10,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .config import ModelConfig
 from .kv_cache import PagedKVCache
 from .weights import ModelWeights
@@ -135,5 +135,5 @@ class DecoderModel:
                                 rope_delta=_ptr(rope_delta))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
-                                          torch.cuda.current_stream().cuda_stream)
+                                          ops._stream())
         _lib.check(rc, "sd_model_forward")

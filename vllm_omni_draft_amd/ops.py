@@ -13,8 +13,13 @@ EPI_STORE, EPI_RESIDUAL, EPI_SILU_MUL, EPI_RELU, EPI_F32, EPI_GELU_TANH = range(
 PAGE = 16
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def on_gpu() -> bool:
+    """False only in a process started with SD_AMD_BACKEND=cpu (the CPU build of the ABI)."""
+    return _lib.backend() == "gpu"
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream if on_gpu() else None
 
 
 def _p(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -22,9 +27,12 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _need(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
-    if not t.is_cuda:
+    if on_gpu() and not t.is_cuda:
         raise _lib.SdError(f"{name}: tensor must live on the GPU (got {t.device}); "
-                           "there is no CPU path")
+                           "the GPU library has no CPU path")
+    if not on_gpu() and t.is_cuda:
+        raise _lib.SdError(f"{name}: this process runs the CPU build of the library "
+                           f"(SD_AMD_BACKEND=cpu) and takes host tensors, got {t.device}")
     if t.dtype != dtype:
         raise _lib.SdError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():

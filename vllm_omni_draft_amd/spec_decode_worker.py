@@ -26,7 +26,7 @@ from typing import Dict, FrozenSet, List, Optional, Sequence, Set
 import torch
 from torch import nn
 
-from . import ops
+from . import _rt, ops
 from .engine import EngineConfig, SpecEngine
 from .metrics import AsyncMetricsCollector, SpecDecodeWorkerMetrics
 from .weights import ModelWeights
@@ -191,7 +191,7 @@ class MultiStepWorker:
         # A sequence whose previous step accepted every proposal lacks the draft KV of
         # its last proposal.  The first draft pass always feeds the last two tokens,
         # so no per-sequence expansion is needed and the set can be ignored.
-        with torch.cuda.stream(self.engine.stream):
+        with _rt.stream_ctx(self.engine.stream):
             self.engine._enqueue_propose()
 
 
@@ -226,7 +226,7 @@ class NGramProposer(SpeculativeProposer):
                            seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
         eng = self.engine
         B = eng.active
-        with torch.cuda.stream(eng.stream):
+        with _rt.stream_ctx(eng.stream):
             eng._enqueue_lookup_proposals()
         return SpeculativeProposals(
             proposal_token_ids=eng.draft_ids[:B],
@@ -246,7 +246,7 @@ class ExternalProposer(SpeculativeProposer):
                            seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
         eng = self.engine
         B = eng.active
-        with torch.cuda.stream(eng.stream):
+        with _rt.stream_ctx(eng.stream):
             eng._enqueue_lookup_proposals()
         return SpeculativeProposals(
             proposal_token_ids=eng.draft_ids[:B],
@@ -288,14 +288,14 @@ class MQAScorer(SpeculativeScorer):
     def score_proposals(self, execute_model_req=None, proposals=None) -> SpeculativeScores:
         eng = self.engine
         B, k = eng.active, eng.k
-        with torch.cuda.stream(eng.stream):
+        with _rt.stream_ctx(eng.stream):
             if proposals is not None:
                 self._take_proposals(proposals)
             eng._enqueue_score()
         logits = eng.t_logits[:B * (k + 1)].view(B, k + 1, eng.V)
         if eng.sampling:
             token_ids = eng.target_ids[:B]
-            with torch.cuda.stream(eng.stream):
+            with _rt.stream_ctx(eng.stream):
                 ops.argmax_rows(eng.t_logits[:B * (k + 1)], out=eng.target_ids.view(-1))
                 token_ids[:, k] = eng.bonus_ids[:B]
             return SpeculativeScores(probs=eng.t_probs[:B], token_ids=token_ids, logits=logits)
@@ -462,9 +462,11 @@ class SpecDecodeWorker:
 
     # -- life cycle (vLLM worker protocol) ----------------------------------------
     def init_device(self) -> None:
-        if not torch.cuda.is_available():
-            raise RuntimeError("SpecDecodeWorker needs a GPU: there is no CPU path")
-        torch.cuda.set_device(self.local_rank)
+        if _rt.on_gpu():
+            if not torch.cuda.is_available():
+                raise RuntimeError("SpecDecodeWorker needs a GPU: the GPU library has no CPU path "
+                                   "(the CPU build of the library is chosen with SD_AMD_BACKEND=cpu)")
+            torch.cuda.set_device(self.local_rank)
         tp = self.config.tensor_parallel_size
         if tp > 1:
             from . import parallel
@@ -484,7 +486,7 @@ class SpecDecodeWorker:
             if tp > 1:
                 vp = c.vocab_parallel_lm_head and cfg.vocab % (16 * tp) == 0
                 cfg, state = W.shard_state_dict(cfg, state, tp, self.rank, vocab_parallel=vp)
-            target = W.from_state_dict(cfg, state, torch.device("cuda", self.local_rank))
+            target = W.from_state_dict(cfg, state, _rt.device(self.local_rank))
         draft = c.draft
         if c.draft_tensor_parallel_size not in (1, tp):
             raise ValueError("draft_tensor_parallel_size must be 1 or tensor_parallel_size")
@@ -495,7 +497,7 @@ class SpecDecodeWorker:
             if draft_tp:   # head split like the target's
                 dcfg, dstate = W.shard_state_dict(dcfg, dstate, tp, self.rank,
                                                   vocab_parallel=target.cfg.lm_vocab > 0)
-            draft = W.from_state_dict(dcfg, dstate, torch.device("cuda", self.local_rank))
+            draft = W.from_state_dict(dcfg, dstate, _rt.device(self.local_rank))
         self.engine = SpecEngine(target, draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
@@ -656,7 +658,7 @@ class SpecDecodeWorker:
         return eng.finish_step()
 
     def _verify_tokens(self, proposals: SpeculativeProposals, scores: SpeculativeScores) -> None:
-        with torch.cuda.stream(self.engine.stream):
+        with _rt.stream_ctx(self.engine.stream):
             self.engine._enqueue_accept()
 
     def _finish(self, request_id: str) -> None:
