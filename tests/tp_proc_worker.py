@@ -1,0 +1,142 @@
+"""Worker of tests/test_gpu_tp_procs.py: one RANK of a two-process tensor-parallel run, both
+processes on card 0 (started with torch.distributed.run, gloo for the host-side exchange).
+
+1. Tries the library's own RCCL group with two ranks (sd_tp_comm_create(world = 2)) and, if the
+   communicator comes up, runs all-reduce / all-gather and a sharded engine with the step graph
+   (collectives captured inside).  RCCL may refuse two ranks on one device; the outcome is
+   recorded either way.
+2. Runs the same sharded engines with a gloo-backed sd_allreduce_fn (the collective crosses a
+   real process boundary: weights sharded per process, vocabulary-parallel head exchange), and
+   checks rank-for-rank equal streams, greedy spec == AR, and closeness to the unsharded model.
+Writes one JSON file per rank into the directory given as argv[1]."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.models import OracleConfig, random_state  # noqa: E402
+from vllm_omni_draft_amd import _lib, config, parallel, weights  # noqa: E402
+from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine  # noqa: E402
+
+
+def cfg_of(oc):
+    return config.create_model_config(
+        None, arch=oc.arch, n_layers=oc.n_layers, hidden=oc.hidden, n_heads=oc.n_heads,
+        n_kv_heads=oc.n_kv_heads, head_dim=oc.head_dim, ffn=oc.ffn, vocab=oc.vocab,
+        max_pos=oc.max_pos, norm_eps=oc.norm_eps, rope_theta=oc.rope_theta,
+        tie_embeddings=oc.tie_embeddings)
+
+
+class GlooGroup(parallel.CallbackAllReduce):
+    """sd_allreduce_fn over torch.distributed (gloo): the partial products leave the card, are
+    summed across the processes on the host and return.  Synchronous, so no step graph."""
+
+    def __init__(self, rank, world):
+        self.buffers = []        # tensors the library may hand to the callback (workspaces)
+        super().__init__(rank, self._allreduce, world_size=world, gather=self._gather)
+
+    def _view(self, ptr, n):
+        for ws in self.buffers:
+            off = ptr - ws.data_ptr()
+            if 0 <= off and off + 2 * n <= ws.numel():
+                return ws[off:off + 2 * n].view(torch.bfloat16)
+        raise AssertionError("all-reduce buffer is in none of the known workspaces")
+
+    def _allreduce(self, ptr, n, stream):
+        try:
+            dev = self._view(ptr, n)
+            torch.cuda.current_stream().synchronize()
+            host = dev.float().cpu()
+            dist.all_reduce(host)                       # two ranks: the f32 sum rounds like a bf16 add
+            dev.copy_(host.to(torch.bfloat16))
+            return 0
+        except Exception as e:  # noqa: BLE001
+            print(f"allreduce failed: {e!r}", file=sys.stderr, flush=True)
+            return -1
+
+    def _gather(self, send, recv):
+        torch.cuda.current_stream().synchronize()
+        host = send.reshape(-1).view(torch.uint8).cpu()
+        parts = [torch.empty_like(host) for _ in range(self.world_size)]
+        dist.all_gather(parts, host)
+        recv.reshape(-1).view(torch.uint8).copy_(torch.cat(parts))
+
+
+def generate(eng, prompts, n_new):
+    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    while min(len(o) for o in outs) < n_new:
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    return [o[:n_new] for o in outs]
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    res = {"rank": rank, "world": world}
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=256, n_heads=4, n_kv_heads=2, head_dim=64,
+                      ffn=512, vocab=512, max_pos=256, tie_embeddings=True)
+    dc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64,
+                      ffn=256, vocab=512, max_pos=256)
+    state = {k: v.to(torch.bfloat16) for k, v in random_state(oc, seed=7).items()}
+    cfg = cfg_of(oc)
+    dw = weights.from_state_dict(cfg_of(dc), {k: v.to(torch.bfloat16) for k, v in
+                                              random_state(dc, seed=8).items()}, "cuda")
+    local, st = weights.shard_state_dict(cfg, state, world, rank, vocab_parallel=True)
+    tw = weights.from_state_dict(local, st, "cuda")
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 60))]
+
+    # ---- 1. the library's RCCL group with two ranks on this one card
+    try:
+        group = parallel.TensorParallelGroup(rank, world)
+        res["rccl_world2"] = "communicator created"
+        t = torch.full((1024,), float(rank + 1), dtype=torch.bfloat16, device="cuda")
+        group.all_reduce(t)
+        torch.cuda.synchronize()
+        res["rccl_allreduce_ok"] = bool((t == 3.0).all().item())
+        send = torch.full((64,), rank, dtype=torch.int32, device="cuda")
+        recv = torch.empty(64 * world, dtype=torch.int32, device="cuda")
+        group.all_gather(send, recv)
+        torch.cuda.synchronize()
+        res["rccl_allgather_ok"] = recv.view(world, 64)[:, 0].tolist() == list(range(world))
+        for graph in (False, True):
+            eng = SpecEngine(tw, dw, EngineConfig(k=3, max_batch=2, max_seq_len=120, split_tokens=128,
+                                                  use_graph=graph), tp_group=group)
+            res[f"rccl_stream_graph_{graph}"] = generate(eng, prompts, 24)
+            del eng
+        group.close()
+    except Exception as e:  # noqa: BLE001 - the refusal is the result
+        res["rccl_world2"] = f"refused: {type(e).__name__}: {e}"
+    dist.barrier()
+
+    # ---- 2. the same engines over a gloo-backed sd_allreduce_fn
+    streams = {}
+    for k in (0, 3):
+        group = GlooGroup(rank, world)
+        eng = SpecEngine(tw, dw if k else None, EngineConfig(k=k, max_batch=2, max_seq_len=120,
+                                                            split_tokens=128, use_graph=False),
+                         tp_group=group)
+        group.buffers = [eng.target.workspace]
+        streams[k] = generate(eng, prompts, 24)
+        del eng
+    res["gloo_ar"], res["gloo_spec"] = streams[0], streams[3]
+    if rank == 0:   # the unsharded model in this process, for closeness
+        full = weights.from_state_dict(cfg, state, "cuda")
+        eng = SpecEngine(full, None, EngineConfig(k=0, max_batch=2, max_seq_len=120, split_tokens=128,
+                                                  use_graph=False))
+        res["unsharded_ar"] = generate(eng, prompts, 24)
+    with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
