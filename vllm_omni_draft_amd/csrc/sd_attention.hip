@@ -333,7 +333,11 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
   STAMP(6);
 }
 
-// Merges the per-split partials of one (sequence, token, head) in split order.
+// Merges the per-split partials of one (sequence, token, head) in split order.  Up to
+// kMergeAhead splits are requested before the sequence length is known (partials of splits
+// past the length are read and ignored), so the launch costs one memory round trip, not
+// three dependent ones; the arithmetic is the same sum in split order either way.
+constexpr int kMergeAhead = 8;
 template <int D>
 __global__ __launch_bounds__(D) void attn_merge_kernel(AttnArgs a, int m_pad) {
   const int d = threadIdx.x;
@@ -344,15 +348,34 @@ __global__ __launch_bounds__(D) void attn_merge_kernel(AttnArgs a, int m_pad) {
   const int G = a.Hq / a.Hkv;
   const int kvh = head / G, g = head % G;
   const int m = t * G + g;
+  const size_t base = (size_t)(b * a.Hkv + kvh) * a.n_splits;
+  float pm[kMergeAhead], pl[kMergeAhead], po[kMergeAhead];
+#pragma unroll
+  for (int s = 0; s < kMergeAhead; ++s) {
+    const size_t row = (base + min(s, a.n_splits - 1)) * m_pad + m;
+    pm[s] = a.part_ml[row * 2];
+    pl[s] = a.part_ml[row * 2 + 1];
+    po[s] = a.part_o[row * D + d];
+  }
   const int kv_len = a.seq_lens[sb] + a.pos_offset + qb * a.q_len + q_len;
   const int n_valid = min((kv_len + a.split_tokens - 1) / a.split_tokens, a.n_splits);
-  const size_t base = (size_t)(b * a.Hkv + kvh) * a.n_splits;
   float mx = -INFINITY;
-  for (int s = 0; s < n_valid; ++s)
+#pragma unroll
+  for (int s = 0; s < kMergeAhead; ++s)
+    if (s < n_valid) mx = fmaxf(mx, pm[s]);
+  for (int s = kMergeAhead; s < n_valid; ++s)
     mx = fmaxf(mx, a.part_ml[((base + s) * m_pad + m) * 2]);
   float o = 0.f, l = 0.f;
   if (mx != -INFINITY) {
-    for (int s = 0; s < n_valid; ++s) {
+#pragma unroll
+    for (int s = 0; s < kMergeAhead; ++s) {
+      if (s < n_valid) {
+        const float f = __builtin_amdgcn_exp2f(pm[s] - mx);
+        o += f * po[s];
+        l += f * pl[s];
+      }
+    }
+    for (int s = kMergeAhead; s < n_valid; ++s) {
       const size_t row = (base + s) * m_pad + m;
       const float f = __builtin_amdgcn_exp2f(a.part_ml[row * 2] - mx);
       o += f * a.part_o[row * D + d];
