@@ -139,3 +139,26 @@ def test_config1_plumbing_opt125m_shapes_through_the_worker():
             seq.append(want)
         n_all += len(ref)
     assert n_match >= 0.6 * n_all, (n_match, n_all)
+
+
+def test_prompts_prefilled_together_give_the_streams_of_one_at_a_time():
+    """Batched prefill (add_requests) on the CPU build: ragged prompts, same streams as
+    add_request prompt by prompt."""
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=128, n_heads=4, n_kv_heads=2, head_dim=64, ffn=256,
+                      vocab=256, max_pos=128)
+    w = _product(oc, _bf(random_state(oc, seed=3)))
+    d = _product(oc, _bf(random_state(oc, seed=4)))
+    rng = np.random.default_rng(1)
+    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in (4, 21, 1)]
+
+    def run(batched):
+        eng = SpecEngine(w, d, EngineConfig(k=2, max_batch=3, max_seq_len=64, split_tokens=128))
+        outs = ([[f] for f in eng.add_requests(prompts)] if batched else
+                [[eng.add_request(i, p)] for i, p in enumerate(prompts)])
+        for _ in range(4):
+            for o, new in zip(outs, eng.step()):
+                o.extend(new)
+        return [o[:5] for o in outs]
+
+    assert run(True) == run(False)

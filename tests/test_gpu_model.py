@@ -252,6 +252,36 @@ def test_draft_equals_target_accepts_all_and_batches():
     assert _generate(_engine(tw, None, 0, max_batch=3), prompts, 40) == ar
 
 
+@pytest.mark.parametrize("temperature", [0.0, 0.8])
+def test_prompts_prefilled_together_give_the_streams_of_one_at_a_time(temperature):
+    """add_requests carries a chunk of every prompt in each pass (ragged lengths: padding rows;
+    one prompt longer than a pass; a one-token prompt).  First tokens, later streams and the
+    acceptance counters equal those of add_request called prompt by prompt."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    rng = np.random.default_rng(4)
+    prompts = [[int(t) for t in rng.integers(0, tcfg.vocab, n)] for n in (5, 33, 1, 150, 17)]
+    kw = dict(max_batch=5, temperature=temperature, seed=9)
+    one = _engine(tw, dw, 3, **kw)
+    want = _generate(one, prompts, 24)
+    eng = _engine(tw, dw, 3, **kw)
+    firsts = eng.add_requests(prompts)
+    assert firsts == [w[0] for w in want]
+    outs = [[f] for f in firsts]
+    while min(len(o) for o in outs) < 24:
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    assert [o[:24] for o in outs] == want
+    assert eng.metrics() == one.metrics()
+    # two groups, the second behind the first
+    eng = _engine(tw, dw, 3, **kw)
+    assert eng.add_requests(prompts[:2]) + eng.add_requests(prompts[2:]) == firsts
+    with pytest.raises(ValueError):
+        eng.add_requests([[1, 2]])
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_wide_batch_spec_equals_ar(use_graph):
     """8 sequences x (k+1 = 6) rows = 48 rows per verify pass: the wide kernel family.  The

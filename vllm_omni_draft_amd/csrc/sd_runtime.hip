@@ -185,9 +185,8 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const bool wide = a->wide != 0;
   SD_REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= (wide ? 256 : 16), SD_ERR_UNSUPPORTED,
              "sd_model_forward: B*q_len = %d outside 1..%d", rows, wide ? 256 : 16);
-  SD_REQUIRE(a->q_len * (d.n_heads / d.n_kv_heads) <= 64 || (wide && a->B == 1), SD_ERR_UNSUPPORTED,
-             "sd_model_forward: q_len %d * (Hq/Hkv) > 64 needs the wide family and one sequence",
-             a->q_len);
+  SD_REQUIRE(a->q_len * (d.n_heads / d.n_kv_heads) <= 64 || wide, SD_ERR_UNSUPPORTED,
+             "sd_model_forward: q_len %d * (Hq/Hkv) > 64 needs the wide family", a->q_len);
   SD_REQUIRE((a->token_ids || a->input_embeds) && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables,
              SD_ERR_INVALID, "sd_model_forward: null buffer");
   SD_REQUIRE(a->max_ctx >= 1 && a->max_ctx <= d.max_pos, SD_ERR_INVALID,

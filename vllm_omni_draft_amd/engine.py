@@ -184,6 +184,7 @@ class SpecEngine:
         self.counters = torch.zeros(3, dtype=torch.int64, device=dev)
         self.zero_lens = torch.zeros(B, **i32)
         self.prompt_buf = torch.zeros(max(cfg.max_seq_len, 8), **i32)
+        self._prompt_rows: Optional[torch.Tensor] = None   # [max_batch, max_seq_len], batched prefill
         self.t_logits = torch.empty(max(MAX_ROWS, B * (k + 1)), self.V,
                                     dtype=torch.float32, device=dev)
         self.d_logits = torch.empty(max(MAX_ROWS, 2 * B), self.V, dtype=torch.float32, device=dev)
@@ -391,6 +392,99 @@ class SpecEngine:
         self.host_gen[slot] = 1
         self.active += 1
         return first_tok
+
+    def add_requests(self, prompts: Sequence[Sequence[int]],
+                     truth_rows: Optional[Sequence[Sequence[int]]] = None) -> List[int]:
+        """Prefills several text prompts in the same passes and returns their first tokens (one
+        synchronisation for all of them).  The prompts take the next free slots in order.
+        Every pass carries a chunk of each prompt (prefill_rows // len(prompts) tokens per
+        sequence, wide kernel family); rows past the end of a shorter prompt are padding whose
+        cache entries are overwritten before anything reads them.  A row's bits do not depend
+        on what shares its pass, so the streams equal those of add_request called once per
+        prompt."""
+        with _rt.stream_ctx(self.stream):
+            if truth_rows is not None:
+                if self.truth is None:
+                    raise ValueError("truth_rows need set_synthetic_acceptance first")
+                for i, tr in enumerate(truth_rows):
+                    row = torch.tensor(list(tr)[:self.truth.shape[1]], dtype=torch.int32)
+                    self.truth[self.active + i, :row.numel()].copy_(row)
+            return self._add_requests([list(p) for p in prompts])
+
+    def _add_requests(self, prompts: List[List[int]]) -> List[int]:
+        if self._inflight is not None:
+            raise RuntimeError("flush() the step in flight before changing the batch")
+        Bp, slot0 = len(prompts), self.active
+        if Bp == 0:
+            return []
+        if slot0 + Bp > self.cfg.max_batch:
+            raise ValueError(f"{Bp} prompts do not fit behind {slot0} active sequences")
+        lens = [len(p) for p in prompts]
+        for n in lens:
+            if n < 1 or n + 1 > self.cfg.max_seq_len:
+                raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
+        n_max = max(lens)
+        if Bp > min(m.prefill_rows for m in (self.target, self.draft) if m is not None):
+            # more prompts than rows in a pass: in groups
+            out: List[int] = []
+            per = min(m.prefill_rows for m in (self.target, self.draft) if m is not None)
+            for i in range(0, Bp, per):
+                out += self._add_requests(prompts[i:i + per])
+            return out
+        if self._prompt_rows is None or self._prompt_rows.shape[0] < Bp:
+            self._prompt_rows = torch.zeros(self.cfg.max_batch, max(self.cfg.max_seq_len, 8),
+                                            dtype=torch.int32, device=self.device)
+        stride = self._prompt_rows.shape[1]
+        host = torch.zeros(Bp, n_max, dtype=torch.int32)
+        for i, p in enumerate(prompts):
+            host[i, :lens[i]] = torch.tensor(p, dtype=torch.int32)
+        self._prompt_rows[:Bp, :n_max].copy_(host)
+        last = torch.tensor([p[-1] for p in prompts], dtype=torch.int32).to(self.device)
+        lens_dev = torch.tensor(lens, dtype=torch.int32).to(self.device)
+        for i in range(Bp):
+            # padding rows write up to n_max - 2 in every sequence's cache
+            self.t_kv.ensure_capacity(slot0 + i, n_max + self.k + 2)
+            if self.d_kv is not None:
+                self.d_kv.ensure_capacity(slot0 + i, n_max + self.k + 2)
+        self.rope_delta[slot0:slot0 + Bp] = 0
+        self._ctx = self._ctx_bucket(n_max + self.k + 2)
+        zl = self.zero_lens[slot0:slot0 + Bp]
+        toks = self._prompt_rows.view(-1)
+        for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
+            if model is None:
+                continue
+            view = _KvView(kv, slot0)
+            # all but each prompt's last token, in chunks: no logits wanted
+            chunk = max(1, model.prefill_rows // Bp)
+            wide = model.prefill_rows > MAX_ROWS or self.wide    # the family add_request uses
+            for c0 in range(0, n_max - 1, chunk):
+                model.forward(view, toks, stride, c0, zl, c0, Bp, min(chunk, n_max - 1 - c0), None,
+                              self._ctx, wide=wide)
+            # every prompt's last token at its own position
+            model.forward(view, last, 1, 0, lens_dev, -1, Bp, 1,
+                          self.t_out[:Bp] if model is self.target else None, self._ctx, wide=wide)
+        if self.sampling:
+            self._target_full_rows(Bp)
+            u = torch.cat([torch.rand(1, generator=self.rng, device=self.device) for _ in range(Bp)])
+            probs = ops.softmax_rows(self.t_logits[:Bp], self.cfg.temperature)
+            first = ops.sample_rows(probs, u)
+        else:
+            first = self._target_argmax(Bp, torch.empty(Bp, dtype=torch.int64, device=self.device))
+        first32 = first.to(torch.int32)
+        sl = slice(slot0, slot0 + Bp)
+        self.tok_buf[sl, 0] = last
+        self.tok_buf[sl, 1] = first32
+        self.seq_lens[sl] = lens_dev + 1
+        self.gen_tokens[sl, 0] = first32
+        self.gen_counts[sl] = 1
+        firsts = [int(t) for t in first.tolist()]
+        for i, n in enumerate(lens):
+            self.host_lens[slot0 + i] = n + 1
+            self.host_gen[slot0 + i] = 1
+            if self.ngram:
+                self.history[slot0 + i] = prompts[i] + [firsts[i]]
+        self.active += Bp
+        return firsts
 
     # ------------------------------------------------------------------ passes
     def _forward(self, model: DecoderModel, kv: PagedKVCache, tokens, tok_stride, tok_offset,

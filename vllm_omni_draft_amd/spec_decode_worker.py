@@ -614,12 +614,26 @@ class SpecDecodeWorker:
             emitted = self._run_speculative_decoding_step(req)
             for slot, toks in enumerate(emitted):
                 out[self._req_at[slot]] = toks
-        for g in prompts:
-            slot = eng.active
-            first = eng.add_request(slot, g.prompt_token_ids, **mm_inputs[g.request_id])
-            self._slot_of[g.request_id] = slot
-            self._req_at.append(g.request_id)
-            out[g.request_id] = [first]
+        # text prompts that arrive together are prefilled in the same passes (one
+        # synchronisation for the group); a prompt with images goes alone
+        i = 0
+        while i < len(prompts):
+            j = i
+            while (j < len(prompts) and not mm_inputs[prompts[j].request_id]
+                   and hasattr(eng, "add_requests")):
+                j += 1
+            if j - i >= 2:
+                group = prompts[i:j]
+                firsts = eng.add_requests([g.prompt_token_ids for g in group])
+            else:
+                group = prompts[i:i + 1]
+                firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
+                                          **mm_inputs[group[0].request_id])]
+            for g, first in zip(group, firsts):
+                self._slot_of[g.request_id] = len(self._req_at)
+                self._req_at.append(g.request_id)
+                out[g.request_id] = [first]
+            i += len(group)
         ids = [g.request_id for g in metas]
         return ModelRunnerOutput(
             req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
