@@ -224,6 +224,42 @@ def test_worker_loads_and_shards_from_state_dicts_with_a_group_of_one():
     group.close()
 
 
+def test_fp8_draft_under_a_bf16_target_keeps_the_target_stream():
+    """draft_quantization="fp8": the draft's matrices are quantised at load (half the bytes per
+    draft pass), the target stays bf16, so the greedy stream is still the bf16 target's own
+    autoregressive stream; a draft that is the target's fp8 copy still gets proposals accepted.
+    Options that do not match the weights they are given for are refused."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                        SpecDecodeConfig, SpecDecodeWorker)
+    tcfg = MODELS["llama"]
+    tstate = _bf(random_state(tcfg, seed=21))
+    tw = _product(tcfg, tstate)
+    prompt = [5, 9, 200, 31, 7]
+    want = _generate(_engine(tw, None, 0), [prompt], 30)[0]
+    w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=(tw.cfg, tstate), draft_quantization="fp8",
+                                          num_speculative_tokens=3, max_num_seqs=1, max_model_len=200,
+                                          split_tokens=128))
+    w.init_device()
+    w.load_model()
+    assert w.engine.draft.weights.fp8 and not w.engine.target.weights.fp8
+    assert w.engine.draft.weights.layers[0].qkv_w.scale is not None
+    out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", True, prompt)])).sampled_token_ids[0]
+    while len(out) < 30:
+        out += w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", False)])).sampled_token_ids[0]
+    assert out[:30] == want
+    m = w.metrics.maybe_collect(force=True)
+    assert m.accepted_tokens > m.draft_tokens // 2      # an fp8 copy of the target mostly agrees with it
+    for bad in (dict(draft=tw, draft_quantization="fp8"),           # bf16 weights object
+                dict(draft=(tw.cfg, tstate), draft_quantization="int4"),
+                dict(draft=None, draft_quantization="fp8"),
+                dict(draft=(tw.cfg, tstate), quantization="fp8")):  # the target object is bf16
+        wb = SpecDecodeWorker(SpecDecodeConfig(target=tw, num_speculative_tokens=3, max_num_seqs=1,
+                                               max_model_len=200, split_tokens=128, **bad))
+        wb.init_device()
+        with pytest.raises(ValueError):
+            wb.load_model()
+
+
 def _llama_pair():
     tcfg = MODELS["llama"]
     dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})

@@ -429,6 +429,13 @@ class SpecDecodeConfig:
     # input rows of the target, and the tokenizer's placeholder token
     vision: Optional[object] = None
     image_token_id: int = 151655
+    # Weight-only fp8 (e4m3, one f32 scale per output row, quantised at load) for a model given
+    # as a (ModelConfig, state_dict) pair.  "fp8" on the draft alone halves the bytes its k
+    # passes stream while the emitted tokens stay the bf16 target's own stream (greedy) or
+    # distribution (sampling): only the acceptance rate can move.  "fp8" on the target changes
+    # the target model itself.  A ModelWeights object loaded with fp8=True needs no option.
+    quantization: Optional[str] = None
+    draft_quantization: Optional[str] = None
 
 
 class SpecDecodeWorker:
@@ -480,13 +487,25 @@ class SpecDecodeWorker:
     def load_model(self) -> None:
         c = self.config
         target, tp = c.target, c.tensor_parallel_size
+        for name, q, given in (("quantization", c.quantization, c.target),
+                               ("draft_quantization", c.draft_quantization, c.draft)):
+            if q not in (None, "fp8"):
+                raise ValueError(f"{name} must be None or 'fp8', not {q!r}")
+            if q and given is None:
+                raise ValueError(f"{name} without a model")
+            if q and tp > 1:
+                raise ValueError(f"{name}: fp8 weights are not sharded (tensor_parallel_size > 1)")
+            if q and not isinstance(given, tuple) and not getattr(given, "fp8", False):
+                raise ValueError(f"{name}={q!r} but the weights object was loaded without fp8; "
+                                 "pass (ModelConfig, state_dict) or load it with fp8=True")
         if isinstance(target, tuple):
             from . import weights as W
             cfg, state = target
             if tp > 1:
                 vp = c.vocab_parallel_lm_head and cfg.vocab % (16 * tp) == 0
                 cfg, state = W.shard_state_dict(cfg, state, tp, self.rank, vocab_parallel=vp)
-            target = W.from_state_dict(cfg, state, _rt.device(self.local_rank))
+            target = W.from_state_dict(cfg, state, _rt.device(self.local_rank),
+                                       fp8=c.quantization == "fp8")
         draft = c.draft
         if c.draft_tensor_parallel_size not in (1, tp):
             raise ValueError("draft_tensor_parallel_size must be 1 or tensor_parallel_size")
@@ -497,7 +516,8 @@ class SpecDecodeWorker:
             if draft_tp:   # head split like the target's
                 dcfg, dstate = W.shard_state_dict(dcfg, dstate, tp, self.rank,
                                                   vocab_parallel=target.cfg.lm_vocab > 0)
-            draft = W.from_state_dict(dcfg, dstate, _rt.device(self.local_rank))
+            draft = W.from_state_dict(dcfg, dstate, _rt.device(self.local_rank),
+                                      fp8=c.draft_quantization == "fp8")
         self.engine = SpecEngine(target, draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,
