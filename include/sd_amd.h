@@ -230,6 +230,57 @@ int sd_paged_attention_static(const void* q, int64_t ldq, const void* k_cache,
                               int split_tokens, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Token trees (multi-candidate verification; upstream: vllm/spec_decode's
+ * tree-style scoring is not in the reference tree, the semantics follow
+ * SpecInfer / Medusa tree attention: every node attends the context and its
+ * own ancestors).  One verify pass scores q_len = 1 + N rows per sequence: row
+ * 0 is the sequence's last token (the root), rows 1..N are candidate tokens in
+ * topological order (a node's parent has a smaller row index).  Row t is
+ * cached at slot seq_lens[b] + pos_offset + t but rotated at position
+ * seq_lens[b] + pos_offset + depth(t); after acceptance the accepted path's
+ * cache entries are moved to their chain slots (sd_kv_compact).
+ *
+ * sd_paged_attention_tree: sd_paged_attention with an ancestor mask.
+ * tree_mask [B*q_len] u64 (device): bit j of entry b*q_len + t set iff new
+ * token t attends new token j (its ancestors and itself, j <= t < 64).  The
+ * arithmetic of a row is that of sd_paged_attention over the keys it sees;
+ * masked keys sit at other slots than in a chain, so sums run in another
+ * order: results match a chain pass to rounding, not bit for bit.          */
+int sd_paged_attention_tree(const void* q, int64_t ldq, const void* k_cache,
+                            const void* v_cache, const int32_t* block_tables,
+                            int max_blocks_per_seq, const int32_t* seq_lens,
+                            int pos_offset, const uint64_t* tree_mask, void* out,
+                            int64_t ldo, int B, int q_len, int Hq, int Hkv, int D,
+                            float scale, int max_ctx, int split_tokens,
+                            void* workspace, size_t workspace_bytes, sd_stream_t stream);
+/* Before the verify pass: tree_tok[b][0] = tok_buf[b*tok_stride + tok_col] (the
+ * root = last emitted token) and rope_pos[b*q_len + t] = seq_lens[b] +
+ * pos_offset + tree_depth[b*q_len + t] (depth of the root = 0).             */
+int sd_tree_prepare(const int32_t* tok_buf, int64_t tok_stride, int tok_col,
+                    int32_t* tree_tok, const int32_t* tree_depth,
+                    const int32_t* seq_lens, int pos_offset, int32_t* rope_pos, int B,
+                    int q_len, sd_stream_t stream);
+/* Greedy acceptance over a tree.  target_ids [B*q_len] i64: the target's argmax
+ * after every row.  tree_tok / tree_parent [B, q_len] i32 (parent row of rows
+ * 1..; entry 0 unused), tree_len [B] rows in use (root included, 1..q_len).
+ * Walks from the root: while the target's token after the current row equals
+ * the token of one of its children (lowest row wins) and fewer than k are
+ * accepted, descend.  out_ids [B, k+1] i64: accepted tokens, then the target's
+ * token after the last accepted row, then -1.  path [B, k] i32: accepted rows;
+ * n_path [B].  counters (or NULL) += {accepted, emitted, depth of the tree}.  */
+int sd_tree_accept_greedy(const int64_t* target_ids, const int32_t* tree_tok,
+                          const int32_t* tree_parent, const int32_t* tree_len, int q_len,
+                          int k, int64_t* out_ids, int32_t* path, int32_t* n_path,
+                          int64_t* counters, int B, sd_stream_t stream);
+/* Moves the accepted rows' K/V (every layer, every KV head) from slot
+ * seq_lens[b] + pos_offset + path[b][d] to slot seq_lens[b] + pos_offset + d + 1,
+ * d = 0..n_path[b]-1, in that order.  Call before seq_lens advances.        */
+int sd_kv_compact(void* k_cache, void* v_cache, int64_t layer_stride_bytes, int n_layers,
+                  const int32_t* block_tables, int max_blocks_per_seq,
+                  const int32_t* seq_lens, int pos_offset, const int32_t* path,
+                  const int32_t* n_path, int k, int B, int Hkv, int D, sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Dense ops of a decoder layer at <= 16 token rows (weight streaming; replaces
  * the per-step model execution inside spec_decode.multi_step_worker and the
  * scorer's target forward).
@@ -495,6 +546,11 @@ typedef struct {
   const void* input_embeds;
   const int32_t* rope_pos;
   const int32_t* rope_delta;
+  /* Token tree pass (NULL: a chain).  tree_mask [B*q_len] u64 as for
+   * sd_paged_attention_tree; needs a rotary model without mrope sections, q_len *
+   * (Hq/Hkv) <= 64, and rope_pos = the rows' rotary positions ([B*q_len] i32; a model
+   * without sections reads one component only).                              */
+  const uint64_t* tree_mask;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

@@ -162,3 +162,37 @@ def test_prompts_prefilled_together_give_the_streams_of_one_at_a_time():
         return [o[:5] for o in outs]
 
     assert run(True) == run(False)
+
+
+def test_token_trees_on_the_cpu_build():
+    """Multi-candidate verification through the CPU build: the host's tree construction and
+    lookup equal the oracle's, and the stream is the autoregressive one."""
+    from oracle import tree as otree
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=128, n_heads=4, n_kv_heads=2, head_dim=64, ffn=256,
+                      vocab=256, max_pos=160)
+    w = _product(oc, _bf(random_state(oc, seed=3)))
+    rng = np.random.default_rng(2)
+    base = [int(t) for t in rng.integers(0, oc.vocab, 10)]
+    prompt = base + base[:5] + [7, 8] + base[:6]
+
+    def run(**kw):
+        eng = SpecEngine(w, None, EngineConfig(max_batch=1, max_seq_len=100, split_tokens=128, **kw))
+        out = [eng.add_request(0, prompt)]
+        while len(out) < 24:
+            out += eng.step()[0]
+        return out[:24], eng
+
+    ar, _ = run(k=0)
+    got, eng = run(k=3, ngram_max=3, ngram_min=1, tree_candidates=3)
+    assert got == ar and eng.metrics()["accepted"] > 0
+    hist = prompt + got
+    cands = eng._lookup_candidates(hist)
+    assert cands == otree.lookup_candidates(hist, 3, 3, 1, 3)
+    eng._upload_trees([cands])
+    t, p, d = otree.build_tree(cands, 3, eng.tree_nodes)
+    n = len(t)
+    assert eng.tree_len[0].item() == n
+    assert eng.tree_tok[0, 1:n].tolist() == t[1:] and eng.tree_parent[0, :n].tolist() == p
+    assert eng.tree_depth[0, :n].tolist() == d
+    assert eng.tree_mask[0, :n].tolist() == otree.ancestor_masks(p)

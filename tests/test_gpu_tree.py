@@ -1,0 +1,298 @@
+"""Token trees (multi-candidate verification) on the GPU against the CPU oracle: the masked
+attention kernel, the acceptance walk, the cache compaction, a tree pass of a whole model
+against chain passes of the same tokens, and the engine's streams against plain
+autoregressive decoding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tree as otree
+from oracle.attention import unpack_pages
+from oracle.models import OracleConfig, random_state
+from tests.test_gpu_attention import _setup
+from tests.test_gpu_model import MODELS, _bf, _engine, _generate, _product
+
+pytestmark = pytest.mark.gpu
+
+
+def _i64(masks):
+    return torch.tensor([m - (1 << 64) if m >= (1 << 63) else m for m in masks], dtype=torch.int64)
+
+
+TREES = [
+    # parents of rows 1.. (row 0 = root)
+    [0, 1, 2, 3, 4],                      # a chain: the tree kernel must equal the causal one
+    [0, 0, 1, 1, 2, 3, 3, 5],             # branching at several depths
+    [0, 0, 0, 0, 0, 0, 0],                # a star
+    [0, 1, 2, 0, 4, 5, 0, 7, 8, 0, 10, 11, 0, 13, 14],   # five chains of three (15 nodes)
+]
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,ctx_lens,split", [
+    (4, 2, 64, [37], 128),
+    (32, 8, 128, [300, 12], 128),         # several splits, ragged batch, partials + merge
+    (32, 8, 128, [1100], 256),
+    (12, 12, 64, [250, 255], 128),        # new tokens straddle a split and a page boundary
+])
+@pytest.mark.parametrize("parents", TREES, ids=["chain", "branchy", "star", "five-chains"])
+def test_tree_attention_matches_oracle(Hq, Hkv, D, ctx_lens, split, parents):
+    from vllm_omni_draft_amd import ops
+    par = [0] + parents
+    q_len, B = len(par), len(ctx_lens)
+    if q_len * (Hq // Hkv) > 64:
+        pytest.skip("more rows than one workgroup column holds")
+    masks = otree.ancestor_masks(par)
+    kc, vc, bt, ks, vs, qs = _setup(B, ctx_lens, q_len, Hq, Hkv, D, seed=sum(ctx_lens) + q_len)
+    q = torch.cat(qs).reshape(B * q_len, Hq * D).cuda()
+    seq_lens = torch.tensor(ctx_lens, dtype=torch.int32).cuda()
+    tm = _i64(masks * B).cuda()
+    max_ctx = max(ctx_lens) + q_len
+    out = ops.paged_attention_tree(q, kc.cuda(), vc.cuda(), bt.cuda(), seq_lens, 0, tm, B, q_len, Hq,
+                                   Hkv, D, D ** -0.5, max_ctx, split)
+    torch.cuda.synchronize()
+    out = out.float().cpu().view(B, q_len, Hq, D)
+    for b in range(B):
+        ref = otree.tree_attention(qs[b], ks[b], vs[b], ctx_lens[b], masks, D ** -0.5)
+        torch.testing.assert_close(out[b], ref, rtol=2e-2, atol=2e-2)
+    if parents == TREES[0]:   # a chain's masks are the causal mask: same bits as the plain kernel
+        plain = ops.paged_attention(q, kc.cuda(), vc.cuda(), bt.cuda(), seq_lens, 0, B, q_len, Hq, Hkv,
+                                    D, D ** -0.5, max_ctx, split)
+        assert torch.equal(plain.float().cpu().view(B, q_len, Hq, D), out)
+
+
+def test_tree_attention_rejects_bad_arguments():
+    from vllm_omni_draft_amd import _lib, ops
+    kc, vc, bt, ks, vs, qs = _setup(1, [20], 4, 4, 2, 64, seed=1)
+    q = torch.cat(qs).reshape(4, 4 * 64).cuda()
+    sl = torch.tensor([20], dtype=torch.int32).cuda()
+    with pytest.raises(_lib.SdError):      # int32 masks
+        ops.paged_attention_tree(q, kc.cuda(), vc.cuda(), bt.cuda(), sl, 0,
+                                 torch.zeros(4, dtype=torch.int32).cuda(), 1, 4, 4, 2, 64, 0.125, 24, 128)
+    with pytest.raises(_lib.SdError):      # too few masks
+        ops.paged_attention_tree(q, kc.cuda(), vc.cuda(), bt.cuda(), sl, 0,
+                                 torch.zeros(3, dtype=torch.int64).cuda(), 1, 4, 4, 2, 64, 0.125, 24, 128)
+
+
+def test_accept_walk_and_prepare_match_oracle():
+    from vllm_omni_draft_amd import ops
+    rng = np.random.default_rng(3)
+    B, k, N, V = 9, 4, 11, 7            # a small vocabulary makes matches and duplicates frequent
+    q = N + 1
+    tok = torch.zeros(B, q, dtype=torch.int32)
+    par = torch.zeros(B, q, dtype=torch.int32)
+    dep = torch.zeros(B, q, dtype=torch.int32)
+    lens = torch.ones(B, dtype=torch.int32)
+    tgt = torch.tensor(rng.integers(0, V, (B, q)), dtype=torch.int64)
+    trees = []
+    for b in range(B):
+        cands = [list(rng.integers(0, V, rng.integers(1, k + 2))) for _ in range(rng.integers(0, 5))]
+        if b == 0:
+            cands = []                                     # no proposals at all
+        if b == 1:                                         # the target follows one chain to the end
+            cands = [[1, 2, 3, 4], [1, 2, 5, 5]]
+        t, p, d = otree.build_tree(cands, k, N)
+        trees.append((t, p))
+        n = len(t)
+        tok[b, :n], par[b, :n], dep[b, :n] = torch.tensor(t), torch.tensor(p), torch.tensor(d)
+        lens[b] = n
+        if b == 1:
+            tgt[b, 0], tgt[b, 1], tgt[b, 2], tgt[b, 3], tgt[b, 4] = 1, 2, 3, 4, 6
+    out = torch.full((B, k + 1), -7, dtype=torch.int64).cuda()
+    path = torch.full((B, k), -7, dtype=torch.int32).cuda()
+    npath = torch.zeros(B, dtype=torch.int32).cuda()
+    counters = torch.zeros(3, dtype=torch.int64).cuda()
+    ops.tree_accept_greedy(tgt.view(-1).cuda(), tok.cuda(), par.cuda(), lens.cuda(), k, out, path, npath,
+                           counters)
+    torch.cuda.synchronize()
+    acc = emit = depth = 0
+    for b in range(B):
+        t, p = trees[b]
+        want_path, want_out = otree.accept_greedy(tgt[b].tolist(), t, p, k)
+        assert npath[b].item() == len(want_path)
+        assert path[b].tolist() == want_path + [-1] * (k - len(want_path))
+        assert out[b].tolist() == want_out + [-1] * (k + 1 - len(want_out))
+        acc += len(want_path)
+        emit += len(want_out)
+        d = [0] * len(t)
+        for r in range(1, len(t)):
+            d[r] = d[p[r]] + 1
+        depth += min(max(d), k)
+    assert counters.tolist() == [acc, emit, depth]
+    assert out[1].tolist() == [1, 2, 3, 4, 6]
+    # prepare: the root token and the rows' rotary positions
+    tok_buf = torch.tensor(rng.integers(0, 99, (B, k + 2)), dtype=torch.int32).cuda()
+    seq_lens = torch.tensor(rng.integers(5, 500, B), dtype=torch.int32).cuda()
+    d_tok, rope = tok.cuda(), torch.zeros(B * q, dtype=torch.int32).cuda()
+    ops.tree_prepare(tok_buf, 1, d_tok, dep.cuda(), seq_lens, -1, rope)
+    torch.cuda.synchronize()
+    assert torch.equal(d_tok[:, 0], tok_buf[:, 1]) and torch.equal(d_tok[:, 1:].cpu(), tok[:, 1:])
+    assert torch.equal(rope.view(B, q).cpu(), (seq_lens.cpu()[:, None] - 1 + dep))
+
+
+@pytest.mark.parametrize("Hkv,D", [(2, 64), (8, 128)])
+def test_kv_compact_moves_the_accepted_rows(Hkv, D):
+    from vllm_omni_draft_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, L, k, pages_per_seq = 3, 2, 4, 6
+    num_pages = B * pages_per_seq + 2
+    bt = torch.randperm(num_pages, generator=g)[:B * pages_per_seq].view(B, pages_per_seq).to(torch.int32)
+    kc = torch.randn(L, num_pages, Hkv, D * 16, generator=g).to(torch.bfloat16)
+    vc = torch.randn(L, num_pages, Hkv, D * 16, generator=g).to(torch.bfloat16)
+    seq_lens = torch.tensor([30, 16, 47], dtype=torch.int32)      # roots at slots 29, 15, 46
+    path = torch.tensor([[2, 5, 9, -1], [1, 2, 3, 4], [-1, -1, -1, -1]], dtype=torch.int32)
+    npath = torch.tensor([3, 4, 0], dtype=torch.int32)
+    n_tok = [int(s) + 12 for s in seq_lens]
+    before = [[unpack_pages(kc[l].view(torch.int16).numpy(), vc[l].view(torch.int16).numpy(), bt[b],
+                            n_tok[b], Hkv, D) for b in range(B)] for l in range(L)]
+    kd, vd = kc.cuda(), vc.cuda()
+    ops.kv_compact(kd, vd, kd[0].numel() * 2, L, bt.cuda(), seq_lens.cuda(), -1, path.cuda(),
+                   npath.cuda(), Hkv, D)
+    torch.cuda.synchronize()
+    for l in range(L):
+        for b in range(B):
+            k_new, v_new = unpack_pages(kd[l].cpu().view(torch.int16).numpy(),
+                                        vd[l].cpu().view(torch.int16).numpy(), bt[b], n_tok[b], Hkv, D)
+            k_old, v_old = before[l][b]
+            want_k, want_v = k_old.copy(), v_old.copy()
+            root = int(seq_lens[b]) - 1
+            for j in range(int(npath[b])):
+                want_k[root + j + 1] = k_old[root + int(path[b, j])]
+                want_v[root + j + 1] = v_old[root + int(path[b, j])]
+            assert np.array_equal(k_new, want_k) and np.array_equal(v_new, want_v)
+
+
+def _chain_logits(model, kv_factory, prefix, chain, max_ctx):
+    """Logits after the last token of prefix + chain, by plain passes over a fresh cache."""
+    kv = kv_factory()
+    toks = torch.tensor(prefix + chain, dtype=torch.int32).cuda()
+    zero = torch.zeros(1, dtype=torch.int32).cuda()
+    n = len(prefix) + len(chain)
+    lg = torch.empty(1, model.cfg.vocab, dtype=torch.float32).cuda()
+    if n > 1:
+        model.forward(kv, toks, 0, 0, zero, 0, 1, n - 1, None, max_ctx)
+    model.forward(kv, toks, 0, n - 1, zero, n - 1, 1, 1, lg, max_ctx)
+    torch.cuda.synchronize()
+    return lg[0].cpu()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_tree_pass_rows_equal_chain_passes(wide):
+    """One tree pass of a model: every row's logits equal (to rounding: the ancestors sit at
+    other cache slots than in a chain, so sums run in another order) the logits of the same
+    root-to-node token path scored as a chain, and the arg-max tokens agree."""
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    oc = MODELS["llama"]
+    w = _product(oc, _bf(random_state(oc, seed=21)))
+    max_ctx = 128
+    model = DecoderModel(w, max_ctx, 128, wide=wide)
+    prefix = [5, 9, 200, 31, 7, 44, 3, 18, 90, 12, 77]
+    cands = [[10, 11, 12], [10, 13], [20, 21, 22], [10, 11, 14]]
+    toks, par, dep = otree.build_tree(cands, 3, 15)
+    q = len(toks)
+    masks = otree.ancestor_masks(par)
+
+    def fresh():
+        kv = PagedKVCache(w.cfg, 16, 1, max_ctx, "cuda")
+        kv.ensure_capacity(0, max_ctx)
+        return kv
+
+    kv = fresh()
+    n = len(prefix)
+    ptoks = torch.tensor(prefix, dtype=torch.int32).cuda()
+    zero = torch.zeros(1, dtype=torch.int32).cuda()
+    model.forward(kv, ptoks, 0, 0, zero, 0, 1, n - 1, None, max_ctx)          # context: tokens 0..n-2
+    tree_tok = torch.tensor([prefix[-1]] + toks[1:], dtype=torch.int32).cuda()
+    rope = torch.tensor([n - 1 + d for d in dep], dtype=torch.int32).cuda()
+    lens = torch.tensor([n], dtype=torch.int32).cuda()
+    lg = torch.empty(q, w.cfg.vocab, dtype=torch.float32).cuda()
+    model.forward(kv, tree_tok, q, 0, lens, -1, 1, q, lg, max_ctx, rope_pos=rope,
+                  tree_mask=_i64(masks).cuda())
+    torch.cuda.synchronize()
+    lg = lg.cpu()
+    for r in range(q):
+        chain, cur = [], r
+        while cur != 0:
+            chain.append(toks[cur])
+            cur = par[cur]
+        ref = _chain_logits(model, fresh, prefix, chain[::-1], max_ctx)
+        scale = ref.abs().max().item()
+        assert (lg[r] - ref).abs().max().item() < 0.02 * scale, r
+        assert lg[r].argmax().item() == ref.argmax().item(), r
+
+
+def _repetitive_prompts(vocab, seed=2):
+    rng = np.random.default_rng(seed)
+    base = [int(t) for t in rng.integers(0, vocab, 12)]
+    alt = base[:6] + [int(t) for t in rng.integers(0, vocab, 6)]
+    return [base + alt + base[:7], alt * 2 + base + alt[:4], [3, 3, 3, 3]]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("rows", ["narrow", "wide"])
+def test_tree_engine_streams_equal_autoregressive(use_graph, rows):
+    """Prompt-lookup trees (several earlier matches merged into one tree per sequence): the
+    emitted streams are the target's autoregressive streams, steps accept at least as many
+    tokens as the single-chain lookup, and after every step the cache holds the accepted path
+    (what the next step's rows attend), which a wrong compaction would break."""
+    oc = MODELS["llama"]
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    prompts = _repetitive_prompts(oc.vocab)
+    n_new = 40
+    ar = [_generate(_engine(tw, None, 0, rows=rows), [p], n_new)[0] for p in prompts]
+
+    def run(eng):
+        outs, steps = [[eng.add_request(i, p)] for i, p in enumerate(prompts)], 0
+        while min(len(o) for o in outs) < n_new:
+            for o, new in zip(outs, eng.step()):
+                o.extend(new)
+            steps += 1
+        return [o[:n_new] for o in outs], steps
+
+    chain = _engine(tw, None, 3, max_batch=3, ngram_max=3, ngram_min=1, use_graph=use_graph, rows=rows)
+    got_chain, steps_chain = run(chain)
+    assert got_chain == ar
+    eng = _engine(tw, None, 3, max_batch=3, ngram_max=3, ngram_min=1, tree_candidates=4,
+                  use_graph=use_graph, rows=rows)
+    assert eng.tree and eng.tree_nodes == 12
+    got, steps = run(eng)
+    assert got == ar
+    m = eng.metrics()
+    # the chain is the tree's first branch: a tree step never accepts less from the same state
+    assert steps <= steps_chain and m["accepted"] > 0 and m["emitted"] - m["accepted"] == 3 * steps
+
+
+def test_external_candidate_sets_are_verified_as_a_tree():
+    """Candidates from outside the engine: per sequence several chains.  With the target's own
+    continuation hidden among wrong candidates every step accepts k tokens."""
+    oc = MODELS["llama"]
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    prompt = [5, 9, 200, 31, 7]
+    ar = _generate(_engine(tw, None, 0), [prompt], 41)[0]
+    eng = _engine(tw, None, 3, external_proposals=True, tree_candidates=3)
+    out = [eng.add_request(0, prompt)]
+    steps = 0
+    while len(out) < 37:
+        nxt = ar[len(out):len(out) + 3]
+        wrong = [(t + 1) % oc.vocab for t in nxt]
+        out += eng.step(proposals=[[wrong, [nxt[0], wrong[1], nxt[2]], nxt]])[0]
+        steps += 1
+    assert out == ar[:len(out)] and len(out) == 1 + 4 * steps
+    m = eng.metrics()
+    assert m["accepted"] == 3 * steps and m["draft"] == 3 * steps
+    # a flat list is one chain; no proposals: one token
+    assert len(eng.step(proposals=[ar[len(out):len(out) + 3]])[0]) == 4
+    assert len(eng.step(proposals=[[]])[0]) == 1
+
+
+def test_tree_mode_refuses_what_it_cannot_do():
+    oc = MODELS["llama"]
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    with pytest.raises(ValueError):
+        _engine(tw, tw, 3, tree_candidates=2)                             # a draft model
+    with pytest.raises(ValueError):
+        _engine(tw, None, 3, ngram_max=2, tree_candidates=2, temperature=0.7)
+    ocfg = OracleConfig(**{**vars(MODELS["opt"])})
+    ow = _product(ocfg, _bf(random_state(ocfg, seed=3)))
+    with pytest.raises(ValueError):
+        _engine(ow, None, 3, ngram_max=2, tree_candidates=2)              # learned positions

@@ -54,7 +54,7 @@ class ForwardArgs(C.Structure):
     _fields_ = [("B", i32), ("q_len", i32), ("token_ids", vp), ("tok_stride", i64),
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
                 ("split_tokens", i32), ("logits", vp), ("wide", i32),
-                ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp)]
+                ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp)]
 
 
 class RopePositions(C.Structure):
@@ -80,8 +80,11 @@ SIGNATURES = {
                                          i32, i32, i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
     "sd_paged_attention_static": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32,
                                         i32, i32, C.c_float, i32, i32, vp]),
-    "sd_paged_attention_static": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, i64, i32, i32, i32,
-                                        i32, i32, C.c_float, i32, i32, vp]),
+    "sd_paged_attention_tree": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, vp, i64, i32, i32, i32,
+                                      i32, i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
+    "sd_tree_prepare": (i32, [vp, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp]),
+    "sd_tree_accept_greedy": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "sd_kv_compact": (i32, [vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "sd_linear": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_linear": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_qkv_rope": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,

@@ -48,6 +48,10 @@ struct AttnArgs {
   int split_tokens, n_splits;
   float* part_o;   // [B, Hkv, n_splits, MT*32, D]
   float* part_ml;  // [B, Hkv, n_splits, MT*32, 2]
+  // Token trees (null: every new token sees all new tokens before it): bit j of
+  // tree_mask[b * q_len + t] says that new token t of sequence b attends new token j (its
+  // ancestors and itself; j <= t).  Keys before the first new token are seen by every row.
+  const unsigned long long* tree_mask;
 };
 
 #ifdef SD_ATTN_STAMPS
@@ -62,7 +66,10 @@ __device__ unsigned long long sd_stamps[16];
 // NBUF == 1 (one 32-row query tile) keeps the kernel within 256 registers, so that two workgroups share a CU and one's
 // prologue and merge overlap the other's stream (large batches); deeper rings run one
 // workgroup per CU.
-template <int D, int MT, int NBUF, int BT_PER_THREAD, bool RELOAD>
+// TREE: the pass scores token trees (AttnArgs::tree_mask); a variant of its own, so that the
+// ordinary kernels carry nothing for it (a run-time test in the shared kernel cost 1.2 us
+// per launch).
+template <int D, int MT, int NBUF, int BT_PER_THREAD, bool RELOAD, bool TREE = false>
 __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_kernel(AttnArgs a) {
   STAMP(0);
   constexpr int KS = D / 16;  // k-steps of the K.Q^T product
@@ -115,6 +122,12 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
       if (valid) v = *reinterpret_cast<const bf16x8*>(qrow + 16 * s + 8 * h);
       qf[mt][s] = v;
     }
+  }
+  unsigned long long anc_m[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 32 + r;
+    anc_m[mt] = TREE && m < m_rows ? a.tree_mask[row0 + m / G] : ~0ull;
   }
   const int pos0 = a.seq_lens[sb] + a.pos_offset + qb * a.q_len;
   const int kv_len = pos0 + q_len;
@@ -203,6 +216,8 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
       const int tile = base + 4 * u;
       const int key0 = tile * 32;
       const bool live = key0 < split_end;  // wave-uniform; dead tiles only keep the ring turning
+      // wave-uniform: a tile that holds new tokens of a token tree takes the ancestor mask too
+      const bool tree_tile = TREE && key0 + 32 > pos0;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         bf16x8 pf[2];
@@ -221,7 +236,9 @@ __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const int key = key0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-            sv[i] = key < kvlen_m[mt] ? s_acc[i] * a.scale_log2 : -INFINITY;
+            bool seen = key < kvlen_m[mt];
+            if (tree_tile) seen = seen && (key < pos0 || ((anc_m[mt] >> ((key - pos0) & 63)) & 1ull));
+            sv[i] = seen ? s_acc[i] * a.scale_log2 : -INFINITY;
             tmax = fmaxf(tmax, sv[i]);
           }
           tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -386,6 +403,33 @@ __global__ __launch_bounds__(D) void attn_merge_kernel(AttnArgs a, int m_pad) {
       (bf16_t)(l > 0.f ? o / l : 0.f);
 }
 
+// Token trees: after acceptance the accepted rows' cache entries move to their chain slots.
+// One thread owns one element of K and of V of a (layer, sequence, KV head) and performs the
+// moves in path order, so a slot is read before a later move overwrites it.
+__global__ __launch_bounds__(128) void kv_compact_kernel(
+    bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, int64_t layer_stride_elems,
+    const int32_t* __restrict__ block_tables, int max_blocks, const int32_t* __restrict__ seq_lens,
+    int pos_offset, const int32_t* __restrict__ path, const int32_t* __restrict__ n_path, int k,
+    int Hkv, int D) {
+  const int b = blockIdx.x, kvh = blockIdx.y, layer = blockIdx.z, d = threadIdx.x;
+  if (d >= D) return;
+  const int n = min(max(n_path[b], 0), k);
+  const int pos0 = seq_lens[b] + pos_offset;
+  const size_t page_elems = (size_t)D * 16;
+  bf16_t* kl = kc + (size_t)layer * layer_stride_elems;
+  bf16_t* vl = vc + (size_t)layer * layer_stride_elems;
+  const int32_t* bt = block_tables + (size_t)b * max_blocks;
+  for (int j = 0; j < n; ++j) {
+    const int src = pos0 + path[(size_t)b * k + j], dst = pos0 + j + 1;
+    if (src == dst) continue;
+    const size_t sp = ((size_t)bt[src >> 4] * Hkv + kvh) * page_elems;
+    const size_t dp = ((size_t)bt[dst >> 4] * Hkv + kvh) * page_elems;
+    const int st = src & 15, dt = dst & 15;
+    kl[dp + ((d >> 3) * 16 + dt) * 8 + (d & 7)] = kl[sp + ((d >> 3) * 16 + st) * 8 + (d & 7)];
+    vl[dp + d * 16 + sd_v_slot(dt)] = vl[sp + d * 16 + sd_v_slot(st)];
+  }
+}
+
 __global__ __launch_bounds__(256) void rope_append_kernel(
     bf16_t* __restrict__ qkv, const float* __restrict__ rope_cs, int max_pos,
     bf16_t* __restrict__ kc, bf16_t* __restrict__ vc, const int32_t* __restrict__ block_tables,
@@ -437,7 +481,7 @@ size_t attn_lds_bytes(int split_tokens) {
   return floats * sizeof(float) + (size_t)(split_tokens / 16 + 8 * NBUF) * sizeof(int32_t);
 }
 
-template <int D, int MT, int NBUF, int BTP, bool RELOAD>
+template <int D, int MT, int NBUF, int BTP, bool RELOAD, bool TREE = false>
 int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
   const size_t lds = attn_lds_bytes<D, MT, NBUF>(a.split_tokens);
   // raise the dynamic-LDS limit once per instantiation and process (host threads may race here)
@@ -445,14 +489,14 @@ int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [] {
     attr_err = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>),
+        reinterpret_cast<const void*>(paged_attn_kernel<D, MT, NBUF, BTP, RELOAD, TREE>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   });
   if (attr_err != hipSuccess) {
     sd_set_error("sd_paged_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     return SD_ERR_HIP;
   }
-  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD>), dim3(a.Hkv, a.n_splits, B), dim3(256),
+  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD, TREE>), dim3(a.Hkv, a.n_splits, B), dim3(256),
                      lds, stream, a);
   SD_CHECK_LAUNCH("sd_paged_attention");
   if (a.n_splits > 1 && a.out) {
@@ -469,6 +513,10 @@ int launch_attn(const AttnArgs& a, int B, hipStream_t stream) {
   constexpr int NBUF = D == 64 ? (MT == 1 ? 4 : 2) : (MT == 1 ? 3 : 1);
   // A split of at most NBUF tiles per wave is loaded whole, with no ring to keep turning.
   const int tiles_per_wave = a.split_tokens / 128;
+  if (a.tree_mask) {  // token trees: the ring variant serves every split size
+    if (a.split_tokens / 16 + 8 * NBUF <= 256) return launch_attn_bt<D, MT, NBUF, 1, true, true>(a, B, stream);
+    return launch_attn_bt<D, MT, NBUF, 4, true, true>(a, B, stream);
+  }
   if (tiles_per_wave == 1) return launch_attn_bt<D, MT, 1, 1, false>(a, B, stream);
   if constexpr (NBUF >= 2) {
     if (tiles_per_wave == 2) return launch_attn_bt<D, MT, 2, 1, false>(a, B, stream);
@@ -527,6 +575,13 @@ extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* k_cach
                                     scale, max_ctx, split_tokens, workspace, workspace_bytes, stream);
 }
 
+static int attention_launch(const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                            const int32_t* block_tables, int max_blocks_per_seq,
+                            const int32_t* seq_lens, int pos_offset, void* out, int64_t ldo, int B,
+                            int q_total, int q_len, int Hq, int Hkv, int D, float scale,
+                            int max_ctx, int split_tokens, void* workspace,
+                            size_t workspace_bytes, const uint64_t* tree_mask, sd_stream_t stream);
+
 extern "C" int sd_paged_attention_blocked(const void* q, int64_t ldq, const void* k_cache,
                                           const void* v_cache, const int32_t* block_tables,
                                           int max_blocks_per_seq, const int32_t* seq_lens,
@@ -535,6 +590,32 @@ extern "C" int sd_paged_attention_blocked(const void* q, int64_t ldq, const void
                                           float scale, int max_ctx, int split_tokens,
                                           void* workspace, size_t workspace_bytes,
                                           sd_stream_t stream) {
+  return attention_launch(q, ldq, k_cache, v_cache, block_tables, max_blocks_per_seq, seq_lens,
+                          pos_offset, out, ldo, B, q_total, q_len, Hq, Hkv, D, scale, max_ctx,
+                          split_tokens, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int sd_paged_attention_tree(const void* q, int64_t ldq, const void* k_cache,
+                                       const void* v_cache, const int32_t* block_tables,
+                                       int max_blocks_per_seq, const int32_t* seq_lens,
+                                       int pos_offset, const uint64_t* tree_mask, void* out,
+                                       int64_t ldo, int B, int q_len, int Hq, int Hkv, int D,
+                                       float scale, int max_ctx, int split_tokens, void* workspace,
+                                       size_t workspace_bytes, sd_stream_t stream) {
+  SD_REQUIRE(tree_mask, SD_ERR_INVALID, "sd_paged_attention_tree: tree_mask is NULL");
+  SD_REQUIRE(q_len >= 1 && q_len <= 64, SD_ERR_UNSUPPORTED,
+             "sd_paged_attention_tree: %d new tokens per sequence outside 1..64", q_len);
+  return attention_launch(q, ldq, k_cache, v_cache, block_tables, max_blocks_per_seq, seq_lens,
+                          pos_offset, out, ldo, B, q_len, q_len, Hq, Hkv, D, scale, max_ctx,
+                          split_tokens, workspace, workspace_bytes, tree_mask, stream);
+}
+
+static int attention_launch(const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                            const int32_t* block_tables, int max_blocks_per_seq,
+                            const int32_t* seq_lens, int pos_offset, void* out, int64_t ldo, int B,
+                            int q_total, int q_len, int Hq, int Hkv, int D, float scale,
+                            int max_ctx, int split_tokens, void* workspace,
+                            size_t workspace_bytes, const uint64_t* tree_mask, sd_stream_t stream) {
   SD_REQUIRE(q_total >= q_len && q_len >= 1, SD_ERR_INVALID,
              "sd_paged_attention_blocked: need 1 <= q_block (%d) <= q_total (%d)", q_len, q_total);
   const int q_blocks = (q_total + q_len - 1) / q_len;
@@ -582,6 +663,7 @@ extern "C" int sd_paged_attention_blocked(const void* q, int64_t ldq, const void
   a.n_splits = n_splits_for(max_ctx, split_tokens);
   a.part_o = nullptr;
   a.part_ml = nullptr;
+  a.tree_mask = (const unsigned long long*)tree_mask;
   SD_REQUIRE(out || a.n_splits > 1, SD_ERR_INVALID,
              "sd_paged_attention: out == NULL (partials only) needs more than one split");
   const int MT = q_len * G <= 32 ? 1 : 2;
@@ -658,6 +740,24 @@ extern "C" int sd_paged_attention_static(const void* q, int64_t ldq, const void*
   return sd_paged_attention_blocked(q, ldq, k_cache, v_cache, block_tables, max_blocks_per_seq,
                                     seq_lens, pos_offset, out, ldo, B, q_len, q_len, Hq, Hkv, D, scale,
                                     max_ctx, split_tokens, ws, SD_STATIC_SCRATCH_BYTES, stream);
+}
+
+extern "C" int sd_kv_compact(void* k_cache, void* v_cache, int64_t layer_stride_bytes, int n_layers,
+                             const int32_t* block_tables, int max_blocks_per_seq,
+                             const int32_t* seq_lens, int pos_offset, const int32_t* path,
+                             const int32_t* n_path, int k, int B, int Hkv, int D,
+                             sd_stream_t stream) {
+  SD_REQUIRE(k_cache && v_cache && block_tables && seq_lens && path && n_path, SD_ERR_INVALID,
+             "sd_kv_compact: null pointer");
+  SD_REQUIRE(B >= 0 && n_layers >= 1 && n_layers <= 65535 && Hkv >= 1 && Hkv <= 65535 && k >= 1 &&
+                 (D == 64 || D == 128) && layer_stride_bytes % 2 == 0,
+             SD_ERR_INVALID, "sd_kv_compact: bad shape (layers=%d Hkv=%d D=%d k=%d)", n_layers, Hkv, D, k);
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(kv_compact_kernel, dim3(B, Hkv, n_layers), dim3(128), 0, (hipStream_t)stream,
+                     (bf16_t*)k_cache, (bf16_t*)v_cache, layer_stride_bytes / 2, block_tables,
+                     max_blocks_per_seq, seq_lens, pos_offset, path, n_path, k, Hkv, D);
+  SD_CHECK_LAUNCH("sd_kv_compact");
+  return SD_OK;
 }
 
 extern "C" int sd_rope_append(void* qkv, const float* rope_cs, int max_pos, void* k_cache,

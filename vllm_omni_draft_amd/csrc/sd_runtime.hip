@@ -220,9 +220,19 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   }
   // multimodal rotary positions, for a model that has sections
   const bool mrope = d.mrope_section_t || d.mrope_section_h;
-  const sd_rope_positions rope_pos{a->rope_pos, a->rope_delta, d.mrope_section_t, d.mrope_section_h};
-  const sd_rope_positions* rpp = mrope && (a->rope_pos || a->rope_delta) ? &rope_pos : nullptr;
-  SD_REQUIRE(mrope || (!a->rope_pos && !a->rope_delta), SD_ERR_INVALID,
+  // A token tree's rows are rotated at their depth, not at their cache slot: explicit
+  // positions, every frequency from the one component.
+  const bool tree = a->tree_mask != nullptr;
+  SD_REQUIRE(!tree || (llama && !mrope && a->rope_pos && !a->input_embeds &&
+                       a->q_len * (Hq / Hkv) <= 64),
+             SD_ERR_UNSUPPORTED,
+             "sd_model_forward: a token tree needs a rotary model without sections, rope_pos, "
+             "token ids and q_len * (Hq/Hkv) <= 64");
+  const sd_rope_positions rope_pos{a->rope_pos, tree ? nullptr : a->rope_delta,
+                                   tree ? D / 2 : d.mrope_section_t, tree ? 0 : d.mrope_section_h};
+  const sd_rope_positions* rpp =
+      tree || (mrope && (a->rope_pos || a->rope_delta)) ? &rope_pos : nullptr;
+  SD_REQUIRE(mrope || tree || (!a->rope_pos && !a->rope_delta), SD_ERR_INVALID,
              "sd_model_forward: rotary positions given to a model without rotary sections");
   for (int li = 0; li < d.n_layers; ++li) {
     const sd_layer_weights& l = m->layers[li];
@@ -244,12 +254,20 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       // (prefill) is attended in blocks of that many tokens by the same launch (their K/V is
       // in the cache already, the causal mask is per row).
       const int q_blk = 64 / (Hq / Hkv);
-      SD_TRY(sd_paged_attention_blocked(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
-                                        kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
-                                        (int64_t)Hq * D, a->B, a->q_len,
-                                        a->q_len < q_blk ? a->q_len : q_blk, Hq, Hkv, D,
-                                        d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
-                                        w.attn_ws_bytes, stream));
+      if (tree) {
+        SD_TRY(sd_paged_attention_tree(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                                       kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
+                                       a->tree_mask, attn, (int64_t)Hq * D, a->B, a->q_len, Hq, Hkv,
+                                       D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
+                                       w.attn_ws_bytes, stream));
+      } else {
+        SD_TRY(sd_paged_attention_blocked(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                                          kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn,
+                                          (int64_t)Hq * D, a->B, a->q_len,
+                                          a->q_len < q_blk ? a->q_len : q_blk, Hq, Hkv, D,
+                                          d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
+                                          w.attn_ws_bytes, stream));
+      }
       SD_TRY(sd_linear_wide(l.o_w, l.o_s, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
                             Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
@@ -281,11 +299,19 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     const int n_splits = (a->max_ctx + a->split_tokens - 1) / a->split_tokens;
     const bool merge_in_proj = n_splits > 1 && n_splits <= 8 && rows * n_splits <= 16 &&
                                sd_fused_norm_fits(rows, Hq * D, false);
-    SD_TRY(sd_paged_attention(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
-                              kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
-                              merge_in_proj ? nullptr : attn, (int64_t)Hq * D, a->B, a->q_len, Hq,
-                              Hkv, D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
-                              w.attn_ws_bytes, stream));
+    if (tree) {
+      SD_TRY(sd_paged_attention_tree(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                                     kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
+                                     a->tree_mask, merge_in_proj ? nullptr : attn, (int64_t)Hq * D,
+                                     a->B, a->q_len, Hq, Hkv, D, d.attn_scale, a->max_ctx,
+                                     a->split_tokens, attn_ws, w.attn_ws_bytes, stream));
+    } else {
+      SD_TRY(sd_paged_attention(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
+                                kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
+                                merge_in_proj ? nullptr : attn, (int64_t)Hq * D, a->B, a->q_len, Hq,
+                                Hkv, D, d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
+                                w.attn_ws_bytes, stream));
+    }
     // Row-parallel projections under tensor parallelism: rank 0 adds the residual and the
     // bias, the others store their partial product, and the sum over ranks lands in h.
     const bool lead = !d.allreduce || d.tp_rank == 0;

@@ -287,6 +287,63 @@ __global__ __launch_bounds__(SD_WAVE) void greedy_verify_kernel(
   }
 }
 
+// ---- token trees ------------------------------------------------------------
+__global__ __launch_bounds__(SD_WAVE) void tree_prepare_kernel(
+    const int32_t* __restrict__ tok_buf, int64_t tok_stride, int tok_col, int32_t* __restrict__ tree_tok,
+    const int32_t* __restrict__ tree_depth, const int32_t* __restrict__ seq_lens, int pos_offset,
+    int32_t* __restrict__ rope_pos, int q_len) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t == 0) tree_tok[(size_t)b * q_len] = tok_buf[(size_t)b * tok_stride + tok_col];
+  if (t < q_len)
+    rope_pos[(size_t)b * q_len + t] = seq_lens[b] + pos_offset + tree_depth[(size_t)b * q_len + t];
+}
+
+// One wave per sequence: the walk is a chain of dependent steps, each step a wave-wide
+// search for the child that carries the target's token.
+__global__ __launch_bounds__(SD_WAVE) void tree_accept_greedy_kernel(
+    const int64_t* __restrict__ target_ids, const int32_t* __restrict__ tree_tok,
+    const int32_t* __restrict__ tree_parent, const int32_t* __restrict__ tree_len, int q_len, int k,
+    int64_t* __restrict__ out_ids, int32_t* __restrict__ path, int32_t* __restrict__ n_path,
+    unsigned long long* __restrict__ counters) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int len = min(max(tree_len[b], 1), q_len);
+  const bool node = lane >= 1 && lane < len;
+  const int my_tok = node ? tree_tok[(size_t)b * q_len + lane] : -1;
+  const int my_par = node ? tree_parent[(size_t)b * q_len + lane] : -1;
+  // depth of the tree (its longest chain): parents come first, so q_len sweeps settle it
+  int depth = 0;
+  for (int sweep = 0; sweep < q_len; ++sweep) {
+    const int pd = __shfl(depth, my_par < 0 ? 0 : my_par, SD_WAVE);
+    const int nd = node ? pd + 1 : 0;
+    if (!__any(nd != depth)) break;
+    depth = nd;
+  }
+  int max_depth = depth;
+  for (int o = 32; o > 0; o >>= 1) max_depth = max(max_depth, __shfl_xor(max_depth, o, SD_WAVE));
+  int cur = 0, j = 0;
+  for (; j < k; ++j) {
+    const int64_t want = target_ids[(size_t)b * q_len + cur];
+    const unsigned long long hit = __ballot(node && my_par == cur && (int64_t)my_tok == want);
+    if (!hit) break;
+    cur = __ffsll((long long)hit) - 1;
+    if (lane == 0) {
+      out_ids[(size_t)b * (k + 1) + j] = want;
+      path[(size_t)b * k + j] = cur;
+    }
+  }
+  if (lane == 0) {
+    out_ids[(size_t)b * (k + 1) + j] = target_ids[(size_t)b * q_len + cur];
+    n_path[b] = j;
+    if (counters) {
+      atomicAdd(&counters[0], (unsigned long long)j);
+      atomicAdd(&counters[1], (unsigned long long)(j + 1));
+      atomicAdd(&counters[2], (unsigned long long)min(max_depth, k));
+    }
+  }
+  if (lane > j && lane <= k) out_ids[(size_t)b * (k + 1) + lane] = -1;
+  if (lane >= j && lane < k) path[(size_t)b * k + lane] = -1;
+}
+
 __global__ __launch_bounds__(kSampleThreads) void argmax_rows_kernel(
     const float* __restrict__ logits, int64_t ld, int64_t* __restrict__ ids, int V) {
   __shared__ float s_f[kSampleWaves];
@@ -949,6 +1006,38 @@ extern "C" int sd_greedy_verify(const int64_t* target_ids, const int64_t* draft_
                      target_ids, draft_ids, proposal_lens, out_ids,
                      (unsigned long long*)counters, k);
   SD_CHECK_LAUNCH("sd_greedy_verify");
+  return SD_OK;
+}
+
+extern "C" int sd_tree_prepare(const int32_t* tok_buf, int64_t tok_stride, int tok_col,
+                               int32_t* tree_tok, const int32_t* tree_depth,
+                               const int32_t* seq_lens, int pos_offset, int32_t* rope_pos, int B,
+                               int q_len, sd_stream_t stream) {
+  SD_REQUIRE(tok_buf && tree_tok && tree_depth && seq_lens && rope_pos, SD_ERR_INVALID,
+             "sd_tree_prepare: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && q_len <= SD_WAVE && tok_col >= 0 && tok_col < tok_stride,
+             SD_ERR_INVALID, "sd_tree_prepare: bad shape (q_len=%d)", q_len);
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(tree_prepare_kernel, dim3(B), dim3(SD_WAVE), 0, (hipStream_t)stream, tok_buf,
+                     tok_stride, tok_col, tree_tok, tree_depth, seq_lens, pos_offset, rope_pos, q_len);
+  SD_CHECK_LAUNCH("sd_tree_prepare");
+  return SD_OK;
+}
+
+extern "C" int sd_tree_accept_greedy(const int64_t* target_ids, const int32_t* tree_tok,
+                                     const int32_t* tree_parent, const int32_t* tree_len,
+                                     int q_len, int k, int64_t* out_ids, int32_t* path,
+                                     int32_t* n_path, int64_t* counters, int B,
+                                     sd_stream_t stream) {
+  SD_REQUIRE(target_ids && tree_tok && tree_parent && tree_len && out_ids && path && n_path,
+             SD_ERR_INVALID, "sd_tree_accept_greedy: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && q_len <= SD_WAVE && k >= 1 && k < SD_WAVE, SD_ERR_INVALID,
+             "sd_tree_accept_greedy: bad shape (q_len=%d k=%d)", q_len, k);
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(tree_accept_greedy_kernel, dim3(B), dim3(SD_WAVE), 0, (hipStream_t)stream,
+                     target_ids, tree_tok, tree_parent, tree_len, q_len, k, out_ids, path, n_path,
+                     (unsigned long long*)counters);
+  SD_CHECK_LAUNCH("sd_tree_accept_greedy");
   return SD_OK;
 }
 

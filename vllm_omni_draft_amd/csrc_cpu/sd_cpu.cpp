@@ -178,6 +178,7 @@ struct Rope {
   int max_blocks;
   const int32_t* seq_lens;
   int pos_offset, q_len, Hq, Hkv, D;
+  const int32_t* rot_pos = nullptr;  // [rows] explicit rotary positions (token trees), or null
 };
 
 // QKV projection (ROTARY tiles) + rotary embedding + cache append; q rows to q_out.
@@ -206,7 +207,8 @@ int qkv_rope_f32(const bf16* W, const float* x, int M, int K, const bf16* bias, 
           lo = rb(lo);
           hi = rb(hi);
           if (head < rp.Hq + rp.Hkv && rp.cs) {
-            const float* cs = rp.cs + (size_t)std::min(pos, rp.max_pos - 1) * D;
+            const int rpos = rp.rot_pos ? std::max(rp.rot_pos[m], 0) : pos;
+            const float* cs = rp.cs + (size_t)std::min(rpos, rp.max_pos - 1) * D;
             const float nlo = lo * cs[i] - hi * cs[half + i], nhi = hi * cs[i] + lo * cs[half + i];
             lo = nlo;
             hi = nhi;
@@ -238,7 +240,8 @@ int qkv_rope_f32(const bf16* W, const float* x, int M, int K, const bf16* bias, 
 // Causal attention of q_len new tokens per sequence over the paged cache.
 void attention_f32(const bf16* q, int64_t ldq, const bf16* kc, const bf16* vc, const int32_t* bt,
                    int max_blocks, const int32_t* seq_lens, int pos_offset, bf16* out, int64_t ldo,
-                   int B, int q_len, int Hq, int Hkv, int D, float scale) {
+                   int B, int q_len, int Hq, int Hkv, int D, float scale,
+                   const uint64_t* tree_mask = nullptr) {
   const int G = Hq / Hkv;
 #pragma omp parallel for collapse(2) schedule(dynamic)
   for (int m = 0; m < B * q_len; ++m)
@@ -253,7 +256,12 @@ void attention_f32(const bf16* q, int64_t ldq, const bf16* kc, const bf16* vc, c
       std::vector<float> qf(D), s(n), acc(D, 0.f);
       for (int d = 0; d < D; ++d) qf[d] = bf2f(q[(size_t)m * ldq + (size_t)h * D + d]);
       float mx = -INFINITY;
+      const int pos0 = n - 1 - t;  // slot of the sequence's first new token
       for (int p = 0; p < n; ++p) {
+        if (tree_mask && p >= pos0 && !((tree_mask[m] >> (p - pos0)) & 1ull)) {
+          s[p] = -INFINITY;  // a new token outside this row's ancestors
+          continue;
+        }
         const bf16* kp = kc + ((size_t)bt[(size_t)b * max_blocks + (p >> 4)] * Hkv + kvh) * D * 16;
         float dot = 0.f;
         for (int d = 0; d < D; ++d) dot += qf[d] * bf2f(kp[((d >> 3) * 16 + (p & 15)) * 8 + (d & 7)]);
@@ -569,6 +577,103 @@ extern "C" int sd_paged_attention_blocked(const void* q, int64_t ldq, const void
                 pos_offset, (bf16*)out, ldo, B, q_total, Hq, Hkv, D, scale);
   return SD_OK;
 }
+extern "C" int sd_paged_attention_tree(const void* q, int64_t ldq, const void* kc, const void* vc,
+                                       const int32_t* bt, int max_blocks, const int32_t* seq_lens,
+                                       int pos_offset, const uint64_t* tree_mask, void* out, int64_t ldo,
+                                       int B, int q_len, int Hq, int Hkv, int D, float scale, int max_ctx,
+                                       int, void*, size_t, sd_stream_t) {
+  REQUIRE(q && kc && vc && bt && seq_lens && out && tree_mask, SD_ERR_INVALID,
+          "sd_paged_attention_tree: null pointer (the CPU build has no partials-only form)");
+  REQUIRE(B >= 0 && q_len >= 1 && q_len <= 64 && Hq >= 1 && Hkv >= 1 && Hq % Hkv == 0 && D % 8 == 0,
+          SD_ERR_INVALID, "sd_paged_attention_tree: bad shape");
+  REQUIRE(max_ctx >= 1 && max_blocks * 16 >= max_ctx, SD_ERR_INVALID,
+          "sd_paged_attention_tree: max_ctx %d exceeds block table (%d pages)", max_ctx, max_blocks);
+  attention_f32((const bf16*)q, ldq, (const bf16*)kc, (const bf16*)vc, bt, max_blocks, seq_lens,
+                pos_offset, (bf16*)out, ldo, B, q_len, Hq, Hkv, D, scale, tree_mask);
+  return SD_OK;
+}
+
+extern "C" int sd_tree_prepare(const int32_t* tok_buf, int64_t tok_stride, int tok_col, int32_t* tree_tok,
+                               const int32_t* tree_depth, const int32_t* seq_lens, int pos_offset,
+                               int32_t* rope_pos, int B, int q_len, sd_stream_t) {
+  REQUIRE(tok_buf && tree_tok && tree_depth && seq_lens && rope_pos && B >= 0 && q_len >= 1 && q_len <= 64 &&
+              tok_col >= 0 && tok_col < tok_stride, SD_ERR_INVALID, "sd_tree_prepare: bad arguments");
+  for (int b = 0; b < B; ++b) {
+    tree_tok[(size_t)b * q_len] = tok_buf[(size_t)b * tok_stride + tok_col];
+    for (int t = 0; t < q_len; ++t)
+      rope_pos[(size_t)b * q_len + t] = seq_lens[b] + pos_offset + tree_depth[(size_t)b * q_len + t];
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_tree_accept_greedy(const int64_t* target_ids, const int32_t* tree_tok,
+                                     const int32_t* tree_parent, const int32_t* tree_len, int q_len, int k,
+                                     int64_t* out_ids, int32_t* path, int32_t* n_path, int64_t* counters,
+                                     int B, sd_stream_t) {
+  REQUIRE(target_ids && tree_tok && tree_parent && tree_len && out_ids && path && n_path && B >= 0 &&
+              q_len >= 1 && q_len <= 64 && k >= 1 && k < 64, SD_ERR_INVALID,
+          "sd_tree_accept_greedy: bad arguments");
+  for (int b = 0; b < B; ++b) {
+    const int len = std::min(std::max(tree_len[b], 1), q_len);
+    const int32_t* tok = tree_tok + (size_t)b * q_len;
+    const int32_t* par = tree_parent + (size_t)b * q_len;
+    int depth[64] = {0}, max_depth = 0;
+    for (int i = 1; i < len; ++i) {
+      depth[i] = depth[std::min(std::max(par[i], 0), i - 1)] + 1;
+      max_depth = std::max(max_depth, depth[i]);
+    }
+    int cur = 0, j = 0;
+    for (; j < k; ++j) {
+      const int64_t want = target_ids[(size_t)b * q_len + cur];
+      int child = -1;
+      for (int i = 1; i < len && child < 0; ++i)
+        if (par[i] == cur && (int64_t)tok[i] == want) child = i;
+      if (child < 0) break;
+      out_ids[(size_t)b * (k + 1) + j] = want;
+      path[(size_t)b * k + j] = child;
+      cur = child;
+    }
+    out_ids[(size_t)b * (k + 1) + j] = target_ids[(size_t)b * q_len + cur];
+    for (int i = j + 1; i <= k; ++i) out_ids[(size_t)b * (k + 1) + i] = -1;
+    for (int i = j; i < k; ++i) path[(size_t)b * k + i] = -1;
+    n_path[b] = j;
+    if (counters) {
+      counters[0] += j;
+      counters[1] += j + 1;
+      counters[2] += std::min(max_depth, k);
+    }
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_kv_compact(void* k_cache, void* v_cache, int64_t layer_stride_bytes, int n_layers,
+                             const int32_t* bt, int max_blocks, const int32_t* seq_lens, int pos_offset,
+                             const int32_t* path, const int32_t* n_path, int k, int B, int Hkv, int D,
+                             sd_stream_t) {
+  REQUIRE(k_cache && v_cache && bt && seq_lens && path && n_path && B >= 0 && n_layers >= 1 && Hkv >= 1 &&
+              k >= 1 && D % 8 == 0, SD_ERR_INVALID, "sd_kv_compact: bad arguments");
+  for (int li = 0; li < n_layers; ++li) {
+    bf16* kc = (bf16*)((char*)k_cache + (size_t)li * layer_stride_bytes);
+    bf16* vc = (bf16*)((char*)v_cache + (size_t)li * layer_stride_bytes);
+    for (int b = 0; b < B; ++b) {
+      const int n = std::min(std::max(n_path[b], 0), k), pos0 = seq_lens[b] + pos_offset;
+      for (int j = 0; j < n; ++j) {
+        const int src = pos0 + path[(size_t)b * k + j], dst = pos0 + j + 1;
+        if (src == dst) continue;
+        for (int h = 0; h < Hkv; ++h) {
+          const size_t sp = ((size_t)bt[(size_t)b * max_blocks + (src >> 4)] * Hkv + h) * D * 16;
+          const size_t dp = ((size_t)bt[(size_t)b * max_blocks + (dst >> 4)] * Hkv + h) * D * 16;
+          for (int d = 0; d < D; ++d) {
+            kc[dp + ((d >> 3) * 16 + (dst & 15)) * 8 + (d & 7)] = kc[sp + ((d >> 3) * 16 + (src & 15)) * 8 + (d & 7)];
+            vc[dp + d * 16 + v_slot(dst & 15)] = vc[sp + d * 16 + v_slot(src & 15)];
+          }
+        }
+      }
+    }
+  }
+  return SD_OK;
+}
+
 extern "C" int sd_paged_attention(const void* q, int64_t ldq, const void* kc, const void* vc,
                                   const int32_t* bt, int max_blocks, const int32_t* seq_lens,
                                   int pos_offset, void* out, int64_t ldo, int B, int q_len, int Hq,
@@ -684,8 +789,9 @@ extern "C" int sd_norm_qkv_rope(const void* W, const float* ws, const void* x, i
                                 const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
                                 int Hkv, int D, int K, const sd_rope_positions* rope_pos, sd_stream_t) {
   REQUIRE(!ws, SD_ERR_UNSUPPORTED, "sd_norm_qkv_rope: fp8 weights are not provided by the CPU build");
-  REQUIRE(!rope_pos || (!rope_pos->pos && !rope_pos->delta), SD_ERR_UNSUPPORTED,
-          "sd_norm_qkv_rope: multimodal rotary positions are not provided by the CPU build");
+  REQUIRE(!rope_pos || (!rope_pos->delta && (!rope_pos->pos || rope_pos->section_t == D / 2)),
+          SD_ERR_UNSUPPORTED,
+          "sd_norm_qkv_rope: multimodal rotary sections are not provided by the CPU build");
   REQUIRE(W && x && q_out && kc && vc && bt && seq_lens && D % 16 == 0 && K % 32 == 0 &&
               ldq >= (int64_t)Hq * D, SD_ERR_INVALID, "sd_norm_qkv_rope: bad arguments");
   const int M = B * q_len;
@@ -693,6 +799,7 @@ extern "C" int sd_norm_qkv_rope(const void* W, const float* ws, const void* x, i
   std::vector<float> xf = rows_f32((const bf16*)x, ldx, M, K);
   if (norm_w) norm_rows(xf, M, K, (const bf16*)norm_w, (const bf16*)norm_b, eps, layer_norm != 0);
   Rope rp{rope_cs, max_pos, (bf16*)kc, (bf16*)vc, bt, max_blocks, seq_lens, pos_offset, q_len, Hq, Hkv, D};
+  if (rope_pos) rp.rot_pos = rope_pos->pos;
   return qkv_rope_f32((const bf16*)W, xf.data(), M, K, (const bf16*)bias, (bf16*)q_out, ldq, rp);
 }
 extern "C" int sd_qkv_rope_wide(const void* W, const float* ws, const void* x, int64_t ldx,
@@ -802,8 +909,11 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const sd_model_desc& d = m->d;
   const int rows = a->B * a->q_len;
   REQUIRE(a->B >= 1 && a->q_len >= 1 && rows <= 4096, SD_ERR_UNSUPPORTED, "sd_model_forward: %d rows", rows);
-  REQUIRE(!a->input_embeds && !a->rope_pos && !a->rope_delta, SD_ERR_UNSUPPORTED,
+  const bool tree = a->tree_mask != nullptr;
+  REQUIRE(!a->input_embeds && !a->rope_delta && (tree || !a->rope_pos), SD_ERR_UNSUPPORTED,
           "sd_model_forward: multimodal inputs are not provided by the CPU build");
+  REQUIRE(!tree || (d.arch == SD_ARCH_LLAMA && a->rope_pos && a->q_len <= 64), SD_ERR_UNSUPPORTED,
+          "sd_model_forward: a token tree needs a rotary model, rope_pos and at most 64 rows per sequence");
   REQUIRE(a->token_ids && a->seq_lens && kv->k_cache && kv->v_cache && kv->block_tables, SD_ERR_INVALID,
           "sd_model_forward: null buffer");
   REQUIRE(workspace_bytes >= sd_model_workspace_bytes(m, rows, 0, 0), SD_ERR_WORKSPACE,
@@ -821,6 +931,7 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   int rc = sd_embed(a->token_ids, a->tok_stride, a->tok_offset, d.embed, d.embed_tiled, d.pos_table,
                     d.pos_bias, a->seq_lens, a->pos_offset, h, a->B, a->q_len, H, d.vocab, st);
   if (rc) return rc;
+  const sd_rope_positions tree_pos{a->rope_pos, nullptr, D / 2, 0};
   for (int li = 0; li < d.n_layers; ++li) {
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
@@ -828,11 +939,11 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     rc = sd_norm_qkv_rope(l.qkv_w, nullptr, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama, l.qkv_b,
                           q, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos, kc, vc,
                           kv->block_tables, kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B,
-                          a->q_len, Hq, Hkv, D, H, nullptr, st);
+                          a->q_len, Hq, Hkv, D, H, tree ? &tree_pos : nullptr, st);
     if (rc) return rc;
     attention_f32(q, (int64_t)Hq * D, (const bf16*)kc, (const bf16*)vc, kv->block_tables,
                   kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, attn, (int64_t)Hq * D, a->B,
-                  a->q_len, Hq, Hkv, D, d.attn_scale);
+                  a->q_len, Hq, Hkv, D, d.attn_scale, a->tree_mask);
     rc = sd_linear(l.o_w, nullptr, attn, (int64_t)Hq * D, l.o_b, h, h, H, rows, H, Hq * D, SD_EPI_RESIDUAL, st);
     if (rc) return rc;
     rc = sd_norm_linear(l.up_w, nullptr, h, H, l.mlp_norm_w, l.mlp_norm_b, d.norm_eps, !llama, l.up_b, act,

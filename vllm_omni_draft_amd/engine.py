@@ -78,6 +78,13 @@ class EngineConfig:
     acceptance_method: str = "rejection_sampler"
     posterior_threshold: float = 0.09
     posterior_alpha: float = 0.3
+    # Multi-candidate verification (greedy, host-made proposals only: prompt lookup or external).
+    # Up to tree_candidates continuations per sequence are merged into a token tree of at most
+    # tree_nodes nodes (0: tree_candidates * k, capped by 64 / (Hq/Hkv) - 1) and scored by ONE
+    # verify pass; the longest root path that matches the target's own tokens is accepted.  1 =
+    # a single chain of k proposals.
+    tree_candidates: int = 1
+    tree_nodes: int = 0
 
 
 def acceptance_pattern(accept_prob: float, k: int, length: int = 16, rotate: int = 0) -> List[int]:
@@ -134,10 +141,26 @@ class SpecEngine:
         dev = target.embed.device
         self.device = dev
         B, k = cfg.max_batch, cfg.k
-        self.max_ctx = cfg.max_seq_len + k + 2
+        self.tree = cfg.tree_candidates > 1
+        self.tree_nodes = 0
+        if self.tree:
+            if not self.host_props:
+                raise ValueError("tree_candidates > 1 needs host-made proposals (prompt lookup or "
+                                 "external_proposals) and no draft model")
+            if cfg.temperature > 0.0:
+                raise ValueError("token trees are verified greedily (temperature 0)")
+            if target.cfg.arch != "llama" or target.cfg.mrope_section:
+                raise ValueError("token trees need a rotary target without mrope_section")
+            cap = min(64 // (target.cfg.n_heads // target.cfg.n_kv_heads) - 1, 63)
+            self.tree_nodes = min(cfg.tree_nodes or cfg.tree_candidates * k, cap)
+            if self.tree_nodes < k:
+                raise ValueError(f"a tree of {self.tree_nodes} nodes cannot hold a chain of k={k}")
+        q_max = max(k, self.tree_nodes) + 1           # rows of a verify pass per sequence
+        self._slack = q_max + 1                       # cache slots a step may write past the last token
+        self.max_ctx = cfg.max_seq_len + self._slack
         if cfg.rows not in ("auto", "narrow", "wide"):
             raise ValueError("rows must be 'auto', 'narrow' or 'wide'")
-        self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * (k + 1) > MAX_ROWS)
+        self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * q_max > MAX_ROWS)
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
                                    wide=self.wide)
         if cfg.draft_rows not in ("auto", "same", "narrow", "wide"):
@@ -185,14 +208,29 @@ class SpecEngine:
         self.zero_lens = torch.zeros(B, **i32)
         self.prompt_buf = torch.zeros(max(cfg.max_seq_len, 8), **i32)
         self._prompt_rows: Optional[torch.Tensor] = None   # [max_batch, max_seq_len], batched prefill
-        self.t_logits = torch.empty(max(MAX_ROWS, B * (k + 1)), self.V,
+        self.t_logits = torch.empty(max(MAX_ROWS, B * q_max), self.V,
                                     dtype=torch.float32, device=dev)
         self.d_logits = torch.empty(max(MAX_ROWS, 2 * B), self.V, dtype=torch.float32, device=dev)
         self.ids_tmp = torch.zeros(max(B, 1), dtype=torch.int64, device=dev)
         self.target_ids = torch.zeros(B, k + 1, dtype=torch.int64, device=dev)
         self.draft_ids = torch.zeros(B, max(k, 1), dtype=torch.int64, device=dev)
         self.out_ids = torch.full((B, k + 1), -1, dtype=torch.int64, device=dev)
-        n_rows = max(MAX_ROWS, B * (k + 1))
+        n_rows = max(MAX_ROWS, B * q_max)
+        if self.tree:
+            q = self.tree_nodes + 1
+            self.tree_tok = torch.zeros(B, q, **i32)        # row 0: the root (last emitted token)
+            self.tree_parent = torch.zeros(B, q, **i32)
+            self.tree_depth = torch.zeros(B, q, **i32)
+            self.tree_len = torch.ones(B, **i32)
+            self.tree_mask = torch.zeros(B, q, dtype=torch.int64, device=dev)
+            self.tree_rope = torch.zeros(B * q, **i32)
+            self.tree_ids = torch.zeros(B * q, dtype=torch.int64, device=dev)
+            self.tree_path = torch.zeros(B, k, **i32)
+            self.tree_npath = torch.zeros(B, **i32)
+            self._tree_host = {name: _rt.pin(torch.zeros(B, q, dtype=torch.int32))
+                               for name in ("tok", "parent", "depth")}
+            self._tree_host["mask"] = _rt.pin(torch.zeros(B, q, dtype=torch.int64))
+            self._tree_host["len"] = _rt.pin(torch.ones(B, dtype=torch.int32))
         self.part_val = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
         self.part_idx = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.int32, device=dev)
         # Vocabulary-parallel target head (tensor parallelism): a pass leaves this rank's
@@ -335,9 +373,9 @@ class SpecEngine:
             raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
         if slot != self.active:
             raise ValueError("slots must be filled in order (slot == number of active sequences)")
-        self.t_kv.ensure_capacity(slot, n + self.k + 2)
+        self.t_kv.ensure_capacity(slot, n + self._slack)
         if self.d_kv is not None:
-            self.d_kv.ensure_capacity(slot, n + self.k + 2)
+            self.d_kv.ensure_capacity(slot, n + self._slack)
         self.prompt_buf[:n].copy_(torch.tensor(list(prompt), dtype=torch.int32))
         delta = 0
         if rope_positions is not None:
@@ -352,7 +390,7 @@ class SpecEngine:
                 raise ValueError(f"input_embeds must be [{n}, {self.target.cfg.hidden}]")
             input_embeds = input_embeds.to(device=self.device, dtype=torch.bfloat16)
         self.rope_delta[slot] = delta
-        self._ctx = self._ctx_bucket(n + self.k + 2)
+        self._ctx = self._ctx_bucket(n + self._slack)
         zl = self.zero_lens[slot:slot + 1]
         for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
             if model is None:
@@ -443,11 +481,11 @@ class SpecEngine:
         lens_dev = torch.tensor(lens, dtype=torch.int32).to(self.device)
         for i in range(Bp):
             # padding rows write up to n_max - 2 in every sequence's cache
-            self.t_kv.ensure_capacity(slot0 + i, n_max + self.k + 2)
+            self.t_kv.ensure_capacity(slot0 + i, n_max + self._slack)
             if self.d_kv is not None:
-                self.d_kv.ensure_capacity(slot0 + i, n_max + self.k + 2)
+                self.d_kv.ensure_capacity(slot0 + i, n_max + self._slack)
         self.rope_delta[slot0:slot0 + Bp] = 0
-        self._ctx = self._ctx_bucket(n_max + self.k + 2)
+        self._ctx = self._ctx_bucket(n_max + self._slack)
         zl = self.zero_lens[slot0:slot0 + Bp]
         toks = self._prompt_rows.view(-1)
         for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
@@ -488,9 +526,10 @@ class SpecEngine:
 
     # ------------------------------------------------------------------ passes
     def _forward(self, model: DecoderModel, kv: PagedKVCache, tokens, tok_stride, tok_offset,
-                 seq_lens, pos_offset, B, q_len, logits, slot0: int = 0) -> None:
+                 seq_lens, pos_offset, B, q_len, logits, slot0: int = 0, tree=None) -> None:
         """One model pass over B sequences x q_len tokens, in sub-batches of at
-        most max_rows token rows."""
+        most max_rows token rows.  tree: (ancestor masks, rotary positions), each with one entry
+        per token row, for a pass over token trees."""
         per = max(1, model.max_rows // q_len)
         starts = list(range(0, B, per))
         lanes = len(starts) > 1 and model is self.draft and bool(self._lanes)
@@ -511,11 +550,14 @@ class SpecEngine:
             if lane and lane not in used:
                 stream.wait_event(fork)
                 used.add(lane)
+            extra = {}
+            if tree is not None:
+                extra = dict(tree_mask=tree[0].view(-1)[b0 * q_len:], rope_pos=tree[1][b0 * q_len:])
             with _rt.stream_ctx(stream if lanes else None):
                 model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens,
                               tok_stride, tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits,
                               self._ctx, rope_delta=delta,
-                              workspace=self._lane_ws[lane] if lanes else None)
+                              workspace=self._lane_ws[lane] if lanes else None, **extra)
         for lane in sorted(used):          # join: the step goes on when every lane is done
             done = torch.cuda.Event()
             done.record(self._lanes[lane - 1])
@@ -531,12 +573,35 @@ class SpecEngine:
         if self._spec_disabled():
             self._enqueue_no_spec_step()
             return
+        if self.tree:
+            self._enqueue_tree_step()
+            return
         if self.host_props:
             self._enqueue_lookup_proposals()
         else:
             self._enqueue_propose(fused)
         self._enqueue_score(fused)
         self._enqueue_accept(fused)
+
+    def _enqueue_tree_step(self) -> None:
+        """Multi-candidate step: one target pass over every sequence's token tree (uploaded by
+        _prepare_step), the greedy walk down the tree, the accepted rows' cache entries moved
+        to their chain slots, the state update."""
+        B, k, q = self.active, self.k, self.tree_nodes + 1
+        ops.tree_prepare(self.tok_buf[:B], 1, self.tree_tok[:B], self.tree_depth[:B],
+                         self.seq_lens[:B], -1, self.tree_rope)
+        self._forward(self.target, self.t_kv, self.tree_tok, q, 0, self.seq_lens, -1, B, q,
+                      self.t_out, tree=(self.tree_mask, self.tree_rope))
+        self._target_argmax(B * q, self.tree_ids[:B * q])
+        ops.tree_accept_greedy(self.tree_ids, self.tree_tok[:B], self.tree_parent[:B],
+                               self.tree_len[:B], k, self.out_ids[:B], self.tree_path[:B],
+                               self.tree_npath[:B], self.counters)
+        kv, c = self.t_kv, self.target.cfg
+        ops.kv_compact(kv.k, kv.v, kv.layer_stride_bytes, c.n_layers, kv.block_tables[:B],
+                       self.seq_lens[:B], -1, self.tree_path[:B], self.tree_npath[:B],
+                       c.n_kv_heads, c.head_dim)
+        ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
+                          self.gen_tokens[:B], self.gen_counts[:B], k, self._records[self._parity, :B])
 
     # -- the target's logits after a pass of n rows (whole, or one vocabulary slice per rank)
     def _target_partials(self, n: int) -> None:
@@ -680,6 +745,67 @@ class SpecEngine:
                     return arr[e + 1:e + 1 + k].tolist()
         return []
 
+    def _lookup_candidates(self, hist: List[int]) -> List[List[int]]:
+        """Up to tree_candidates distinct continuations: the tokens after earlier occurrences of
+        the sequence's last n tokens, longest n first, most recent match first (the first
+        candidate is _lookup's chain)."""
+        import numpy as np
+        k, arr = self.k, np.asarray(hist, dtype=np.int64)
+        n_hist, out = arr.size, []
+        if n_hist < 2:
+            return out
+        ends = np.nonzero(arr[:-1] == arr[-1])[0][::-1]
+        for n in range(min(self.cfg.ngram_max, n_hist - 1), self.cfg.ngram_min - 1, -1):
+            pat = arr[n_hist - n:]
+            for e in ends:
+                if e + 1 >= n and np.array_equal(arr[e + 1 - n:e + 1], pat):
+                    cont = arr[e + 1:e + 1 + k].tolist()
+                    if cont and cont not in out:
+                        out.append(cont)
+                        if len(out) >= self.cfg.tree_candidates:
+                            return out
+        return out
+
+    def _upload_trees(self, candidates: List[List[List[int]]]) -> None:
+        """Merges every sequence's candidate chains into a token tree (rows in insertion order:
+        a node's parent always has a smaller row) and uploads tokens, parents, depths and
+        ancestor masks.  Unused rows are leaves under the root that the walk never looks at."""
+        N, k, h = self.tree_nodes, self.k, self._tree_host
+        for b, cands in enumerate(candidates):
+            toks, parents, depths, masks = [0], [0], [0], [1]
+            child = {}
+            for chain in cands:
+                cur = 0
+                for d, tok in enumerate(chain[:k]):
+                    row = child.get((cur, tok))
+                    if row is None:
+                        if len(toks) > N:
+                            break
+                        row = len(toks)
+                        child[(cur, tok)] = row
+                        toks.append(int(tok))
+                        parents.append(cur)
+                        depths.append(d + 1)
+                        masks.append(masks[cur] | (1 << row))
+                    cur = row
+            h["len"][b] = len(toks)
+            for t in range(len(toks), N + 1):
+                toks.append(0)
+                parents.append(0)
+                depths.append(1)
+                masks.append(1 | (1 << t))
+            h["tok"][b] = torch.tensor(toks, dtype=torch.int32)
+            h["parent"][b] = torch.tensor(parents, dtype=torch.int32)
+            h["depth"][b] = torch.tensor(depths, dtype=torch.int32)
+            h["mask"][b] = torch.tensor([m - (1 << 64) if m >= (1 << 63) else m for m in masks],
+                                        dtype=torch.int64)
+        # column 0 of tree_tok (the root token) is written on the device by sd_tree_prepare
+        self.tree_tok[:, 1:].copy_(h["tok"][:, 1:], non_blocking=True)
+        self.tree_parent.copy_(h["parent"], non_blocking=True)
+        self.tree_depth.copy_(h["depth"], non_blocking=True)
+        self.tree_mask.copy_(h["mask"], non_blocking=True)
+        self.tree_len.copy_(h["len"], non_blocking=True)
+
     def _enqueue_score(self, fused: bool = False) -> None:
         """One target pass over {last token, k proposals} of every sequence:
         t_logits [B*(k+1), V], plus target_ids (greedy) or t_probs / bonus_ids."""
@@ -766,10 +892,16 @@ class SpecEngine:
         if proposals is not None:
             if len(proposals) != self.active:
                 raise ValueError(f"{len(proposals)} proposal lists for {self.active} sequences")
-            proposals = [[] if p is None else [int(t) for t in p] for p in proposals]
-            for p in proposals:
-                if any(t < 0 or t >= self.V for t in p):
-                    raise ValueError("proposed token outside the vocabulary")
+            if self.tree:   # per sequence: several candidate chains (or one flat chain)
+                proposals = [[] if not p else
+                             ([[int(t) for t in c] for c in p] if isinstance(p[0], (list, tuple))
+                              else [[int(t) for t in p]]) for p in proposals]
+                flat = [t for p in proposals for c in p for t in c]
+            else:
+                proposals = [[] if p is None else [int(t) for t in p] for p in proposals]
+                flat = [t for p in proposals for t in p]
+            if any(t < 0 or t >= self.V for t in flat):
+                raise ValueError("proposed token outside the vocabulary")
         self._pending_props = proposals
 
     def step(self, sync: bool = True,
@@ -794,7 +926,7 @@ class SpecEngine:
     def _prepare_step(self) -> None:
         B, k = self.active, self.k
         for b in range(B):
-            need = self.host_lens[b] + k + 2
+            need = self.host_lens[b] + self._slack
             if need > self.max_ctx:
                 raise RuntimeError(f"sequence {b} would exceed max_seq_len")
             # pages are taken a few at a time, so most steps upload no block-table entries
@@ -807,7 +939,17 @@ class SpecEngine:
         # contexts on the single-split path (no partials, no merge kernel).  The split
         # boundaries stay at fixed absolute positions, so results do not depend on the bound.
         self._ctx = self._ctx_bucket()
-        if self.host_props:
+        if self.tree:
+            pending, self._pending_props = self._pending_props, None
+            cands = []
+            for b in range(B):
+                if self.ngram:
+                    cands.append(self._lookup_candidates(self.history[b]))
+                else:
+                    cands.append(pending[b] if pending is not None else [])
+            cands += [[] for _ in range(self.cfg.max_batch - B)]
+            self._upload_trees(cands)
+        elif self.host_props:
             pending, self._pending_props = self._pending_props, None
             for b in range(B):
                 if self.ngram:
@@ -840,6 +982,7 @@ class SpecEngine:
         lib = _lib.load()
         if self.cfg.use_graph and _rt.on_gpu():   # (the CPU build has no stream capture)
             key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity)
+            # (a tree step has one shape too: every sequence's tree is padded to tree_nodes rows)
             g = self._graphs.get(key)
             if g is None:
                 self._enqueue_step()          # eager warm-up step (also a real step)
@@ -908,7 +1051,7 @@ class SpecEngine:
 
     def _ctx_bucket(self, need: Optional[int] = None) -> int:
         if need is None:
-            need = max(self.host_lens[:max(self.active, 1)]) + self.k + 2
+            need = max(self.host_lens[:max(self.active, 1)]) + self._slack
         bound = self.cfg.split_tokens
         while bound < need:
             bound *= 2

@@ -93,7 +93,8 @@ class DecoderModel:
                 wide: Optional[bool] = None, input_embeds: Optional[torch.Tensor] = None,
                 rope_pos: Optional[torch.Tensor] = None,
                 rope_delta: Optional[torch.Tensor] = None,
-                workspace: Optional[torch.Tensor] = None) -> None:
+                workspace: Optional[torch.Tensor] = None,
+                tree_mask: Optional[torch.Tensor] = None) -> None:
         """Enqueues one pass over B*q_len token rows on the current stream.
         Token t of sequence b is token_ids[b*tok_stride + tok_offset + t] at
         position seq_lens[b] + pos_offset + t.  `logits` ([B*q_len, vocab] f32)
@@ -101,7 +102,10 @@ class DecoderModel:
         [B*q_len, hidden]) replace the embedding lookup; a model with mrope_section takes
         its rotary positions from rope_pos (int32 [3, B*q_len]) or, for text after an image,
         from the cache position + rope_delta[b] (int32 [B]).  workspace: another buffer of
-        the size of self.workspace, for passes that run concurrently on several streams."""
+        the size of self.workspace, for passes that run concurrently on several streams.
+        Token trees: tree_mask (int64 [B*q_len], bit j of entry b*q_len+t: row t attends new
+        row j) with rope_pos = the rows' rotary positions (int32 [B*q_len]); rotary models
+        without mrope_section only."""
         ws = self.workspace if workspace is None else workspace
         if ws.numel() < self.workspace.numel() or ws.dtype != torch.uint8:
             raise _lib.SdError("workspace must be a uint8 tensor of at least self.workspace's size")
@@ -110,12 +114,20 @@ class DecoderModel:
                                          or not input_embeds.is_contiguous()
                                          or tuple(input_embeds.shape) != (rows, self.cfg.hidden)):
             raise _lib.SdError("input_embeds must be a contiguous bfloat16 [B*q_len, hidden] tensor")
-        if rope_pos is not None and (rope_pos.dtype != torch.int32 or not rope_pos.is_contiguous()
-                                     or tuple(rope_pos.shape) != (3, rows)):
+        if tree_mask is not None:
+            if (tree_mask.dtype != torch.int64 or not tree_mask.is_contiguous()
+                    or tree_mask.numel() < rows):
+                raise _lib.SdError("tree_mask must be a contiguous int64 tensor of B*q_len entries")
+            if (rope_pos is None or rope_pos.dtype != torch.int32 or not rope_pos.is_contiguous()
+                    or rope_pos.numel() < rows or self.cfg.mrope_section or self.cfg.arch != "llama"):
+                raise _lib.SdError("a token tree needs int32 rope_pos [B*q_len] and a rotary model "
+                                   "without mrope_section")
+        elif rope_pos is not None and (rope_pos.dtype != torch.int32 or not rope_pos.is_contiguous()
+                                       or tuple(rope_pos.shape) != (3, rows)):
             raise _lib.SdError("rope_pos must be a contiguous int32 [3, B*q_len] tensor")
         if rope_delta is not None and (rope_delta.dtype != torch.int32 or rope_delta.numel() < B):
             raise _lib.SdError("rope_delta must be an int32 tensor of at least B entries")
-        if (rope_pos is not None or rope_delta is not None) and not self.cfg.mrope_section:
+        if ((rope_pos is not None and tree_mask is None) or rope_delta is not None) and not self.cfg.mrope_section:
             raise _lib.SdError("rotary positions given to a model without mrope_section")
         if token_ids.dtype != torch.int32 or seq_lens.dtype != torch.int32:
             raise _lib.SdError("token_ids and seq_lens must be int32 device tensors")
@@ -132,7 +144,7 @@ class DecoderModel:
                                 max_ctx=max_ctx or self.max_ctx, split_tokens=self.split_tokens,
                                 logits=_ptr(logits), wide=int(self.wide if wide is None else wide),
                                 input_embeds=_ptr(input_embeds), rope_pos=_ptr(rope_pos),
-                                rope_delta=_ptr(rope_delta))
+                                rope_delta=_ptr(rope_delta), tree_mask=_ptr(tree_mask))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
                                           ops._stream())

@@ -262,6 +262,74 @@ def paged_attention_static(q, k_cache, v_cache, block_tables, seq_lens, pos_offs
     return out
 
 
+def paged_attention_tree(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, tree_mask, B, q_len,
+                         Hq, Hkv, D, scale, max_ctx, split_tokens=256, workspace=None) -> torch.Tensor:
+    """paged_attention over a token tree: tree_mask [B*q_len] int64 (bit j of entry b*q_len+t:
+    new token t attends new token j)."""
+    _need(q, torch.bfloat16, "q")
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    _need(tree_mask, torch.int64, "tree_mask")
+    if tree_mask.numel() < B * q_len:
+        raise _lib.SdError("paged_attention_tree: tree_mask needs B*q_len entries")
+    out = torch.empty(B * q_len, Hq * D, dtype=torch.bfloat16, device=q.device)
+    need = paged_attention_workspace_bytes(B, q_len, Hq, D, max_ctx, split_tokens)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=q.device)
+    _lib.check(_lib.load().sd_paged_attention_tree(
+        _p(q), q.shape[-1], _p(k_cache), _p(v_cache), _p(block_tables), block_tables.shape[1],
+        _p(seq_lens), pos_offset, _p(tree_mask), _p(out), Hq * D, B, q_len, Hq, Hkv, D, float(scale),
+        max_ctx, split_tokens, _p(workspace), workspace.numel(), _stream()),
+        "sd_paged_attention_tree")
+    return out
+
+
+def tree_prepare(tok_buf, tok_col, tree_tok, tree_depth, seq_lens, pos_offset, rope_pos) -> None:
+    """tree_tok[:, 0] = tok_buf[:, tok_col]; rope_pos[b, t] = seq_lens[b] + pos_offset + depth[b, t]."""
+    for t, n in ((tok_buf, "tok_buf"), (tree_tok, "tree_tok"), (tree_depth, "tree_depth"),
+                 (seq_lens, "seq_lens"), (rope_pos, "rope_pos")):
+        _need(t, torch.int32, n)
+    B, q_len = tree_tok.shape
+    if tuple(tree_depth.shape) != (B, q_len) or rope_pos.numel() < B * q_len or tok_buf.shape[0] < B:
+        raise _lib.SdError("tree_prepare: inconsistent shapes")
+    _lib.check(_lib.load().sd_tree_prepare(_p(tok_buf), tok_buf.shape[1], tok_col, _p(tree_tok),
+                                           _p(tree_depth), _p(seq_lens), pos_offset, _p(rope_pos), B,
+                                           q_len, _stream()), "sd_tree_prepare")
+
+
+def tree_accept_greedy(target_ids, tree_tok, tree_parent, tree_len, k, out_ids, path, n_path,
+                       counters=None) -> None:
+    """Greedy acceptance walk over a token tree (see sd_tree_accept_greedy)."""
+    _need(target_ids, torch.int64, "target_ids")
+    for t, n in ((tree_tok, "tree_tok"), (tree_parent, "tree_parent"), (tree_len, "tree_len"),
+                 (path, "path"), (n_path, "n_path")):
+        _need(t, torch.int32, n)
+    _need(out_ids, torch.int64, "out_ids")
+    B, q_len = tree_tok.shape
+    if (target_ids.numel() < B * q_len or tuple(tree_parent.shape) != (B, q_len)
+            or tuple(out_ids.shape) != (B, k + 1) or tuple(path.shape) != (B, k)
+            or tree_len.numel() < B or n_path.numel() < B):
+        raise _lib.SdError("tree_accept_greedy: inconsistent shapes")
+    _lib.check(_lib.load().sd_tree_accept_greedy(_p(target_ids), _p(tree_tok), _p(tree_parent),
+                                                 _p(tree_len), q_len, k, _p(out_ids), _p(path),
+                                                 _p(n_path), _p(counters), B, _stream()),
+               "sd_tree_accept_greedy")
+
+
+def kv_compact(k_cache, v_cache, layer_stride_bytes, n_layers, block_tables, seq_lens, pos_offset,
+               path, n_path, Hkv, D) -> None:
+    """Moves the accepted tree rows' K/V to their chain slots (see sd_kv_compact)."""
+    _need(block_tables, torch.int32, "block_tables")
+    _need(seq_lens, torch.int32, "seq_lens")
+    _need(path, torch.int32, "path")
+    _need(n_path, torch.int32, "n_path")
+    B, k = path.shape
+    _lib.check(_lib.load().sd_kv_compact(_p(k_cache), _p(v_cache), layer_stride_bytes, n_layers,
+                                         _p(block_tables), block_tables.shape[1], _p(seq_lens),
+                                         pos_offset, _p(path), _p(n_path), k, B, Hkv, D, _stream()),
+               "sd_kv_compact")
+
+
 def paged_attention_blocked(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_total,
                             q_block, Hq, Hkv, D, scale, max_ctx, split_tokens=256,
                             workspace=None) -> torch.Tensor:

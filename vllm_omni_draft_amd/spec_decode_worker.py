@@ -398,6 +398,11 @@ class SpecDecodeConfig:
     # (ExecuteModelRequest.external_proposals / scheduled_spec_decode_tokens) or from the
     # `proposer` object given to the worker; the engine only verifies
     external_proposals: bool = False
+    # multi-candidate verification of host-made proposals (prompt lookup / external): up to
+    # this many continuations per sequence are merged into a token tree and scored by one
+    # verify pass (greedy only); see EngineConfig.tree_candidates
+    speculative_tree_candidates: int = 1
+    speculative_tree_nodes: int = 0
     max_num_seqs: int = 1
     max_model_len: int = 2048
     temperature: float = 0.0
@@ -525,6 +530,7 @@ class SpecDecodeWorker:
             draft_rows=c.draft_rows,
             ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
             external_proposals=c.external_proposals,
+            tree_candidates=c.speculative_tree_candidates, tree_nodes=c.speculative_tree_nodes,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
             acceptance_method=c.spec_decoding_acceptance_method,
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
