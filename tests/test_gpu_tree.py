@@ -60,6 +60,43 @@ def test_tree_attention_matches_oracle(Hq, Hkv, D, ctx_lens, split, parents):
         assert torch.equal(plain.float().cpu().view(B, q_len, Hq, D), out)
 
 
+@pytest.mark.parametrize("Hq,Hkv,D", [(32, 8, 128), (4, 2, 64)])
+@pytest.mark.parametrize("root", [5, 20, 29, 40, 250, 1044, 1050])
+def test_tree_rows_equal_the_same_rows_laid_out_as_a_chain(Hq, Hkv, D, root):
+    """Every root-to-leaf chain of a 15-node tree, with the new tokens crossing tile, page and
+    split boundaries and (4 heads per KV head) two query tiles: a row of the tree pass equals,
+    to two bf16 steps, the row of the plain kernel over a cache that holds the chain contiguously
+    (only the summation order may differ).  With short contexts a single wrongly seen or missed
+    key would be ten times that."""
+    from vllm_omni_draft_amd import ops
+    from tests.gpu_util import pack_cache_fast
+    par = [0, 0, 1, 2, 3, 4, 0, 6, 7, 8, 9, 0, 11, 12, 13, 14]
+    masks, q_len, split = otree.ancestor_masks(par), 16, 256
+    g = torch.Generator().manual_seed(root)
+    n, pages = root + q_len, 2048 // 16
+    bt = torch.randperm(pages, generator=g).to(torch.int32).view(1, -1)
+    k = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16)
+    q = torch.randn(q_len, Hq, D, generator=g).to(torch.bfloat16)
+    kc = torch.zeros(pages, Hkv, D * 16, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    pack_cache_fast(kc, vc, k, v, bt[0])
+    sl = torch.tensor([root], dtype=torch.int32).cuda()
+    out = ops.paged_attention_tree(q.reshape(q_len, Hq * D).cuda(), kc.cuda(), vc.cuda(), bt.cuda(), sl, 0,
+                                   _i64(masks).cuda(), 1, q_len, Hq, Hkv, D, D ** -0.5, 2048, split)
+    out = out.cpu().view(q_len, Hq, D).float()
+    for chain in ([1, 2, 3, 4, 5], [6, 7, 8, 9, 10], [11, 12, 13, 14, 15]):
+        rows = [0] + chain
+        k2, v2 = k.clone(), v.clone()
+        for d, r in enumerate(rows):
+            k2[root + d], v2[root + d] = k[root + r], v[root + r]
+        kc2, vc2 = torch.zeros_like(kc), torch.zeros_like(vc)
+        pack_cache_fast(kc2, vc2, k2, v2, bt[0])
+        ref = ops.paged_attention(q[rows].reshape(6, Hq * D).cuda(), kc2.cuda(), vc2.cuda(), bt.cuda(), sl, 0,
+                                  1, 6, Hq, Hkv, D, D ** -0.5, 2048, split).cpu().view(6, Hq, D).float()
+        torch.testing.assert_close(out[rows], ref, rtol=2 ** -7, atol=2 ** -9)
+
+
 def test_tree_attention_rejects_bad_arguments():
     from vllm_omni_draft_amd import _lib, ops
     kc, vc, bt, ks, vs, qs = _setup(1, [20], 4, 4, 2, 64, seed=1)

@@ -218,19 +218,23 @@ class SpecEngine:
         n_rows = max(MAX_ROWS, B * q_max)
         if self.tree:
             q = self.tree_nodes + 1
-            self.tree_tok = torch.zeros(B, q, **i32)        # row 0: the root (last emitted token)
-            self.tree_parent = torch.zeros(B, q, **i32)
-            self.tree_depth = torch.zeros(B, q, **i32)
-            self.tree_len = torch.ones(B, **i32)
-            self.tree_mask = torch.zeros(B, q, dtype=torch.int64, device=dev)
+            # tokens, parents, depths, lengths and ancestor masks share one buffer: one upload
+            # per step.  Row 0 of a tree is the root (the last emitted token, written on the device).
+            n_i32 = 2 * ((3 * B * q + B + 1) // 2)        # even: the 64-bit masks follow
+            self._tree_dev = torch.zeros(n_i32 + 2 * B * q, **i32)
+            self._tree_host = _rt.pin(torch.zeros(n_i32 + 2 * B * q, dtype=torch.int32))
+
+            def views(buf):
+                return (buf[:B * q].view(B, q), buf[B * q:2 * B * q].view(B, q),
+                        buf[2 * B * q:3 * B * q].view(B, q), buf[3 * B * q:3 * B * q + B],
+                        buf[n_i32:].view(torch.int64).view(B, q))
+            (self.tree_tok, self.tree_parent, self.tree_depth, self.tree_len,
+             self.tree_mask) = views(self._tree_dev)
+            self._tree_np = [v.numpy() for v in views(self._tree_host)]
             self.tree_rope = torch.zeros(B * q, **i32)
             self.tree_ids = torch.zeros(B * q, dtype=torch.int64, device=dev)
             self.tree_path = torch.zeros(B, k, **i32)
             self.tree_npath = torch.zeros(B, **i32)
-            self._tree_host = {name: _rt.pin(torch.zeros(B, q, dtype=torch.int32))
-                               for name in ("tok", "parent", "depth")}
-            self._tree_host["mask"] = _rt.pin(torch.zeros(B, q, dtype=torch.int64))
-            self._tree_host["len"] = _rt.pin(torch.ones(B, dtype=torch.int32))
         self.part_val = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
         self.part_idx = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.int32, device=dev)
         # Vocabulary-parallel target head (tensor parallelism): a pass leaves this rank's
@@ -768,9 +772,11 @@ class SpecEngine:
 
     def _upload_trees(self, candidates: List[List[List[int]]]) -> None:
         """Merges every sequence's candidate chains into a token tree (rows in insertion order:
-        a node's parent always has a smaller row) and uploads tokens, parents, depths and
-        ancestor masks.  Unused rows are leaves under the root that the walk never looks at."""
-        N, k, h = self.tree_nodes, self.k, self._tree_host
+        a node's parent always has a smaller row) and uploads tokens, parents, depths, lengths and
+        ancestor masks in one copy.  Unused rows are leaves under the root that the walk never
+        looks at."""
+        N, k = self.tree_nodes, self.k
+        h_tok, h_par, h_dep, h_len, h_mask = self._tree_np
         for b, cands in enumerate(candidates):
             toks, parents, depths, masks = [0], [0], [0], [1]
             child = {}
@@ -788,23 +794,17 @@ class SpecEngine:
                         depths.append(d + 1)
                         masks.append(masks[cur] | (1 << row))
                     cur = row
-            h["len"][b] = len(toks)
+            h_len[b] = len(toks)
             for t in range(len(toks), N + 1):
                 toks.append(0)
                 parents.append(0)
                 depths.append(1)
                 masks.append(1 | (1 << t))
-            h["tok"][b] = torch.tensor(toks, dtype=torch.int32)
-            h["parent"][b] = torch.tensor(parents, dtype=torch.int32)
-            h["depth"][b] = torch.tensor(depths, dtype=torch.int32)
-            h["mask"][b] = torch.tensor([m - (1 << 64) if m >= (1 << 63) else m for m in masks],
-                                        dtype=torch.int64)
-        # column 0 of tree_tok (the root token) is written on the device by sd_tree_prepare
-        self.tree_tok[:, 1:].copy_(h["tok"][:, 1:], non_blocking=True)
-        self.tree_parent.copy_(h["parent"], non_blocking=True)
-        self.tree_depth.copy_(h["depth"], non_blocking=True)
-        self.tree_mask.copy_(h["mask"], non_blocking=True)
-        self.tree_len.copy_(h["len"], non_blocking=True)
+            h_tok[b], h_par[b], h_dep[b] = toks, parents, depths
+            h_mask[b] = [m - (1 << 64) if m >= (1 << 63) else m for m in masks]
+        # (column 0 of tree_tok, the root token, is written afterwards on the device by
+        # sd_tree_prepare)
+        self._tree_dev.copy_(self._tree_host, non_blocking=True)
 
     def _enqueue_score(self, fused: bool = False) -> None:
         """One target pass over {last token, k proposals} of every sequence:
