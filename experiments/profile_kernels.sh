@@ -3,7 +3,7 @@
 # the counter passes.  Run from the repository root on the GPU box.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/r1_profile
+OUT=$ROOT/gpurun_out/${ROUND:-r2}_profile
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_linear -o k -- \

@@ -3,7 +3,7 @@
 # GPU was active (one counter pass per script).  Run from the repository root on the GPU box.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/r1_profile
+OUT=$ROOT/gpurun_out/${ROUND:-r2}_profile
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 C="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"

@@ -3,7 +3,7 @@
 # roofline kernels (one counter per pass).  Run from the repository root on the GPU box.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
-OUT=$ROOT/gpurun_out/r1_profile
+OUT=$ROOT/gpurun_out/${ROUND:-r2}_profile
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \

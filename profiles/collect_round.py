@@ -9,7 +9,7 @@ gpurun_out/<round>_profile:
   <round>_pmc_mfma.json              matrix-pipe utilisation of the roofline kernels
                                      (experiments/profile_mfma.sh), when that pass was run
 
-usage: python profiles/collect_round.py [round-prefix, default r1]
+usage: python profiles/collect_round.py [round-prefix, default r2]
 """
 import csv
 import json
@@ -41,7 +41,7 @@ def counter_avg(path, counter):
 
 
 def main():
-    rnd = sys.argv[1] if len(sys.argv) > 1 else "r1"
+    rnd = sys.argv[1] if len(sys.argv) > 1 else "r2"
     src = os.path.join(ROOT, "gpurun_out", f"{rnd}_profile")
     dst = os.path.join(ROOT, "profiles")
     shutil.copy(os.path.join(src, "stats", "bench_kernel_stats.csv"),
