@@ -50,7 +50,10 @@ def main():
     max_ctx = int(os.environ.get("SD_MAX_CTX", "1280"))
     cfg = config.preset(name)
     w = weights.random_init(cfg, seed=2, device=dev)
-    model = DecoderModel(w, max_ctx, int(os.environ.get("SD_SPLIT", "256")))
+    model = DecoderModel(w, max_ctx, int(os.environ.get("SD_SPLIT", "256")),
+                         wide=os.environ.get("SD_WIDE", "0") == "1")
+    if os.environ.get("SD_WIDE", "0") == "1":
+        print("wide kernel family", flush=True)
     kv = PagedKVCache(cfg, PagedKVCache.pages_for(cfg, 1, max_ctx), 1, max_ctx, dev)
     kv.ensure_capacity(0, max_ctx)
     kv.k.normal_(0, 0.5)
