@@ -54,22 +54,24 @@ def main():
                          wide=os.environ.get("SD_WIDE", "0") == "1")
     if os.environ.get("SD_WIDE", "0") == "1":
         print("wide kernel family", flush=True)
-    kv = PagedKVCache(cfg, PagedKVCache.pages_for(cfg, 1, max_ctx), 1, max_ctx, dev)
-    kv.ensure_capacity(0, max_ctx)
+    B = int(os.environ.get("SD_B", "1"))          # sequences per pass, q_len rows each
+    kv = PagedKVCache(cfg, PagedKVCache.pages_for(cfg, B, max_ctx), B, max_ctx, dev)
+    for b in range(B):
+        kv.ensure_capacity(b, max_ctx)
     kv.k.normal_(0, 0.5)
     kv.v.normal_(0, 0.5)
-    seq_lens = torch.tensor([ctx], dtype=torch.int32, device=dev)
-    toks = torch.tensor([5, 7, 11, 13, 17, 19, 23, 29], dtype=torch.int32, device=dev)
-    logits = torch.empty(q_len, cfg.vocab, dtype=torch.float32, device=dev)
+    seq_lens = torch.tensor([ctx] * B, dtype=torch.int32, device=dev)
+    toks = torch.arange(5, 5 + 64, dtype=torch.int32, device=dev)
+    logits = torch.empty(B * q_len, cfg.vocab, dtype=torch.float32, device=dev)
     layer_bytes = sum(t.nbytes() for t in (w.layers[0].qkv_w, w.layers[0].o_w, w.layers[0].up_w,
                                            w.layers[0].down_w))
     reps = 4   # passes per graph: the average hides the graph's own launch cost
-    full = graph_time(lambda: [model.forward(kv, toks, 8, 0, seq_lens, 0, 1, q_len, logits, max_ctx)
+    full = graph_time(lambda: [model.forward(kv, toks, 0, 0, seq_lens, 0, B, q_len, logits, max_ctx)
                                for _ in range(reps)]) / reps
-    body = graph_time(lambda: [model.forward(kv, toks, 8, 0, seq_lens, 0, 1, q_len, None, max_ctx)
+    body = graph_time(lambda: [model.forward(kv, toks, 0, 0, seq_lens, 0, B, q_len, None, max_ctx)
                                for _ in range(reps)]) / reps
     per_layer = body / cfg.n_layers
-    print(f"{name} ctx={ctx} q_len={q_len} max_ctx={max_ctx}: pass {full:.1f} us, without head "
+    print(f"{name} B={B} ctx={ctx} q_len={q_len} max_ctx={max_ctx}: pass {full:.1f} us, without head "
           f"{body:.1f} us, head {full - body:.1f} us ({w.lm_head.nbytes() / 1e6:.0f} MB, "
           f"{w.lm_head.nbytes() / 1e6 / max(full - body, 1e-3):.2f} TB/s), layer {per_layer:.2f} us "
           f"({layer_bytes / 1e6:.1f} MB, {layer_bytes / 1e6 / per_layer:.2f} TB/s)", flush=True)
