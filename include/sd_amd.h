@@ -229,6 +229,14 @@ int sd_paged_attention_static(const void* q, int64_t ldq, const void* k_cache,
                               int Hq, int Hkv, int D, float scale, int max_ctx,
                               int split_tokens, sd_stream_t stream);
 
+/* tokens[b*stride + col] = map[tokens[b*stride + col]] for b < B (ids outside 0..n_map-1 are
+ * clamped).  For a draft whose LM head covers a subset of the vocabulary (sd_model_desc.lm_vocab
+ * rows in the order of `map`): turns the head's row index into the token id after
+ * sd_propose_from_partials / sd_store_proposal.  (Upstream counterpart: none in the reference;
+ * the technique is a frequency-ranked draft vocabulary.)                               */
+int sd_map_tokens(int32_t* tokens, int64_t stride, int col, const int32_t* map, int n_map,
+                  int B, sd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Token trees (multi-candidate verification; upstream: vllm/spec_decode's
  * tree-style scoring is not in the reference tree, the semantics follow

@@ -283,6 +283,48 @@ def test_prompts_prefilled_together_give_the_streams_of_one_at_a_time(temperatur
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_draft_head_over_a_vocabulary_subset(use_graph):
+    """A draft whose LM head covers a subset of the vocabulary: with a permutation of the whole
+    vocabulary the proposals (hence the counters) are those of the plain draft; with half of it
+    every proposal lies inside the subset; the emitted stream is the target's either way."""
+    from vllm_omni_draft_amd import config, weights
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dstate = _bf(random_state(dcfg, seed=22))
+    dw = _product(dcfg, dstate)
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 73))]
+    ar = [_generate(_engine(tw, None, 0), [p], 40)[0] for p in prompts]
+    plain = _engine(tw, dw, 3, max_batch=2, use_graph=use_graph)
+    assert _generate(plain, prompts, 40) == ar
+    rng = np.random.default_rng(0)
+    perm = [int(t) for t in rng.permutation(tcfg.vocab)]
+    half = sorted(perm[:tcfg.vocab // 2])
+    for subset, same_counters in ((perm, True), (half, False)):
+        dsub = weights.from_state_dict(dw.cfg, dstate, "cuda", head_subset=subset)
+        assert dsub.cfg.lm_vocab == len(subset) and dsub.head_map.tolist() == subset
+        eng = _engine(tw, dsub, 3, max_batch=2, use_graph=use_graph)
+        outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+        while min(len(o) for o in outs) < 40:
+            new = eng.step()
+            assert set(eng.tok_buf[:2, 2:].flatten().tolist()) <= set(subset)
+            for o, n in zip(outs, new):
+                o.extend(n)
+        assert [o[:40] for o in outs] == ar
+        if same_counters:
+            assert eng.metrics() == plain.metrics()
+    with pytest.raises(ValueError):
+        weights.from_state_dict(dw.cfg, dstate, "cuda", head_subset=[1, 2, 3])       # not a multiple of 16
+    with pytest.raises(ValueError):
+        weights.from_state_dict(dw.cfg, dstate, "cuda", head_subset=[0] * 16)        # duplicates
+    with pytest.raises(ValueError):
+        _engine(tw, weights.from_state_dict(dw.cfg, dstate, "cuda", head_subset=half), 3, temperature=0.7)
+    with pytest.raises(ValueError):
+        _engine(weights.from_state_dict(tw.cfg, _bf(random_state(tcfg, seed=21)), "cuda", head_subset=half),
+                dw, 3)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_wide_batch_spec_equals_ar(use_graph):
     """8 sequences x (k+1 = 6) rows = 48 rows per verify pass: the wide kernel family.  The
     speculative stream equals the autoregressive one of an engine on the same family."""

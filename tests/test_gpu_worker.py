@@ -249,7 +249,20 @@ def test_fp8_draft_under_a_bf16_target_keeps_the_target_stream():
     assert out[:30] == want
     m = w.metrics.maybe_collect(force=True)
     assert m.accepted_tokens > m.draft_tokens // 2      # an fp8 copy of the target mostly agrees with it
+    # the same draft with an fp8 head over half of the vocabulary: still the target's stream
+    w2 = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=(tw.cfg, tstate), draft_quantization="fp8",
+                                           draft_vocab_subset=list(range(0, tcfg.vocab, 2)),
+                                           num_speculative_tokens=3, max_num_seqs=1, max_model_len=200,
+                                           split_tokens=128))
+    w2.init_device()
+    w2.load_model()
+    assert w2.engine.draft.cfg.lm_vocab == tcfg.vocab // 2 and w2.engine.d_map is not None
+    out2 = w2.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", True, prompt)])).sampled_token_ids[0]
+    while len(out2) < 30:
+        out2 += w2.execute_model(ExecuteModelRequest([SequenceGroupMetadata("r", False)])).sampled_token_ids[0]
+    assert out2[:30] == want
     for bad in (dict(draft=tw, draft_quantization="fp8"),           # bf16 weights object
+                dict(draft=tw, draft_vocab_subset=list(range(16))),  # a whole-vocabulary weights object
                 dict(draft=(tw.cfg, tstate), draft_quantization="int4"),
                 dict(draft=None, draft_quantization="fp8"),
                 dict(draft=(tw.cfg, tstate), quantization="fp8")):  # the target object is bf16

@@ -82,6 +82,7 @@ SIGNATURES = {
                                         i32, i32, C.c_float, i32, i32, vp]),
     "sd_paged_attention_tree": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, vp, i64, i32, i32, i32,
                                       i32, i32, C.c_float, i32, i32, vp, C.c_size_t, vp]),
+    "sd_map_tokens": (i32, [vp, i64, i32, vp, i32, i32, vp]),
     "sd_tree_prepare": (i32, [vp, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp]),
     "sd_tree_accept_greedy": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp]),
     "sd_kv_compact": (i32, [vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),

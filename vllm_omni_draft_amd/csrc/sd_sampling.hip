@@ -287,6 +287,15 @@ __global__ __launch_bounds__(SD_WAVE) void greedy_verify_kernel(
   }
 }
 
+__global__ __launch_bounds__(SD_WAVE) void map_tokens_kernel(int32_t* __restrict__ tokens, int64_t stride,
+                                                             int col, const int32_t* __restrict__ map,
+                                                             int n_map, int B) {
+  const int b = blockIdx.x * SD_WAVE + threadIdx.x;
+  if (b >= B) return;
+  int32_t* t = tokens + (size_t)b * stride + col;
+  *t = map[min(max(*t, 0), n_map - 1)];
+}
+
 // ---- token trees ------------------------------------------------------------
 __global__ __launch_bounds__(SD_WAVE) void tree_prepare_kernel(
     const int32_t* __restrict__ tok_buf, int64_t tok_stride, int tok_col, int32_t* __restrict__ tree_tok,
@@ -1006,6 +1015,17 @@ extern "C" int sd_greedy_verify(const int64_t* target_ids, const int64_t* draft_
                      target_ids, draft_ids, proposal_lens, out_ids,
                      (unsigned long long*)counters, k);
   SD_CHECK_LAUNCH("sd_greedy_verify");
+  return SD_OK;
+}
+
+extern "C" int sd_map_tokens(int32_t* tokens, int64_t stride, int col, const int32_t* map, int n_map,
+                             int B, sd_stream_t stream) {
+  SD_REQUIRE(tokens && map && n_map >= 1 && B >= 0 && col >= 0 && col < stride, SD_ERR_INVALID,
+             "sd_map_tokens: bad arguments (n_map=%d col=%d)", n_map, col);
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(map_tokens_kernel, dim3((B + SD_WAVE - 1) / SD_WAVE), dim3(SD_WAVE), 0,
+                     (hipStream_t)stream, tokens, stride, col, map, n_map, B);
+  SD_CHECK_LAUNCH("sd_map_tokens");
   return SD_OK;
 }
 

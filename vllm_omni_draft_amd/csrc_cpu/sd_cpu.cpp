@@ -593,6 +593,17 @@ extern "C" int sd_paged_attention_tree(const void* q, int64_t ldq, const void* k
   return SD_OK;
 }
 
+extern "C" int sd_map_tokens(int32_t* tokens, int64_t stride, int col, const int32_t* map, int n_map, int B,
+                             sd_stream_t) {
+  REQUIRE(tokens && map && n_map >= 1 && B >= 0 && col >= 0 && col < stride, SD_ERR_INVALID,
+          "sd_map_tokens: bad arguments");
+  for (int b = 0; b < B; ++b) {
+    int32_t* t = tokens + (size_t)b * stride + col;
+    *t = map[std::min(std::max(*t, 0), n_map - 1)];
+  }
+  return SD_OK;
+}
+
 extern "C" int sd_tree_prepare(const int32_t* tok_buf, int64_t tok_stride, int tok_col, int32_t* tree_tok,
                                const int32_t* tree_depth, const int32_t* seq_lens, int pos_offset,
                                int32_t* rope_pos, int B, int q_len, sd_stream_t) {

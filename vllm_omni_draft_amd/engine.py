@@ -118,7 +118,13 @@ class SpecEngine:
         same inputs."""
         if draft_tp and tp_group is None:
             raise ValueError("draft_tp needs a tp_group")
-        if draft is not None and draft.cfg.lm_vocab and not draft_tp:
+        d_sub = draft is not None and getattr(draft, "head_map", None) is not None
+        if d_sub and (draft_tp or cfg.temperature > 0.0):
+            raise ValueError("a draft head over a vocabulary subset proposes greedily and is not "
+                             "sharded (temperature 0, no draft_tp)")
+        if getattr(target, "head_map", None) is not None:
+            raise ValueError("the target's LM head must cover the whole vocabulary")
+        if draft is not None and draft.cfg.lm_vocab and not draft_tp and not d_sub:
             raise ValueError("a vocabulary-parallel draft head needs draft_tp")
         if cfg.k < 0 or cfg.k > 7:
             raise ValueError("k must be in 0..7")
@@ -253,8 +259,14 @@ class SpecEngine:
             self.vp_rows = torch.empty(n_tp * n_rows * Vl, dtype=torch.float32, device=dev)
         # the same for a sharded draft with a vocabulary-parallel head (buffers shared with the
         # target's exchange: everything runs on one stream)
-        self.d_vp = self.draft is not None and draft.cfg.lm_vocab > 0
+        # a draft head over a vocabulary subset: its row indices become token ids after every
+        # proposal (sd_map_tokens)
+        self.d_map = draft.head_map if d_sub else None
+        self.d_vp = self.draft is not None and draft.cfg.lm_vocab > 0 and not d_sub
         self.d_out = self.d_logits
+        if d_sub:
+            self.d_out = torch.empty(self.d_logits.shape[0], draft.cfg.lm_vocab, dtype=torch.float32,
+                                     device=dev)
         if self.d_vp:
             if not self.vp or draft.cfg.lm_vocab != target.cfg.lm_vocab:
                 raise ValueError("a vocabulary-parallel draft head needs the target's head split "
@@ -702,11 +714,13 @@ class SpecEngine:
                 off, step = 0, 1
             if self.d_vp and (self.sampling or not fused):
                 self._gather_rows(self.d_out, self.d_logits, B * step)   # whole rows on every rank
-            rows = self.d_logits[:B * step]
+            rows = (self.d_out if self.d_map is not None else self.d_logits)[:B * step]
             if fused:
                 self._partials(self.d_out, B * step, self.d_vp)
                 ops.propose_from_partials(self.part_val, self.part_idx, off, step,
                                           self.tok_buf[:B], k, i)
+                if self.d_map is not None:
+                    ops.map_tokens(self.tok_buf[:B], 2 + i, self.d_map)
                 continue
             if self.sampling:
                 ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
@@ -717,6 +731,8 @@ class SpecEngine:
             else:
                 ops.argmax_rows(rows, out=self.ids_tmp, row_offset=off, row_step=step)
             ops.store_proposal(self.ids_tmp[:B], self.tok_buf[:B], k, i)
+            if self.d_map is not None:
+                ops.map_tokens(self.tok_buf[:B], 2 + i, self.d_map)
         if self.truth is not None:    # benchmark control: impose the acceptance schedule
             ops.debug_force_proposals(self.tok_buf[:B], k, self.seq_lens[:B], self.truth,
                                       self.accept_pattern, self.force_ctr[:B], self.V)

@@ -284,6 +284,15 @@ def paged_attention_tree(q, k_cache, v_cache, block_tables, seq_lens, pos_offset
     return out
 
 
+def map_tokens(tokens: torch.Tensor, col: int, token_map: torch.Tensor) -> None:
+    """tokens[:, col] = token_map[tokens[:, col]] (int32 [B, stride]; see sd_map_tokens)."""
+    _need(tokens, torch.int32, "tokens")
+    _need(token_map, torch.int32, "token_map")
+    B, stride = tokens.shape
+    _lib.check(_lib.load().sd_map_tokens(_p(tokens), stride, col, _p(token_map), token_map.numel(), B,
+                                         _stream()), "sd_map_tokens")
+
+
 def tree_prepare(tok_buf, tok_col, tree_tok, tree_depth, seq_lens, pos_offset, rope_pos) -> None:
     """tree_tok[:, 0] = tok_buf[:, tok_col]; rope_pos[b, t] = seq_lens[b] + pos_offset + depth[b, t]."""
     for t, n in ((tok_buf, "tok_buf"), (tree_tok, "tree_tok"), (tree_depth, "tree_depth"),

@@ -441,6 +441,12 @@ class SpecDecodeConfig:
     # the target model itself.  A ModelWeights object loaded with fp8=True needs no option.
     quantization: Optional[str] = None
     draft_quantization: Optional[str] = None
+    # Token ids (a multiple of 16 of them, e.g. the most frequent tokens of the deployment's
+    # traffic) that the draft's LM head covers; None = the whole vocabulary.  The draft given as
+    # (ModelConfig, state_dict) is loaded with a head of those rows only: each draft pass streams
+    # that fraction of the head, the draft can only propose those tokens, the target still emits
+    # any token (greedy decoding only).
+    draft_vocab_subset: Optional[Sequence[int]] = None
 
 
 class SpecDecodeWorker:
@@ -522,7 +528,11 @@ class SpecDecodeWorker:
                 dcfg, dstate = W.shard_state_dict(dcfg, dstate, tp, self.rank,
                                                   vocab_parallel=target.cfg.lm_vocab > 0)
             draft = W.from_state_dict(dcfg, dstate, _rt.device(self.local_rank),
-                                      fp8=c.draft_quantization == "fp8")
+                                      fp8=c.draft_quantization == "fp8",
+                                      head_subset=c.draft_vocab_subset)
+        elif c.draft_vocab_subset is not None and getattr(draft, "head_map", None) is None:
+            raise ValueError("draft_vocab_subset needs the draft as (ModelConfig, state_dict), or a "
+                             "weights object loaded with head_subset")
         self.engine = SpecEngine(target, draft, EngineConfig(
             k=c.num_speculative_tokens, max_batch=c.max_num_seqs, max_seq_len=c.max_model_len,
             split_tokens=c.split_tokens, temperature=c.temperature, seed=c.seed,

@@ -51,6 +51,9 @@ class ModelWeights:
     final_norm_b: Optional[torch.Tensor] = None
     rope_cs: Optional[torch.Tensor] = None
     fp8: bool = False
+    # LM head over a subset of the vocabulary (a draft model's cheaper head): head_map[i] is the
+    # token id of head row i (int32, on the device); None = the whole vocabulary in order
+    head_map: Optional[torch.Tensor] = None
 
     def nbytes(self) -> int:
         seen, total = set(), 0
@@ -88,10 +91,27 @@ def _tile_matrix(w: torch.Tensor, mode: int = ops.TILE_PLAIN, head_dim: int = 0,
     return ops.tile_weights(w, mode, head_dim)
 
 
-def _embed_and_head(embed: torch.Tensor, head, device, fp8: bool = False):
+def _head_subset(cfg: ModelConfig, head_subset, device):
+    """(config whose head has one row per listed token, the ids as a device tensor)."""
+    ids = torch.as_tensor(list(head_subset), dtype=torch.int64)
+    if ids.numel() == 0 or ids.numel() % 16 or ids.min() < 0 or ids.max() >= cfg.vocab:
+        raise ValueError("head_subset: a positive multiple of 16 token ids inside the vocabulary")
+    if ids.unique().numel() != ids.numel():
+        raise ValueError("head_subset: token ids must be distinct")
+    if cfg.lm_vocab:
+        raise ValueError("head_subset: the head is already a slice (vocabulary-parallel)")
+    import dataclasses
+    return dataclasses.replace(cfg, lm_vocab=int(ids.numel())), ids.to(device)
+
+
+def _embed_and_head(embed: torch.Tensor, head, device, fp8: bool = False, subset=None):
     """Untied: row-major embedding + tiled head.  Tied: ONE tiled buffer serves
     both (the embedding gather reads rows out of the tiled layout); with fp8 the
-    head is a quantised copy and the embedding table stays row-major bf16."""
+    head is a quantised copy and the embedding table stays row-major bf16.  subset (token
+    ids): the head keeps those rows only, in that order; the embedding table stays whole."""
+    if subset is not None:
+        src = embed if head is None else _dev(head, device)
+        return embed, _tile_matrix(src[subset].contiguous(), fp8=fp8), False
     if head is None:
         if fp8:
             return embed, _tile_matrix(embed, fp8=True), False
@@ -115,9 +135,15 @@ def language_model_state(state: Dict[str, torch.Tensor]) -> Dict[str, torch.Tens
 
 
 def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cuda",
-                    fp8: bool = False) -> ModelWeights:
+                    fp8: bool = False, head_subset=None) -> ModelWeights:
+    """head_subset (token ids, a multiple of 16 of them): the LM head computes logits for those
+    tokens only (ModelWeights.head_map; for draft models: a head over the frequent tokens costs
+    a fraction of the whole one, and whatever the draft cannot propose the target still emits)."""
     cfg.validate()
     state = language_model_state(state)
+    sub = None
+    if head_subset is not None:
+        cfg, sub = _head_subset(cfg, head_subset, device)
 
     def _tile(w, mode=ops.TILE_PLAIN, head_dim=0):  # every layer matrix alike
         return _tile_matrix(w, mode, head_dim, fp8=fp8)
@@ -144,10 +170,11 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
                 up_w=_tile(_dev(up_w, device), ops.TILE_GATED),
                 down_w=_tile(_dev(g(lp + "mlp.down_proj.weight"), device))))
         embed, lm_head, tied = _embed_and_head(_dev(g(pre + "embed_tokens.weight"), device),
-                                               opt("lm_head.weight"), device, fp8)
+                                               opt("lm_head.weight"), device, fp8, sub)
         return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, fp8=fp8,
                             final_norm_w=_dev(g(pre + "norm.weight"), device), lm_head=lm_head,
-                            layers=layers, rope_cs=rope_table(cfg, device))
+                            layers=layers, rope_cs=rope_table(cfg, device),
+                            head_map=None if sub is None else sub.to(torch.int32))
     pre = "model.decoder."
     for i in range(cfg.n_layers):
         lp = f"{pre}layers.{i}."
@@ -164,8 +191,9 @@ def from_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], device="cu
             up_w=_tile(_dev(g(lp + "fc1.weight"), device)), up_b=_dev(g(lp + "fc1.bias"), device),
             down_w=_tile(_dev(g(lp + "fc2.weight"), device)), down_b=_dev(g(lp + "fc2.bias"), device)))
     embed, lm_head, tied = _embed_and_head(_dev(g(pre + "embed_tokens.weight"), device),
-                                           opt("lm_head.weight"), device, fp8)
+                                           opt("lm_head.weight"), device, fp8, sub)
     return ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, fp8=fp8,
+                        head_map=None if sub is None else sub.to(torch.int32),
                         pos_table=_dev(g(pre + "embed_positions.weight"), device),
                         final_norm_w=_dev(g(pre + "final_layer_norm.weight"), device),
                         final_norm_b=_dev(g(pre + "final_layer_norm.bias"), device),
@@ -213,10 +241,15 @@ def shard_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], tp_size: 
 
 
 def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02,
-                fp8: bool = False) -> ModelWeights:
+                fp8: bool = False, head_subset=None) -> ModelWeights:
     """Seeded random weights generated directly on the device in the fused
-    layout (no host copy: an 8B model is 16 GB)."""
+    layout (no host copy: an 8B model is 16 GB).  head_subset: as for from_state_dict (the
+    other tensors are those of the same seed without it)."""
     cfg.validate()
+    sub = None
+    full_rows = cfg.head_rows
+    if head_subset is not None:
+        cfg, sub = _head_subset(cfg, head_subset, device)
     gen = torch.Generator(device=device).manual_seed(seed)
 
     def _tile(w, mode=ops.TILE_PLAIN, head_dim=0):
@@ -246,10 +279,10 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
                 mlp_norm_w=ones(H), mlp_norm_b=rn(H), up_w=_tile(rn(F, H)), up_b=rn(F),
                 down_w=_tile(rn(H, F)), down_b=rn(H)))
     embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5)
-    embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(cfg.head_rows, H),
-                                           device, fp8)
+    embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(full_rows, H),
+                                           device, fp8, sub)
     w = ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, final_norm_w=ones(H), lm_head=lm_head,
-                     layers=layers, fp8=fp8)
+                     layers=layers, fp8=fp8, head_map=None if sub is None else sub.to(torch.int32))
     if cfg.arch == "llama":
         w.rope_cs = rope_table(cfg, device)
     else:
@@ -259,7 +292,7 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
 
 
 def from_safetensors_dir(cfg: ModelConfig, model_dir: str, device="cuda",
-                         fp8: bool = False) -> ModelWeights:
+                         fp8: bool = False, head_subset=None) -> ModelWeights:
     """Loads every *.safetensors shard of a local Hugging Face checkpoint."""
     from safetensors import safe_open
 
@@ -273,4 +306,4 @@ def from_safetensors_dir(cfg: ModelConfig, model_dir: str, device="cuda",
                 state[key] = f.get_tensor(key)
     if cfg.arch == "opt" and "decoder.embed_tokens.weight" in state:
         state = {"model." + k if k.startswith("decoder.") else k: v for k, v in state.items()}
-    return from_state_dict(cfg, state, device, fp8=fp8)
+    return from_state_dict(cfg, state, device, fp8=fp8, head_subset=head_subset)
