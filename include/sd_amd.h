@@ -139,6 +139,22 @@ int sd_rejection_sample_split(const float* target_probs, const int64_t* bonus_id
 int sd_fill_uniforms(float* out, int n, uint64_t seed, uint64_t* counter,
                      sd_stream_t stream);
 
+/* Per-sequence streams of uniforms (a request's SamplingParams.seed; upstream hands
+ * RejectionSampler.forward a `seeded_seqs` map of per-sequence generators): sequence b draws
+ * its j-th number of a step from hash(seeds[b], counters[b], j), whatever else is in the batch,
+ * so a seeded request samples the same tokens alone and among others.  The numbers land where
+ * the step's kernels read them: region r holds n numbers per sequence at
+ * out[offset + i * stride_j + b * stride_b], i < n; j runs through the regions in order.
+ * Afterwards counters[b] += 1 for b < B.  At most SD_UNIFORM_REGIONS_MAX regions.          */
+#define SD_UNIFORM_REGIONS_MAX 8
+typedef struct {
+  int64_t offset;
+  int32_t n;
+  int64_t stride_j, stride_b;
+} sd_uniform_region;
+int sd_fill_uniforms_seq(float* out, const sd_uniform_region* regions, int n_regions,
+                         const uint64_t* seeds, uint64_t* counters, int B, sd_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Paged KV cache and attention (replaces vLLM's paged_attention_v1/v2 as used
  * by spec_decode.batch_expansion's scorer, with k+1 query tokens per sequence

@@ -506,7 +506,6 @@ def test_sampled_tokens_follow_the_oracle_target_distribution(B, use_graph, meth
     rounds = 0
     while counts.sum() < 21000:
         eng.reset()
-        eng.rng.manual_seed(1000 + rounds)
         seqs = [[(7 * b + rounds) % cfg.vocab] for b in range(B)]      # one-token prompts
         for b in range(B):
             seqs[b].append(eng.add_request(b, seqs[b]))
@@ -523,6 +522,40 @@ def test_sampled_tokens_follow_the_oracle_target_distribution(B, use_graph, meth
     # sensitivity: the same counts do NOT pass against the draft's distribution
     with pytest.raises(AssertionError):
         _check_transitions(counts, Q)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_a_seeded_request_samples_the_same_tokens_alone_and_in_a_batch(use_graph):
+    """Every sequence draws from its own stream (its seed, its own step counter): the tokens a
+    seeded request samples do not depend on its batch mates, its slot, how it was admitted
+    (alone or in a batched prefill) or a move to another slot when a neighbour leaves."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    pa, pb, pc = [5, 9, 200, 31, 7], list(range(40, 60)), [3, 1, 4, 1, 5, 9, 2, 6]
+    kw = dict(temperature=0.8, use_graph=use_graph)
+
+    def alone(prompt, seed, n=30):
+        eng = _engine(tw, dw, 3, max_batch=1, **kw)
+        out = [eng.add_request(0, prompt, seed=seed)]
+        while len(out) < n:
+            out += eng.step()[0]
+        return out[:n]
+
+    a5, b7 = alone(pa, 5), alone(pb, 7)
+    assert alone(pa, 5) == a5 and alone(pa, 6) != a5              # reproducible, and the seed matters
+    eng = _engine(tw, dw, 3, max_batch=3, **kw)
+    outs = [[t] for t in eng.add_requests([pc, pa, pb], seeds=[None, 5, 7])]     # slots 0, 1, 2
+    for _ in range(4):
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    eng.remove_request(0)                                         # pb moves from slot 2 to slot 0
+    outs = [outs[2], outs[1]]
+    while min(len(o) for o in outs) < 30:
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    assert outs[1][:30] == a5 and outs[0][:30] == b7
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -333,3 +333,33 @@ def test_fill_uniforms_is_uniform_and_advances():
     counter.zero_()
     ops.fill_uniforms(u, 7, counter)          # same (seed, counter) -> same numbers
     assert torch.equal(a, u)
+
+
+def test_per_sequence_uniform_streams_match_the_host_hash():
+    """sd_fill_uniforms_seq: sequence b's j-th number of a step is hash(seed_b, counter_b, j) at
+    the place its region says; counters advance by one; seeds above 2**63 work."""
+    from vllm_omni_draft_amd import ops
+    B, k = 5, 3
+    sizes = [k * B, B * k, B * (k + 1), B]
+    out = torch.full((sum(sizes) + 7,), -1.0, dtype=torch.float32).cuda()
+    regions = [(0, k, B, 1), (k * B, k, 1, k), (2 * k * B, k + 1, 1, k + 1), (2 * k * B + B * (k + 1), 1, 0, 1)]
+    seeds_u = [0, 1, 12345678901234567890, 2 ** 64 - 1, 42]
+    seeds = torch.tensor([s - 2 ** 64 if s >= 2 ** 63 else s for s in seeds_u], dtype=torch.int64).cuda()
+    counters = torch.tensor([0, 5, 7, 2 ** 40, 3], dtype=torch.int64).cuda()
+    c0 = counters.tolist()
+    n_active = 4                                   # the last sequence is not in the batch
+    for step in range(2):
+        ops.fill_uniforms_seq(out, ops.uniform_regions(regions), seeds, counters, n_active)
+        torch.cuda.synchronize()
+        got = out.cpu().tolist()
+        for b in range(n_active):
+            j = 0
+            for off, n, sj, sb in regions:
+                for i in range(n):
+                    want = np.float32(ops.uniform24(seeds_u[b], c0[b] + step, j))
+                    assert np.float32(got[off + i * sj + b * sb]) == want, (b, j)
+                    j += 1
+        assert counters.tolist() == [c + step + 1 for c in c0[:n_active]] + c0[n_active:]
+    assert all(v == -1.0 for v in got[sum(sizes):])                # nothing past the regions
+    vals = [got[off + i * sj + b * sb] for off, n, sj, sb in regions for i in range(n) for b in range(n_active)]
+    assert all(0.0 <= v < 1.0 for v in vals) and len(set(vals)) > len(vals) - 3

@@ -419,7 +419,7 @@ def test_a_refused_step_loses_no_tokens():
     bad = [P("long", list(range(8))),                   # prompt + 1 > max_seq_len
            P("empty", []),
            P("hot", [2, 2], temperature=0.7),           # another temperature
-           P("seeded", [2, 2], seed=11),                # per-request seed
+           P("seeded", [2, 2], seed="eleven"),          # a seed that is not an integer
            P("a", [2, 2])]                              # already running
     for g in bad:
         with pytest.raises((ValueError, KeyError)):

@@ -57,6 +57,10 @@ class ForwardArgs(C.Structure):
                 ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp)]
 
 
+class UniformRegion(C.Structure):
+    _fields_ = [("offset", i64), ("n", i32), ("stride_j", i64), ("stride_b", i64)]
+
+
 class RopePositions(C.Structure):
     _fields_ = [("pos", vp), ("delta", vp), ("section_t", i32), ("section_h", i32)]
 
@@ -125,6 +129,7 @@ SIGNATURES = {
     "sd_sample_rows_split": (i32, [vp, i64, vp, vp, i32, i32, vp, vp]),
     "sd_rejection_sample_split": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
     "sd_fill_uniforms": (i32, [vp, i32, C.c_uint64, vp, vp]),
+    "sd_fill_uniforms_seq": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, vp]),
     "sd_verify_from_partials": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, i32,

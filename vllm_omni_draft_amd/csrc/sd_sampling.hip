@@ -712,6 +712,38 @@ __global__ __launch_bounds__(1024) void fill_uniforms_kernel(float* __restrict__
   if (threadIdx.x == 0) *counter = c + 1;
 }
 
+__device__ __forceinline__ float uniform24(unsigned long long seed, unsigned long long c,
+                                          unsigned long long i) {
+  unsigned long long z = seed ^ (c * 0x9e3779b97f4a7c15ull) ^ (i << 32 | (unsigned)i);
+  z += 0x9e3779b97f4a7c15ull;   // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+struct UniformRegions {
+  sd_uniform_region r[SD_UNIFORM_REGIONS_MAX];
+  int n;
+};
+
+// One wave per sequence: lane j writes the sequence's j-th, (j+64)-th, ... number of the step.
+__global__ __launch_bounds__(SD_WAVE) void fill_uniforms_seq_kernel(
+    float* __restrict__ out, UniformRegions regs, const unsigned long long* __restrict__ seeds,
+    unsigned long long* __restrict__ counters) {
+  const int b = blockIdx.x;
+  const unsigned long long seed = seeds[b], c = counters[b];
+  int j0 = 0;
+  for (int r = 0; r < regs.n; ++r) {
+    const sd_uniform_region& g = regs.r[r];
+    for (int i = threadIdx.x; i < g.n; i += SD_WAVE)
+      out[g.offset + (int64_t)i * g.stride_j + (int64_t)b * g.stride_b] =
+          uniform24(seed, c, (unsigned long long)(j0 + i));
+    j0 += g.n;
+  }
+  if (threadIdx.x == 0) counters[b] = c + 1;
+}
+
 __global__ __launch_bounds__(kSampleThreads) void sample_rows_kernel(
     const float* __restrict__ probs, int64_t ld, const float* __restrict__ uniforms,
     int64_t* __restrict__ ids, int V) {
@@ -1175,6 +1207,27 @@ extern "C" int sd_fill_uniforms(float* out, int n, uint64_t seed, uint64_t* coun
   hipLaunchKernelGGL(fill_uniforms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, out, n,
                      (unsigned long long)seed, reinterpret_cast<unsigned long long*>(counter));
   SD_CHECK_LAUNCH("sd_fill_uniforms");
+  return SD_OK;
+}
+
+extern "C" int sd_fill_uniforms_seq(float* out, const sd_uniform_region* regions, int n_regions,
+                                    const uint64_t* seeds, uint64_t* counters, int B,
+                                    sd_stream_t stream) {
+  SD_REQUIRE(out && regions && seeds && counters && B >= 0 && n_regions >= 1 &&
+                 n_regions <= SD_UNIFORM_REGIONS_MAX,
+             SD_ERR_INVALID, "sd_fill_uniforms_seq: bad arguments (regions=%d)", n_regions);
+  UniformRegions regs;
+  regs.n = n_regions;
+  for (int r = 0; r < n_regions; ++r) {
+    SD_REQUIRE(regions[r].n >= 0 && regions[r].offset >= 0, SD_ERR_INVALID,
+               "sd_fill_uniforms_seq: region %d has a negative size or offset", r);
+    regs.r[r] = regions[r];
+  }
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(fill_uniforms_seq_kernel, dim3(B), dim3(SD_WAVE), 0, (hipStream_t)stream, out,
+                     regs, reinterpret_cast<const unsigned long long*>(seeds),
+                     reinterpret_cast<unsigned long long*>(counters));
+  SD_CHECK_LAUNCH("sd_fill_uniforms_seq");
   return SD_OK;
 }
 

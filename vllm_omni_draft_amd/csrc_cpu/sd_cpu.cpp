@@ -504,6 +504,36 @@ extern "C" int sd_sample_rows_split(const float* p, int64_t ld, const float* u, 
   return sd_sample_rows(p, ld, u, ids, R, V, s);
 }
 
+namespace {
+inline float uniform24(unsigned long long seed, unsigned long long c, unsigned long long i) {
+  unsigned long long z = seed ^ (c * 0x9e3779b97f4a7c15ull) ^ (i << 32 | (unsigned)i);
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+}  // namespace
+
+extern "C" int sd_fill_uniforms_seq(float* out, const sd_uniform_region* regions, int n_regions,
+                                    const uint64_t* seeds, uint64_t* counters, int B, sd_stream_t) {
+  REQUIRE(out && regions && seeds && counters && B >= 0 && n_regions >= 1 &&
+              n_regions <= SD_UNIFORM_REGIONS_MAX, SD_ERR_INVALID, "sd_fill_uniforms_seq: bad arguments");
+  for (int b = 0; b < B; ++b) {
+    int j0 = 0;
+    for (int r = 0; r < n_regions; ++r) {
+      const sd_uniform_region& g = regions[r];
+      REQUIRE(g.n >= 0 && g.offset >= 0, SD_ERR_INVALID, "sd_fill_uniforms_seq: bad region");
+      for (int i = 0; i < g.n; ++i)
+        out[g.offset + (int64_t)i * g.stride_j + (int64_t)b * g.stride_b] =
+            uniform24(seeds[b], counters[b], (unsigned long long)(j0 + i));
+      j0 += g.n;
+    }
+    counters[b] += 1;
+  }
+  return SD_OK;
+}
+
 extern "C" int sd_fill_uniforms(float* out, int n, uint64_t seed, uint64_t* counter, sd_stream_t) {
   REQUIRE(out && counter && n >= 0, SD_ERR_INVALID, "sd_fill_uniforms: bad arguments");
   const unsigned long long c = *counter;

@@ -299,9 +299,17 @@ class SpecEngine:
             self.u_accept = parts[1].view(B, kk)
             self.u_recover = parts[2].view(B, k + 1)
             self.u_bonus = parts[3]
-            self.u_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+            # every sequence draws from a stream of its own (its request's seed, or one derived
+            # from cfg.seed and the order of admission): what a sequence samples does not depend
+            # on its batch mates
+            self.u_seeds = torch.zeros(B, dtype=torch.int64, device=dev)
+            self.u_counters = torch.zeros(B, dtype=torch.int64, device=dev)
+            self.host_seeds: List[int] = [0] * B
+            self._admitted = 0
+            self.u_regions = ops.uniform_regions([
+                (0, kk, B, 1), (kk * B, kk, 1, kk), (2 * kk * B, k + 1, 1, k + 1),
+                (2 * kk * B + B * (k + 1), 1, 0, 1)])
             self.bonus_ids = torch.zeros(B, dtype=torch.int64, device=dev)
-            self.rng = torch.Generator(device=dev).manual_seed(cfg.seed)  # first-token draw
             self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * (k + 1)), dev)
         # synthetic acceptance control (benchmarks with random weights)
         self.truth: Optional[torch.Tensor] = None
@@ -363,7 +371,8 @@ class SpecEngine:
     def add_request(self, slot: int, prompt: Sequence[int],
                     input_embeds: Optional[torch.Tensor] = None,
                     rope_positions: Optional[torch.Tensor] = None,
-                    truth_row: Optional[Sequence[int]] = None) -> int:
+                    truth_row: Optional[Sequence[int]] = None,
+                    seed: Optional[int] = None) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
         first token from the target and returns it (this synchronises).
         Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
@@ -371,17 +380,32 @@ class SpecEngine:
         placeholder tokens' places; the draft still embeds the token ids), rope_positions
         [3, len(prompt)] the rotary positions for models with mrope_section.  truth_row
         (benchmarks with synthetic acceptance, see set_synthetic_acceptance): the request's
-        token stream from position 0, stored in the slot's row of the truth table."""
+        token stream from position 0, stored in the slot's row of the truth table.  seed
+        (sampling): the request's own random stream; the tokens it samples are then the same
+        whatever else is in the batch (None: a stream derived from EngineConfig.seed and the
+        order of admission)."""
         with _rt.stream_ctx(self.stream):
             if truth_row is not None:
                 if self.truth is None:
                     raise ValueError("truth_row needs set_synthetic_acceptance first")
                 row = torch.tensor(list(truth_row)[:self.truth.shape[1]], dtype=torch.int32)
                 self.truth[slot, :row.numel()].copy_(row)
-            return self._add_request(slot, prompt, input_embeds, rope_positions)
+            return self._add_request(slot, prompt, input_embeds, rope_positions, seed)
+
+    def _seed_slot(self, slot: int, seed: Optional[int]) -> float:
+        """Gives batch slot `slot` its random stream; returns the uniform of its first token."""
+        m = (1 << 64) - 1
+        if seed is None:
+            seed = (self.cfg.seed * 0x9e3779b97f4a7c15 + (self._admitted + 1) * 0xbf58476d1ce4e5b9) & m
+        self._admitted += 1
+        seed &= m
+        self.host_seeds[slot] = seed
+        self.u_seeds[slot] = seed - (1 << 64) if seed >= (1 << 63) else seed
+        self.u_counters[slot] = 0
+        return ops.uniform24(seed, 1 << 63, 0)    # a counter value no step reaches
 
     def _add_request(self, slot: int, prompt: Sequence[int], input_embeds=None,
-                     rope_positions=None) -> int:
+                     rope_positions=None, seed: Optional[int] = None) -> int:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
         n = len(prompt)
@@ -429,7 +453,7 @@ class SpecEngine:
         # first generated token from the last prompt row (a 1-token pass: row 0)
         if self.sampling:
             self._target_full_rows(1)
-            u = torch.rand(1, generator=self.rng, device=self.device)
+            u = torch.tensor([self._seed_slot(slot, seed)], dtype=torch.float32).to(self.device)
             probs = ops.softmax_rows(self.t_logits[:1], self.cfg.temperature)
             first = ops.sample_rows(probs, u)
         else:
@@ -448,7 +472,8 @@ class SpecEngine:
         return first_tok
 
     def add_requests(self, prompts: Sequence[Sequence[int]],
-                     truth_rows: Optional[Sequence[Sequence[int]]] = None) -> List[int]:
+                     truth_rows: Optional[Sequence[Sequence[int]]] = None,
+                     seeds: Optional[Sequence[Optional[int]]] = None) -> List[int]:
         """Prefills several text prompts in the same passes and returns their first tokens (one
         synchronisation for all of them).  The prompts take the next free slots in order.
         Every pass carries a chunk of each prompt (prefill_rows // len(prompts) tokens per
@@ -463,9 +488,11 @@ class SpecEngine:
                 for i, tr in enumerate(truth_rows):
                     row = torch.tensor(list(tr)[:self.truth.shape[1]], dtype=torch.int32)
                     self.truth[self.active + i, :row.numel()].copy_(row)
-            return self._add_requests([list(p) for p in prompts])
+            if seeds is not None and len(seeds) != len(prompts):
+                raise ValueError("one seed (or None) per prompt")
+            return self._add_requests([list(p) for p in prompts], seeds)
 
-    def _add_requests(self, prompts: List[List[int]]) -> List[int]:
+    def _add_requests(self, prompts: List[List[int]], seeds=None) -> List[int]:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
         Bp, slot0 = len(prompts), self.active
@@ -483,7 +510,7 @@ class SpecEngine:
             out: List[int] = []
             per = min(m.prefill_rows for m in (self.target, self.draft) if m is not None)
             for i in range(0, Bp, per):
-                out += self._add_requests(prompts[i:i + per])
+                out += self._add_requests(prompts[i:i + per], None if seeds is None else seeds[i:i + per])
             return out
         if self._prompt_rows is None or self._prompt_rows.shape[0] < Bp:
             self._prompt_rows = torch.zeros(self.cfg.max_batch, max(self.cfg.max_seq_len, 8),
@@ -519,7 +546,8 @@ class SpecEngine:
                           self.t_out[:Bp] if model is self.target else None, self._ctx, wide=wide)
         if self.sampling:
             self._target_full_rows(Bp)
-            u = torch.cat([torch.rand(1, generator=self.rng, device=self.device) for _ in range(Bp)])
+            u = torch.tensor([self._seed_slot(slot0 + i, None if seeds is None else seeds[i])
+                              for i in range(Bp)], dtype=torch.float32).to(self.device)
             probs = ops.softmax_rows(self.t_logits[:Bp], self.cfg.temperature)
             first = ops.sample_rows(probs, u)
         else:
@@ -883,6 +911,9 @@ class SpecEngine:
             if slot != last:
                 moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta,
                          self.force_ctr]
+                if self.sampling:
+                    moved += [self.u_seeds, self.u_counters]
+                    self.host_seeds[slot] = self.host_seeds[last]
                 if self.truth is not None:
                     moved.append(self.truth)
                 for t in moved:
@@ -897,7 +928,7 @@ class SpecEngine:
     # ------------------------------------------------------------------ stepping
     def _refresh_uniforms(self) -> None:
         """Fresh uniforms for the coming step, drawn on the device (no host work, no sync)."""
-        ops.fill_uniforms(self.u_all, self.cfg.seed, self.u_counter)
+        ops.fill_uniforms_seq(self.u_all, self.u_regions, self.u_seeds, self.u_counters, self.active)
 
     def set_external_proposals(self, proposals: Optional[Sequence[Sequence[int]]]) -> None:
         """Proposals of the coming step, one token list (at most k are used) per active

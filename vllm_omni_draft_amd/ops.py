@@ -545,6 +545,39 @@ def fill_uniforms(out: torch.Tensor, seed: int, counter: torch.Tensor) -> None:
                                             _p(counter), _stream()), "sd_fill_uniforms")
 
 
+def uniform_regions(regions):
+    """ctypes array for fill_uniforms_seq from (offset, n, stride_j, stride_b) tuples."""
+    arr = (_lib.UniformRegion * len(regions))()
+    for i, (off, n, sj, sb) in enumerate(regions):
+        arr[i] = _lib.UniformRegion(off, n, sj, sb)
+    return arr
+
+
+def fill_uniforms_seq(out: torch.Tensor, regions, seeds: torch.Tensor, counters: torch.Tensor,
+                      B: int) -> None:
+    """Per-sequence uniform streams: sequence b's j-th number of the step is
+    hash(seeds[b], counters[b], j), written into out at the regions' places
+    (ops.uniform_regions); counters[:B] += 1."""
+    _need(out, torch.float32, "out")
+    _need(seeds, torch.int64, "seeds")
+    _need(counters, torch.int64, "counters")
+    if seeds.numel() < B or counters.numel() < B:
+        raise _lib.SdError("fill_uniforms_seq: seeds / counters shorter than B")
+    _lib.check(_lib.load().sd_fill_uniforms_seq(_p(out), regions, len(regions), _p(seeds),
+                                                _p(counters), B, _stream()), "sd_fill_uniforms_seq")
+
+
+def uniform24(seed: int, counter: int, j: int) -> float:
+    """The number fill_uniforms_seq gives sequence (seed, counter) at index j, on the host."""
+    m = (1 << 64) - 1
+    z = (seed ^ ((counter * 0x9e3779b97f4a7c15) & m) ^ (((j << 32) | (j & 0xffffffff)) & m)) & m
+    z = (z + 0x9e3779b97f4a7c15) & m
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & m
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & m
+    z ^= z >> 31
+    return (z >> 40) / 16777216.0
+
+
 # ---------------------------------------------------------------- step glue
 def store_proposal(ids, tok_buf, k, step) -> None:
     B = tok_buf.shape[0]

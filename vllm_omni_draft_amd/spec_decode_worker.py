@@ -42,8 +42,10 @@ class SamplingParams:
     # max_tokens and the end-of-sequence token); the worker emits tokens until a request is
     # listed as finished, like a V1 model runner.
     max_tokens: int = 16
-    # A per-request seed is refused: the uniforms of a step are drawn on the device from one
-    # counter-based stream per worker (SpecDecodeConfig.seed), not per request.
+    # The request's own random stream (sampling): every sequence draws its uniforms from
+    # hash(seed, step, index) on the device, so a seeded request samples the same tokens alone
+    # and among any batch mates.  None: a stream derived from SpecDecodeConfig.seed and the order
+    # of admission.  Greedy workers ignore it.
     seed: Optional[int] = None
     ignore_eos: bool = True
 
@@ -613,9 +615,8 @@ class SpecDecodeWorker:
             if sp.temperature is not None and have is not None and float(sp.temperature) != float(have):
                 raise ValueError(f"request {g.request_id} asks for temperature {sp.temperature}; this "
                                  f"worker runs every sequence at {have}")
-            if sp.seed is not None:
-                raise ValueError(f"request {g.request_id} asks for a per-request seed; this worker "
-                                 "draws from one stream per worker (SpecDecodeConfig.seed)")
+            if sp.seed is not None and not isinstance(sp.seed, int):
+                raise ValueError(f"request {g.request_id}: seed must be an integer")
             if g.request_id in self._slot_of and g.request_id not in finished:
                 raise KeyError(f"request {g.request_id} is already running")
             n = len(g.prompt_token_ids)
@@ -658,13 +659,16 @@ class SpecDecodeWorker:
             while (j < len(prompts) and not mm_inputs[prompts[j].request_id]
                    and hasattr(eng, "add_requests")):
                 j += 1
+            seeded = bool(getattr(eng, "sampling", False))    # greedy engines have no use for seeds
             if j - i >= 2:
                 group = prompts[i:j]
-                firsts = eng.add_requests([g.prompt_token_ids for g in group])
+                kw = dict(seeds=[g.sampling_params.seed for g in group]) if seeded else {}
+                firsts = eng.add_requests([g.prompt_token_ids for g in group], **kw)
             else:
                 group = prompts[i:i + 1]
+                kw = dict(seed=group[0].sampling_params.seed) if seeded else {}
                 firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
-                                          **mm_inputs[group[0].request_id])]
+                                          **mm_inputs[group[0].request_id], **kw)]
             for g, first in zip(group, firsts):
                 self._slot_of[g.request_id] = len(self._req_at)
                 self._req_at.append(g.request_id)
