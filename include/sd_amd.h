@@ -650,7 +650,7 @@ int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32_t* tok_buf
  *  - sd_verify_from_partials: rows b*(k+1)+i are the target's k+1 rows;
  *    greedy acceptance against tok_buf[:, 2:2+k] (as sd_greedy_verify;
  *    out_ids and counters optional), then the state update and step record
- *    of sd_advance_state.  k == 0 is plain autoregressive decoding.          */
+ *    of sd_advance_state.  k == 0 is plain autoregressive decoding; k <= 15.  */
 #define SD_ARGMAX_PARTS 64
 int sd_argmax_partial(const float* logits, int64_t ld, float* part_val,
                       int32_t* part_idx, int R, int V, sd_stream_t stream);

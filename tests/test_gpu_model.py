@@ -190,7 +190,7 @@ def _generate(eng, prompts, n_new):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
-@pytest.mark.parametrize("k", [1, 3, 5])
+@pytest.mark.parametrize("k", [1, 3, 5, 8, 15])
 def test_greedy_spec_equals_ar_on_gpu(k, use_graph):
     tcfg, dcfg = MODELS["llama"], MODELS["opt"]
     dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
@@ -599,6 +599,13 @@ def test_prompt_lookup_proposer_equals_ar_and_accepts_repeats(use_graph):
     m = eng.metrics()
     # a tiny random model falls into a loop quickly: the lookup then predicts it
     assert m["draft"] > 0 and m["accepted"] > 0
+    # long lookups (k = 12: 13 verify rows): once the model loops, whole runs are accepted
+    eng = _engine(tw, None, 12, max_batch=1, ngram_max=3, ngram_min=1, use_graph=use_graph)
+    assert _generate(eng, prompts[:1], 60) == ar[:1]
+    m12 = eng.metrics()
+    assert m12["accepted"] > 0 and (m12["emitted"] - m12["accepted"]) < 60     # fewer steps than tokens
+    with pytest.raises(ValueError):
+        _engine(tw, None, 16, ngram_max=3)                                     # beyond the fused walk
     # sampling mode runs with the one-hot draft distribution of the lookup
     eng = _engine(tw, None, 4, max_batch=2, ngram_max=3, temperature=1.0, seed=1, use_graph=use_graph)
     out = _generate(eng, prompts, 30)

@@ -945,14 +945,14 @@ __global__ __launch_bounds__(SD_WAVE) void propose_from_partials_kernel(
 
 // Greedy verification straight from the target's argmax partials: wave j finishes row j
 // of the sequence, wave 0 then matches the proposals in tok_buf and applies the result.
-__global__ __launch_bounds__(SD_WAVE * 8) void verify_from_partials_kernel(
+__global__ __launch_bounds__(SD_WAVE * 16) void verify_from_partials_kernel(
     const float* __restrict__ part_val, const int32_t* __restrict__ part_idx,
     int32_t* __restrict__ tok_buf, const int32_t* __restrict__ proposal_lens,
     int64_t* __restrict__ out_ids, unsigned long long* __restrict__ counters,
     int32_t* __restrict__ seq_lens, int32_t* __restrict__ gen_tokens, int64_t gen_stride,
     int gen_capacity, int32_t* __restrict__ gen_counts, int32_t* __restrict__ step_out, int k) {
-  __shared__ int s_target[8];
-  __shared__ int64_t s_out[8];
+  __shared__ int s_target[16];
+  __shared__ int64_t s_out[16];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (wave <= k) {
     const int id = wave_argmax_finish(part_val, part_idx, b * (k + 1) + wave, lane);
@@ -1360,9 +1360,9 @@ extern "C" int sd_verify_from_partials(const float* part_val, const int32_t* par
                                        int32_t* gen_counts, int32_t* step_out, int B, int k,
                                        sd_stream_t stream) {
   SD_REQUIRE(part_val && part_idx && tok_buf && seq_lens && gen_counts && B >= 0 && k >= 0 &&
-                 k <= 7, SD_ERR_INVALID, "sd_verify_from_partials: bad arguments (B=%d k=%d)", B, k);
+                 k <= 15, SD_ERR_INVALID, "sd_verify_from_partials: bad arguments (B=%d k=%d)", B, k);
   if (B == 0) return SD_OK;
-  hipLaunchKernelGGL(verify_from_partials_kernel, dim3(B), dim3(SD_WAVE * 8), 0,
+  hipLaunchKernelGGL(verify_from_partials_kernel, dim3(B), dim3(SD_WAVE * (k < 8 ? 8 : 16)), 0,
                      (hipStream_t)stream, part_val, part_idx, tok_buf, proposal_lens, out_ids,
                      reinterpret_cast<unsigned long long*>(counters), seq_lens, gen_tokens,
                      gen_stride, gen_capacity, gen_counts, step_out, k);

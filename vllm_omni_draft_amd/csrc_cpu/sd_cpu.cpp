@@ -1103,16 +1103,16 @@ extern "C" int sd_verify_from_partials(const float* pv, const int32_t* pi, int32
                                        int32_t* seq_lens, int32_t* gen_tokens, int64_t gen_stride,
                                        int gen_capacity, int32_t* gen_counts, int32_t* step_out, int B,
                                        int k, sd_stream_t) {
-  REQUIRE(pv && pi && tok_buf && seq_lens && gen_counts && B >= 0 && k >= 0 && k <= 7, SD_ERR_INVALID,
+  REQUIRE(pv && pi && tok_buf && seq_lens && gen_counts && B >= 0 && k >= 0 && k <= 15, SD_ERR_INVALID,
           "sd_verify_from_partials: bad arguments (B=%d k=%d)", B, k);
   for (int b = 0; b < B; ++b) {
-    int target[8];
+    int target[16];
     for (int i = 0; i <= k; ++i) target[i] = finish_partials(pv, pi, b * (k + 1) + i);
     const int L = std::min(std::max(lens ? lens[b] : k, 0), k);
     const int32_t* prop = tok_buf + (size_t)b * (k + 2) + 2;
     int j = 0;
     while (j < L && prop[j] == target[j]) ++j;
-    int64_t o[8];
+    int64_t o[16];
     for (int i = 0; i <= k; ++i) o[i] = i < j ? prop[i] : (i == j ? target[j] : -1);
     if (out_ids)
       for (int i = 0; i <= k; ++i) out_ids[(size_t)b * (k + 1) + i] = o[i];

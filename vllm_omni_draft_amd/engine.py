@@ -126,8 +126,11 @@ class SpecEngine:
             raise ValueError("the target's LM head must cover the whole vocabulary")
         if draft is not None and draft.cfg.lm_vocab and not draft_tp and not d_sub:
             raise ValueError("a vocabulary-parallel draft head needs draft_tp")
-        if cfg.k < 0 or cfg.k > 7:
-            raise ValueError("k must be in 0..7")
+        # a verify pass scores k+1 rows of a sequence in one workgroup column of the attention
+        # kernel: (k+1) * (query heads per KV head) <= 64; the fused acceptance walks <= 16 rows
+        k_max = min(15, 64 // (target.cfg.n_heads // target.cfg.n_kv_heads) - 1)
+        if cfg.k < 0 or cfg.k > k_max:
+            raise ValueError(f"k must be in 0..{k_max} for this target")
         if cfg.acceptance_method not in ("rejection_sampler", "typical_acceptance_sampler"):
             raise ValueError(f"unknown acceptance_method {cfg.acceptance_method!r}")
         self.typical = cfg.acceptance_method == "typical_acceptance_sampler"
