@@ -111,6 +111,15 @@ int sd_softmax_rows(const float* logits, int64_t ld, float temperature,
 int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
                    int64_t* ids, int R, int V, sd_stream_t stream);
 
+/* sd_softmax_rows(_split) with one temperature per sequence (per-request SamplingParams.
+ * temperature): row r uses temperatures[r / rows_per_seq] (device, f32).  A temperature of 0 asks
+ * for the greedy distribution: probability 1 on the first maximum of the row, so that the
+ * acceptance kernels treat a greedy request exactly like token matching.  scratch == NULL: one
+ * workgroup per row; else the split form (sd_sampling_scratch_bytes(R) bytes).          */
+int sd_softmax_rows_seq(const float* logits, int64_t ld, const float* temperatures,
+                        int rows_per_seq, float* probs, int64_t ld_probs, int R, int V,
+                        void* scratch, sd_stream_t stream);
+
 /* Split forms of the three vocabulary-wide steps of the sampling path: each row
  * is cut into 64 slices worked on by one workgroup each (a handful of rows
  * otherwise occupies a handful of CUs), a per-row step finishes.  Same results

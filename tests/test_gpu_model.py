@@ -559,6 +559,40 @@ def test_a_seeded_request_samples_the_same_tokens_alone_and_in_a_batch(use_graph
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+def test_requests_with_their_own_temperatures_share_a_batch(use_graph):
+    """A sampling engine serves every request at its own temperature: a greedy request (0) gets
+    the greedy autoregressive stream, seeded requests at 0.8 and 1.3 get the streams they get
+    alone on an engine of that temperature."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    pa, pb, pc = [5, 9, 200, 31, 7], list(range(40, 60)), [3, 1, 4, 1, 5, 9, 2, 6]
+    greedy = _generate(_engine(tw, None, 0), [pa], 30)[0]
+
+    def alone(prompt, seed, T):
+        eng = _engine(tw, dw, 3, max_batch=1, temperature=T, use_graph=use_graph)
+        out = [eng.add_request(0, prompt, seed=seed)]
+        while len(out) < 30:
+            out += eng.step()[0]
+        return out[:30]
+
+    b08, c13 = alone(pb, 7, 0.8), alone(pc, 9, 1.3)
+    assert b08 != alone(pb, 7, 1.3)                                  # the temperature matters
+    eng = _engine(tw, dw, 3, max_batch=3, temperature=0.8, use_graph=use_graph)
+    outs = [[eng.add_request(0, pa, temperature=0.0)], [eng.add_request(1, pb, seed=7)],
+            [eng.add_request(2, pc, seed=9, temperature=1.3)]]
+    while min(len(o) for o in outs) < 30:
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    assert outs[0][:30] == greedy and outs[1][:30] == b08 and outs[2][:30] == c13
+    with pytest.raises(ValueError):
+        _engine(tw, dw, 3).add_request(0, pa, temperature=0.7)       # a greedy engine cannot sample
+    with pytest.raises(ValueError):
+        eng.add_requests([pa], temperatures=[-1.0])
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_typical_acceptance_engine_known_answers(use_graph):
     """Typical acceptance at its two extremes.  A threshold nothing can exceed rejects every
     proposal and emits the target's most likely token: the stream after the (sampled) first

@@ -363,3 +363,32 @@ def test_per_sequence_uniform_streams_match_the_host_hash():
     assert all(v == -1.0 for v in got[sum(sizes):])                # nothing past the regions
     vals = [got[off + i * sj + b * sb] for off, n, sj, sb in regions for i in range(n) for b in range(n_active)]
     assert all(0.0 <= v < 1.0 for v in vals) and len(set(vals)) > len(vals) - 3
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_softmax_with_one_temperature_per_sequence(split):
+    """Row r is softened by temperatures[r // rows_per_seq]; a temperature of 0 puts all mass on
+    the row's first maximum (ties included), in both launch forms."""
+    from vllm_omni_draft_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n_seq, per, V = 5, 3, 50272
+    logits = torch.randn(n_seq * per, V, generator=g) * 3.0
+    logits[4, 100] = logits[4, 40000] = logits[4].max() + 1.0        # a tie inside a greedy sequence
+    logits[5, V - 1] = logits[5].max() + 2.0                          # maximum in the last slice
+    temps = torch.tensor([0.7, 0.0, 1.0, 2.5, 0.0])
+    scratch = ops.sampling_scratch(n_seq * per, "cuda") if split else None
+    out = ops.softmax_rows(logits.cuda(), temps.cuda(), rows_per_seq=per, scratch=scratch).cpu()
+    for r in range(n_seq * per):
+        T = temps[r // per].item()
+        if T > 0:
+            ref = torch.softmax(logits[r].double() / T, dim=0).float()
+            torch.testing.assert_close(out[r], ref, rtol=2e-5, atol=1e-9)
+        else:
+            want = torch.zeros(V)
+            want[int(logits[r].argmax())] = 1.0                       # torch returns the first maximum
+            assert torch.equal(out[r], want), r
+    assert out[4, 100] == 1.0 and out[4, 40000] == 0.0 and out[5, V - 1] == 1.0
+    # strided rows (a draft pass's "last row of every sequence") with one row per sequence
+    sub = ops.softmax_rows(logits.cuda(), temps.cuda(), row_offset=2, row_step=3, scratch=scratch).cpu()
+    for b in range(n_seq):
+        assert torch.equal(sub[b], out[3 * b + 2]) or temps[b] != temps[(3 * b + 2) // per]

@@ -273,6 +273,39 @@ def test_fp8_draft_under_a_bf16_target_keeps_the_target_stream():
             wb.load_model()
 
 
+def test_worker_serves_requests_at_their_own_temperature_and_seed():
+    """SamplingParams.temperature and .seed per request through the worker: on a sampling worker
+    a temperature-0 request gets the greedy stream and a seeded request the same tokens whether
+    it runs alone or beside others; a greedy worker refuses a request that wants to sample."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SamplingParams,
+                                                        SequenceGroupMetadata)
+    tcfg = MODELS["llama"]
+    dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    pa, pb = [5, 9, 200, 31, 7], list(range(40, 60))
+    greedy = _generate(_engine(tw, None, 0), [pa], 24)[0]
+
+    def run(worker, reqs):
+        out = worker.execute_model(ExecuteModelRequest(
+            [SequenceGroupMetadata(r, True, p, SamplingParams(**sp)) for r, p, sp in reqs]))
+        got = {r: list(t) for r, t in zip(out.req_ids, out.sampled_token_ids)}
+        while min(len(t) for t in got.values()) < 24:
+            out = worker.execute_model(ExecuteModelRequest(
+                [SequenceGroupMetadata(r, False) for r, _, _ in reqs]))
+            for r, t in zip(out.req_ids, out.sampled_token_ids):
+                got[r] += t
+        return {r: t[:24] for r, t in got.items()}
+
+    alone = run(_worker(tw, dw, 3, True, max_num_seqs=1, temperature=0.8),
+                [("b", pb, dict(seed=7, temperature=1.2))])["b"]
+    both = run(_worker(tw, dw, 3, True, max_num_seqs=2, temperature=0.8),
+               [("a", pa, dict(temperature=0.0)), ("b", pb, dict(seed=7, temperature=1.2))])
+    assert both["a"] == greedy and both["b"] == alone
+    with pytest.raises(ValueError):
+        run(_worker(tw, dw, 3, True, max_num_seqs=1), [("a", pa, dict(temperature=0.8))])
+
+
 def _llama_pair():
     tcfg = MODELS["llama"]
     dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})

@@ -1,6 +1,8 @@
 """The allocation-free attention entry point (sd_paged_attention_static) against the entry
 point it is a variant of (sd_paged_attention with a caller workspace): bit-identical output
 on two calls in a row, the second with a smaller input, through the C ABI."""
+import gc
+
 import pytest
 import torch
 
@@ -18,12 +20,20 @@ def _case(ops, B, ctx_lens, q_len, Hq, Hkv, D, split, seed):
     ref = ops.paged_attention(q, kc, vc, bt, seq_lens, 0, B, q_len, Hq, Hkv, D, D ** -0.5, max_ctx,
                               split)
     out = torch.full_like(ref, float("nan"))
+    # Garbage of earlier tests (engines with reference cycles) must not be collected while the
+    # allocator is being watched: a collection in between frees device memory and changes the count.
+    gc.collect()
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
-    ops.paged_attention_static(q, kc, vc, bt, seq_lens, 0, B, q_len, Hq, Hkv, D, D ** -0.5, max_ctx,
-                               split, out)
-    torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before      # torch's allocator was not touched
+    gc.disable()
+    try:
+        before = torch.cuda.memory_allocated()
+        ops.paged_attention_static(q, kc, vc, bt, seq_lens, 0, B, q_len, Hq, Hkv, D, D ** -0.5,
+                                   max_ctx, split, out)
+        torch.cuda.synchronize()
+        after = torch.cuda.memory_allocated()
+    finally:
+        gc.enable()
+    assert after == before                               # torch's allocator was not touched
     assert torch.equal(out, ref)
 
 

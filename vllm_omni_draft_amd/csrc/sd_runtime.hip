@@ -204,7 +204,6 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   void* act = base + w.act;
   void* attn_ws = base + w.attn_ws;
   const int H = d.hidden, D = d.head_dim, Hq = d.n_heads, Hkv = d.n_kv_heads, F = d.ffn;
-  const int64_t qkv_cols = (int64_t)(Hq + 2 * Hkv) * D;
   const bool llama = d.arch == SD_ARCH_LLAMA;
 
   if (a->input_embeds) {

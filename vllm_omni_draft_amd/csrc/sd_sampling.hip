@@ -5,6 +5,8 @@
 // The accept mask of a sequence is one wavefront ballot: lane i tests position
 // i, lanes past the proposal length vote "accepted", and the first rejected
 // position is the lowest clear bit of the 64-bit mask.
+#include <climits>
+
 #include "sd_common.h"
 
 namespace {
@@ -362,14 +364,37 @@ __global__ __launch_bounds__(kSampleThreads) void argmax_rows_kernel(
   if (threadIdx.x == 0) ids[r] = idx;
 }
 
+// Temperature of row r: the scalar, or (temps != null) that of sequence r / rows_per_seq.  A
+// temperature of 0 asks for the greedy distribution: all mass on the first maximum of the row.
+struct RowTemps {
+  const float* temps;
+  int rows_per_seq;
+  float inv_t;
+};
+__device__ __forceinline__ float row_inv_t(const RowTemps& t, int r, bool& greedy) {
+  greedy = false;
+  if (!t.temps) return t.inv_t;
+  const float T = t.temps[r / t.rows_per_seq];
+  greedy = !(T > 0.f);
+  return greedy ? 1.f : 1.f / T;
+}
+
 __global__ __launch_bounds__(kSampleThreads) void softmax_rows_kernel(
-    const float* __restrict__ logits, int64_t ld, float inv_t,
+    const float* __restrict__ logits, int64_t ld, RowTemps tm,
     float* __restrict__ probs, int64_t ld_probs, int V) {
   __shared__ float s_f[kSampleWaves];
+  __shared__ int s_i[kSampleWaves];
   __shared__ double s_d[kSampleWaves];
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + (size_t)r * ld;
   float* out = probs + (size_t)r * ld_probs;
+  bool greedy;
+  const float inv_t = row_inv_t(tm, r, greedy);
+  if (greedy) {   // block-uniform
+    const int best = block_argmax(row, V, s_f, s_i);
+    for (int i = tid; i < V; i += blockDim.x) out[i] = i == best ? 1.f : 0.f;
+    return;
+  }
   float mx = -INFINITY;
   for (int i = tid; i < V; i += blockDim.x) mx = fmaxf(mx, row[i] * inv_t);
   mx = wave_max(mx);
@@ -429,13 +454,15 @@ __device__ __forceinline__ double part_block_sum(double v, double* smem) {
 }
 
 __global__ __launch_bounds__(kPartThreads) void softmax_partial_kernel(
-    const float* __restrict__ logits, int64_t ld, float inv_t, RowScratch sc, int V) {
+    const float* __restrict__ logits, int64_t ld, RowTemps tm, RowScratch sc, int V) {
   __shared__ float s_f[kPartThreads / 64];
   __shared__ double s_d[kPartThreads / 64];
   const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
   int lo, hi;
   part_range(part, V, lo, hi);
   const float* row = logits + (size_t)r * ld;
+  bool greedy;
+  const float inv_t = row_inv_t(tm, r, greedy);   // greedy rows: slice maxima of the raw logits
   float mx = -INFINITY;
   for (int i = lo + tid; i < hi; i += kPartThreads) mx = fmaxf(mx, row[i] * inv_t);
   mx = wave_max(mx);
@@ -454,12 +481,34 @@ __global__ __launch_bounds__(kPartThreads) void softmax_partial_kernel(
 }
 
 __global__ __launch_bounds__(kPartThreads) void softmax_finish_kernel(
-    const float* __restrict__ logits, int64_t ld, float inv_t, RowScratch sc,
+    const float* __restrict__ logits, int64_t ld, RowTemps tm, RowScratch sc,
     float* __restrict__ probs, int64_t ld_probs, int V) {
   const int part = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
+  bool greedy;
+  const float inv_t = row_inv_t(tm, r, greedy);
   // every thread folds the row's 64 slice statistics the same way
   float mx = -INFINITY;
   for (int p = 0; p < kRowParts; ++p) mx = fmaxf(mx, sc.pmax[(size_t)r * kRowParts + p]);
+  if (greedy) {   // all mass on the first maximum: the lowest slice that holds it, lowest index
+    __shared__ int s_first[kPartThreads / 64];
+    int first_part = 0;
+    while (first_part < kRowParts - 1 && sc.pmax[(size_t)r * kRowParts + first_part] != mx) ++first_part;
+    int lo, hi;
+    part_range(part, V, lo, hi);
+    const float* row = logits + (size_t)r * ld;
+    float* out = probs + (size_t)r * ld_probs;
+    int mine = INT_MAX;
+    if (part == first_part)
+      for (int i = lo + tid; i < hi; i += kPartThreads)
+        if (row[i] == mx) mine = min(mine, i);
+    for (int o = 32; o > 0; o >>= 1) mine = min(mine, __shfl_xor(mine, o, 64));
+    if ((tid & 63) == 0) s_first[tid >> 6] = mine;
+    __syncthreads();
+    int best = s_first[0];
+    for (int w = 1; w < kPartThreads / 64; ++w) best = min(best, s_first[w]);
+    for (int i = lo + tid; i < hi; i += kPartThreads) out[i] = i == best ? 1.f : 0.f;
+    return;
+  }
   double total = 0.0;
   for (int p = 0; p < kRowParts; ++p) {
     const float pm = sc.pmax[(size_t)r * kRowParts + p];
@@ -1115,8 +1164,34 @@ extern "C" int sd_softmax_rows(const float* logits, int64_t ld, float temperatur
              (double)temperature);
   if (R == 0) return SD_OK;
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(kSampleThreads), 0,
-                     (hipStream_t)stream, logits, ld, 1.0f / temperature, probs, ld_probs, V);
+                     (hipStream_t)stream, logits, ld, RowTemps{nullptr, 1, 1.0f / temperature}, probs,
+                     ld_probs, V);
   SD_CHECK_LAUNCH("sd_softmax_rows");
+  return SD_OK;
+}
+
+extern "C" int sd_softmax_rows_seq(const float* logits, int64_t ld, const float* temperatures,
+                                   int rows_per_seq, float* probs, int64_t ld_probs, int R, int V,
+                                   void* scratch, sd_stream_t stream) {
+  SD_REQUIRE(R >= 0 && V >= 1 && ld >= V && ld_probs >= V && logits && probs && temperatures &&
+                 rows_per_seq >= 1,
+             SD_ERR_INVALID, "sd_softmax_rows_seq: bad arguments (R=%d V=%d rows_per_seq=%d)", R, V,
+             rows_per_seq);
+  if (R == 0) return SD_OK;
+  const RowTemps tm{temperatures, rows_per_seq, 1.f};
+  if (!scratch) {
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(kSampleThreads), 0, (hipStream_t)stream,
+                       logits, ld, tm, probs, ld_probs, V);
+    SD_CHECK_LAUNCH("sd_softmax_rows_seq");
+    return SD_OK;
+  }
+  const RowScratch sc = row_scratch(scratch, R);
+  hipLaunchKernelGGL(softmax_partial_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
+                     (hipStream_t)stream, logits, ld, tm, sc, V);
+  SD_CHECK_LAUNCH("sd_softmax_rows_seq");
+  hipLaunchKernelGGL(softmax_finish_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
+                     (hipStream_t)stream, logits, ld, tm, sc, probs, ld_probs, V);
+  SD_CHECK_LAUNCH("sd_softmax_rows_seq");
   return SD_OK;
 }
 
@@ -1146,11 +1221,12 @@ extern "C" int sd_softmax_rows_split(const float* logits, int64_t ld, float temp
              (double)temperature);
   if (R == 0) return SD_OK;
   const RowScratch sc = row_scratch(scratch, R);
+  const RowTemps tm{nullptr, 1, 1.0f / temperature};
   hipLaunchKernelGGL(softmax_partial_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
-                     (hipStream_t)stream, logits, ld, 1.0f / temperature, sc, V);
+                     (hipStream_t)stream, logits, ld, tm, sc, V);
   SD_CHECK_LAUNCH("sd_softmax_rows_split");
   hipLaunchKernelGGL(softmax_finish_kernel, dim3(kRowParts, R), dim3(kPartThreads), 0,
-                     (hipStream_t)stream, logits, ld, 1.0f / temperature, sc, probs, ld_probs, V);
+                     (hipStream_t)stream, logits, ld, tm, sc, probs, ld_probs, V);
   SD_CHECK_LAUNCH("sd_softmax_rows_split");
   return SD_OK;
 }

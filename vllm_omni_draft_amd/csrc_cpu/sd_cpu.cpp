@@ -495,6 +495,22 @@ extern "C" int sd_sample_rows(const float* probs, int64_t ld, const float* u, in
 }
 
 extern "C" size_t sd_sampling_scratch_bytes(int R) { return R > 0 ? 64 : 0; }
+extern "C" int sd_softmax_rows_seq(const float* logits, int64_t ld, const float* temps, int rows_per_seq,
+                                   float* probs, int64_t ldp, int R, int V, void*, sd_stream_t s) {
+  REQUIRE(logits && probs && temps && R >= 0 && V >= 1 && rows_per_seq >= 1, SD_ERR_INVALID,
+          "sd_softmax_rows_seq: bad arguments");
+  for (int r = 0; r < R; ++r) {
+    const float T = temps[r / rows_per_seq];
+    if (T > 0.f) {
+      const int rc = sd_softmax_rows(logits + (size_t)r * ld, ld, T, probs + (size_t)r * ldp, ldp, 1, V, s);
+      if (rc) return rc;
+    } else {
+      const int best = first_argmax(logits + (size_t)r * ld, V);
+      for (int i = 0; i < V; ++i) probs[(size_t)r * ldp + i] = i == best ? 1.f : 0.f;
+    }
+  }
+  return SD_OK;
+}
 extern "C" int sd_softmax_rows_split(const float* l, int64_t ld, float t, float* p, int64_t ldp, int R,
                                      int V, void*, sd_stream_t s) {
   return sd_softmax_rows(l, ld, t, p, ldp, R, V, s);

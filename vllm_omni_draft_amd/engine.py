@@ -305,6 +305,8 @@ class SpecEngine:
             # every sequence draws from a stream of its own (its request's seed, or one derived
             # from cfg.seed and the order of admission): what a sequence samples does not depend
             # on its batch mates
+            # one temperature per sequence (its request's, or cfg.temperature); 0 = greedy
+            self.temps = torch.full((B,), float(cfg.temperature), **f32)
             self.u_seeds = torch.zeros(B, dtype=torch.int64, device=dev)
             self.u_counters = torch.zeros(B, dtype=torch.int64, device=dev)
             self.host_seeds: List[int] = [0] * B
@@ -375,7 +377,7 @@ class SpecEngine:
                     input_embeds: Optional[torch.Tensor] = None,
                     rope_positions: Optional[torch.Tensor] = None,
                     truth_row: Optional[Sequence[int]] = None,
-                    seed: Optional[int] = None) -> int:
+                    seed: Optional[int] = None, temperature: Optional[float] = None) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
         first token from the target and returns it (this synchronises).
         Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
@@ -386,14 +388,27 @@ class SpecEngine:
         token stream from position 0, stored in the slot's row of the truth table.  seed
         (sampling): the request's own random stream; the tokens it samples are then the same
         whatever else is in the batch (None: a stream derived from EngineConfig.seed and the
-        order of admission)."""
+        order of admission).  temperature (sampling engines): the request's own temperature,
+        0 for a greedy request among sampling ones (None: EngineConfig.temperature)."""
         with _rt.stream_ctx(self.stream):
             if truth_row is not None:
                 if self.truth is None:
                     raise ValueError("truth_row needs set_synthetic_acceptance first")
                 row = torch.tensor(list(truth_row)[:self.truth.shape[1]], dtype=torch.int32)
                 self.truth[slot, :row.numel()].copy_(row)
+            self._set_temperature(slot, temperature)
             return self._add_request(slot, prompt, input_embeds, rope_positions, seed)
+
+    def _set_temperature(self, slot: int, temperature: Optional[float]) -> None:
+        if self.sampling:
+            t = self.cfg.temperature if temperature is None else float(temperature)
+            if not t >= 0.0:
+                raise ValueError(f"temperature {temperature} must be >= 0")
+            if 0 <= slot < self.cfg.max_batch:
+                self.temps[slot] = t
+        elif temperature not in (None, 0, 0.0):
+            raise ValueError("a greedy engine (EngineConfig.temperature == 0) cannot sample; build "
+                             "the engine with a temperature > 0 to mix sampling and greedy requests")
 
     def _seed_slot(self, slot: int, seed: Optional[int]) -> float:
         """Gives batch slot `slot` its random stream; returns the uniform of its first token."""
@@ -457,7 +472,7 @@ class SpecEngine:
         if self.sampling:
             self._target_full_rows(1)
             u = torch.tensor([self._seed_slot(slot, seed)], dtype=torch.float32).to(self.device)
-            probs = ops.softmax_rows(self.t_logits[:1], self.cfg.temperature)
+            probs = ops.softmax_rows(self.t_logits[:1], self.temps[slot:slot + 1])
             first = ops.sample_rows(probs, u)
         else:
             first = self._target_argmax(1, torch.empty(1, dtype=torch.int64, device=self.device))
@@ -476,7 +491,8 @@ class SpecEngine:
 
     def add_requests(self, prompts: Sequence[Sequence[int]],
                      truth_rows: Optional[Sequence[Sequence[int]]] = None,
-                     seeds: Optional[Sequence[Optional[int]]] = None) -> List[int]:
+                     seeds: Optional[Sequence[Optional[int]]] = None,
+                     temperatures: Optional[Sequence[Optional[float]]] = None) -> List[int]:
         """Prefills several text prompts in the same passes and returns their first tokens (one
         synchronisation for all of them).  The prompts take the next free slots in order.
         Every pass carries a chunk of each prompt (prefill_rows // len(prompts) tokens per
@@ -493,6 +509,10 @@ class SpecEngine:
                     self.truth[self.active + i, :row.numel()].copy_(row)
             if seeds is not None and len(seeds) != len(prompts):
                 raise ValueError("one seed (or None) per prompt")
+            if temperatures is not None and len(temperatures) != len(prompts):
+                raise ValueError("one temperature (or None) per prompt")
+            for i in range(len(prompts)):
+                self._set_temperature(self.active + i, None if temperatures is None else temperatures[i])
             return self._add_requests([list(p) for p in prompts], seeds)
 
     def _add_requests(self, prompts: List[List[int]], seeds=None) -> List[int]:
@@ -551,7 +571,7 @@ class SpecEngine:
             self._target_full_rows(Bp)
             u = torch.tensor([self._seed_slot(slot0 + i, None if seeds is None else seeds[i])
                               for i in range(Bp)], dtype=torch.float32).to(self.device)
-            probs = ops.softmax_rows(self.t_logits[:Bp], self.cfg.temperature)
+            probs = ops.softmax_rows(self.t_logits[:Bp], self.temps[slot0:slot0 + Bp])
             first = ops.sample_rows(probs, u)
         else:
             first = self._target_argmax(Bp, torch.empty(Bp, dtype=torch.int64, device=self.device))
@@ -690,7 +710,7 @@ class SpecEngine:
                       self.t_out)
         if self.sampling:
             self._target_full_rows(B)
-            ops.softmax_rows(self.t_logits[:B], self.cfg.temperature, out=self.t_probs.view(-1, self.V),
+            ops.softmax_rows(self.t_logits[:B], self.temps[:B], out=self.t_probs.view(-1, self.V),
                              scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
@@ -717,7 +737,7 @@ class SpecEngine:
                       self.t_out)
         if self.sampling:
             self._target_full_rows(B)
-            ops.softmax_rows(self.t_logits[:B], self.cfg.temperature,
+            ops.softmax_rows(self.t_logits[:B], self.temps[:B],
                              out=self.t_probs.view(-1, self.V)[:B], scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
@@ -754,7 +774,7 @@ class SpecEngine:
                     ops.map_tokens(self.tok_buf[:B], 2 + i, self.d_map)
                 continue
             if self.sampling:
-                ops.softmax_rows(rows, self.cfg.temperature, row_offset=off, row_step=step,
+                ops.softmax_rows(rows, self.temps[:B], row_offset=off, row_step=step,
                                  out_ptr=self.d_probs.data_ptr() + i * self.V * 4, out_ld=k * self.V,
                                  scratch=self.samp_scratch)
                 ops.sample_rows(self.d_probs.view(-1, self.V)[:B * k], self.u_draft[i],
@@ -864,7 +884,7 @@ class SpecEngine:
             self._target_partials(B * (k + 1))
         elif self.sampling:
             self._target_full_rows(B * (k + 1))
-            ops.softmax_rows(rows, self.cfg.temperature, out=self.t_probs.view(-1, self.V),
+            ops.softmax_rows(rows, self.temps[:B], rows_per_seq=k + 1, out=self.t_probs.view(-1, self.V),
                              scratch=self.samp_scratch)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
                             out=self.bonus_ids, row_offset=k, row_step=k + 1,
@@ -915,7 +935,7 @@ class SpecEngine:
                 moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta,
                          self.force_ctr]
                 if self.sampling:
-                    moved += [self.u_seeds, self.u_counters]
+                    moved += [self.u_seeds, self.u_counters, self.temps]
                     self.host_seeds[slot] = self.host_seeds[last]
                 if self.truth is not None:
                     moved.append(self.truth)

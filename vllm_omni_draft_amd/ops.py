@@ -148,16 +148,30 @@ def argmax_rows(logits: torch.Tensor, out: Optional[torch.Tensor] = None, *, row
     return out
 
 
-def softmax_rows(logits: torch.Tensor, temperature: float = 1.0, out=None, *, row_offset=0,
-                 row_step=1, out_ptr=None, out_ld=None, scratch=None) -> torch.Tensor:
+def softmax_rows(logits: torch.Tensor, temperature=1.0, out=None, *, row_offset=0,
+                 row_step=1, out_ptr=None, out_ld=None, scratch=None,
+                 rows_per_seq: int = 1) -> torch.Tensor:
     """softmax(logits / T) of rows row_offset, row_offset+row_step, ...; the
-    result goes to `out` ([R, V]) or to raw address out_ptr with row stride out_ld."""
+    result goes to `out` ([R, V]) or to raw address out_ptr with row stride out_ld.
+    temperature: a number, or a float32 device tensor with one temperature per sequence
+    (processed row r belongs to sequence r // rows_per_seq; 0 = all mass on the row's first
+    maximum)."""
     _need(logits, torch.float32, "logits")
     R_all, V = logits.shape
     R = (R_all - row_offset + row_step - 1) // row_step
     if out is None and out_ptr is None:
         out = torch.empty(R, V, dtype=torch.float32, device=logits.device)
     dst = out_ptr if out_ptr is not None else out.data_ptr()
+    if isinstance(temperature, torch.Tensor):
+        _need(temperature, torch.float32, "temperature")
+        if rows_per_seq < 1 or temperature.numel() * rows_per_seq < R:
+            raise _lib.SdError("softmax_rows: fewer temperatures than sequences")
+        if scratch is not None:
+            _scratch_ok(scratch, R, "softmax_rows")
+        _lib.check(_lib.load().sd_softmax_rows_seq(
+            logits.data_ptr() + row_offset * V * 4, V * row_step, _p(temperature), rows_per_seq, dst,
+            out_ld or V, R, V, _p(scratch), _stream()), "sd_softmax_rows_seq")
+        return out
     if scratch is not None:
         _scratch_ok(scratch, R, "softmax_rows")
         _lib.check(_lib.load().sd_softmax_rows_split(

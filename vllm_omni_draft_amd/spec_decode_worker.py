@@ -35,8 +35,10 @@ from .weights import ModelWeights
 # --------------------------------------------------------------------------- carriers
 @dataclass
 class SamplingParams:
-    # None: the worker's temperature.  One temperature serves the whole batch (the step is one
-    # captured graph); a request that asks for another one is refused, not silently served.
+    # None: the worker's temperature.  A sampling worker (SpecDecodeConfig.temperature > 0) serves
+    # every request at its own temperature, greedy requests (0) included: the step's softmax
+    # kernels read one temperature per sequence.  A greedy worker has no sampling buffers and
+    # refuses a request that asks to sample.
     temperature: Optional[float] = None
     # Stop conditions belong to the caller's scheduler (scheduler.SpecDecodeScheduler enforces
     # max_tokens and the end-of-sequence token); the worker emits tokens until a request is
@@ -612,9 +614,14 @@ class SpecDecodeWorker:
             seen.add(g.request_id)
         for g in prompts:
             sp = g.sampling_params
-            if sp.temperature is not None and have is not None and float(sp.temperature) != float(have):
-                raise ValueError(f"request {g.request_id} asks for temperature {sp.temperature}; this "
-                                 f"worker runs every sequence at {have}")
+            if sp.temperature is not None and have is not None:
+                t = float(sp.temperature)
+                if not t >= 0.0:
+                    raise ValueError(f"request {g.request_id}: temperature {sp.temperature} < 0")
+                if t != float(have) and not getattr(eng, "sampling", False):
+                    raise ValueError(f"request {g.request_id} asks for temperature {sp.temperature}; "
+                                     f"this worker decodes greedily (build it with a temperature > 0 "
+                                     f"to serve sampling and greedy requests together)")
             if sp.seed is not None and not isinstance(sp.seed, int):
                 raise ValueError(f"request {g.request_id}: seed must be an integer")
             if g.request_id in self._slot_of and g.request_id not in finished:
@@ -662,11 +669,13 @@ class SpecDecodeWorker:
             seeded = bool(getattr(eng, "sampling", False))    # greedy engines have no use for seeds
             if j - i >= 2:
                 group = prompts[i:j]
-                kw = dict(seeds=[g.sampling_params.seed for g in group]) if seeded else {}
+                kw = dict(seeds=[g.sampling_params.seed for g in group],
+                          temperatures=[g.sampling_params.temperature for g in group]) if seeded else {}
                 firsts = eng.add_requests([g.prompt_token_ids for g in group], **kw)
             else:
                 group = prompts[i:i + 1]
-                kw = dict(seed=group[0].sampling_params.seed) if seeded else {}
+                kw = dict(seed=group[0].sampling_params.seed,
+                          temperature=group[0].sampling_params.temperature) if seeded else {}
                 firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
                                           **mm_inputs[group[0].request_id], **kw)]
             for g, first in zip(group, firsts):
