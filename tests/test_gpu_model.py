@@ -100,6 +100,55 @@ def test_forward_logits_match_oracle(name):
     assert agree > 0.9
 
 
+_LLAMA3_SCALING = {"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0, "high_freq_factor": 4.0,
+                   "original_max_position_embeddings": 8192}
+FULL_WIDTH = {
+    # BASELINE configs[1]: Llama-3-8B target, Llama-3.2-1B draft
+    "llama3-8b+1b": (
+        OracleConfig(arch="llama", n_layers=2, hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128,
+                     ffn=14336, vocab=128256, rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
+                     max_pos=512, tie_embeddings=True),
+        OracleConfig(arch="llama", n_layers=2, hidden=2048, n_heads=32, n_kv_heads=8, head_dim=64,
+                     ffn=8192, vocab=128256, rope_theta=500000.0, rope_scaling=_LLAMA3_SCALING,
+                     max_pos=512, tie_embeddings=True), False),
+    # BASELINE configs[2]: Qwen2.5-7B target (7 query heads per KV head, QKV biases), 0.5B draft
+    "qwen2.5-7b+0.5b": (
+        OracleConfig(arch="llama", n_layers=2, hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128,
+                     ffn=18944, vocab=152064, norm_eps=1e-6, rope_theta=1e6, max_pos=512,
+                     tie_embeddings=True),
+        OracleConfig(arch="llama", n_layers=2, hidden=896, n_heads=14, n_kv_heads=2, head_dim=64,
+                     ffn=4864, vocab=152064, norm_eps=1e-6, rope_theta=1e6, max_pos=512,
+                     tie_embeddings=True), True),
+}
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("pair", list(FULL_WIDTH))
+def test_full_width_layers_against_the_oracle(pair, wide):
+    """The named configurations' layer shapes at full width (hidden size, head grouping, ffn,
+    vocabulary, rope variant, biases), two layers of each so that the CPU oracle can follow, on
+    both kernel families: logits of prompt chunks, decode tokens and a 6-row verify pass against
+    the oracle, and greedy speculative == autoregressive through the engine."""
+    tcfg, dcfg, bias = FULL_WIDTH[pair]
+    tstate = _bf(random_state(tcfg, seed=31, qkv_bias=bias))
+    tw = _product(tcfg, tstate, qkv_bias=bias)
+    toks = torch.randint(0, tcfg.vocab, (20,), generator=torch.Generator().manual_seed(9)).tolist()
+    got = _logits_via_engine(tw, toks, [8, 1, 1, 6, 4], wide=wide)
+    lm = OracleLM(tcfg, tstate, bf16_acts=True)
+    ref = lm.forward(toks, 0, lm.new_cache())
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 0.03 * scale, (got - ref).abs().max().item() / scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.8
+    del lm, ref, tstate
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=32, qkv_bias=bias)), qkv_bias=bias)
+    rows = "wide" if wide else "narrow"
+    ar = _generate(_engine(tw, None, 0, rows=rows), [toks], 24)[0]
+    eng = _engine(tw, dw, 5, rows=rows)
+    assert _generate(eng, [toks], 24)[0] == ar
+    m = eng.metrics()
+    assert m["draft"] > 0 and m["emitted"] >= 24 - 1
+
+
 @pytest.mark.parametrize("name", list(MODELS))
 def test_wide_forward_logits_match_oracle_and_are_chunk_invariant(name):
     """The 17..256-row kernel family: same oracle bar, and a token's logits do not depend on
