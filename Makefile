@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := vllm_omni_draft_amd/csrc
-SRCS  := $(CSRC)/sd_runtime.hip $(CSRC)/sd_sampling.hip $(CSRC)/sd_linear.hip $(CSRC)/sd_linear_wide.hip $(CSRC)/sd_attention.hip
+SRCS  := $(CSRC)/sd_runtime.hip $(CSRC)/sd_sampling.hip $(CSRC)/sd_linear.hip $(CSRC)/sd_linear_wide.hip $(CSRC)/sd_attention.hip $(CSRC)/sd_ipc.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vllm_omni_draft_amd/libsd_amd.so
 EXTRA ?=

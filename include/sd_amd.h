@@ -595,6 +595,39 @@ int sd_model_forward(sd_model* m, const sd_kv_cache* kv,
                      size_t workspace_bytes, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * One-shot collectives over peer-mapped device memory (xGMI inside a node) for the small
+ * messages of a tensor-parallel verify pass (rows x hidden bf16: 96 KB at 70B / 6 rows), where
+ * a ring's 2(N-1) dependent steps cost more than every rank reading every peer once.
+ * (Upstream: vLLM's custom_all_reduce for small messages; not in the reference tree.)
+ *
+ * Every rank creates one exchange buffer (sd_ipc_buffer_create: fine-grained device memory +
+ * its 64-byte IPC handle), the host code passes the handles around (any channel; the Python
+ * host uses torch.distributed), every rank maps its peers' buffers (sd_ipc_buffer_open) and
+ * builds a communicator over the world_size pointers (own buffer at index rank).  A call
+ * publishes the message in the rank's buffer, raises per-slice flags, waits for the peers'
+ * flags and combines the ranks' data IN RANK ORDER, so every rank ends with the same bits.
+ * Calls are stream-ordered kernels only (capturable); call counters live in device memory.
+ * Every rank must make the same sequence of calls.  A peer that does not arrive within ~4 s
+ * makes the waiting workgroup give up (garbage result, sd_ipc_comm_errors > 0), never a hang.
+ * Limits: <= 8 ranks, messages <= max_message_bytes <= 16 MiB, multiples of 16 bytes.
+ * sd_ipc_allreduce is an sd_allreduce_fn (ctx = the sd_ipc_comm*); sd_ipc_allgather has
+ * sd_tp_allgather's meaning.                                                            */
+#define SD_IPC_HANDLE_BYTES 64
+typedef struct sd_ipc_comm sd_ipc_comm;
+size_t sd_ipc_buffer_bytes(size_t max_message_bytes);
+int sd_ipc_buffer_create(size_t bytes, void** ptr, void* handle_out);
+int sd_ipc_buffer_open(const void* handle, void** ptr);
+int sd_ipc_buffer_close(void* ptr);   /* a peer's mapping */
+int sd_ipc_buffer_destroy(void* ptr); /* the rank's own buffer */
+sd_ipc_comm* sd_ipc_comm_create(int rank, int world_size, void* const* bufs,
+                                size_t max_message_bytes);
+void sd_ipc_comm_destroy(sd_ipc_comm* comm);
+int sd_ipc_comm_errors(sd_ipc_comm* comm, int* n_timeouts); /* synchronises */
+int sd_ipc_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream);
+int sd_ipc_allgather(const void* send, void* recv, size_t bytes_per_rank, void* ctx,
+                     sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Tensor-parallel group over RCCL (one process per GPU; xGMI inside a node).
  * Replaces the NCCL tensor_model_parallel_all_reduce of the target model's
  * row-parallel layers.  Rank 0 makes an id, the host spreads its

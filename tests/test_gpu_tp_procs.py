@@ -26,6 +26,17 @@ def test_two_process_tensor_parallel_engines(tmp_path):
     # sharding only changes rounding: most tokens equal the unsharded model's
     same = sum(a == b for x, y in zip(res[0]["gloo_ar"], res[0]["unsharded_ar"]) for a, b in zip(x, y))
     assert same >= 0.5 * sum(len(x) for x in res[0]["gloo_ar"])
+    # the one-shot IPC collectives: real cross-process exchanges inside kernels
+    for rr in res:
+        assert rr["ipc"] == "ran", rr["ipc"]
+        assert rr["ipc_allreduce_ok"] and rr["ipc_allgather_ok"] and rr["ipc_timeouts"] == 0
+    for graph in ("False", "True"):
+        assert res[0][f"ipc_stream_graph_{graph}"] == res[1][f"ipc_stream_graph_{graph}"]
+        assert res[0][f"ipc_stream_graph_{graph}"] == res[0][f"ipc_ar_graph_{graph}"]   # lossless
+        # two ranks: the IPC sum (f32 in rank order, rounded once) is the gloo path's sum
+        assert res[0][f"ipc_stream_graph_{graph}"] == res[0]["gloo_spec"]
+    assert res[0]["ipc_worker_stream"] == res[1]["ipc_worker_stream"] == res[0]["ipc_stream_graph_True"]
+    assert res[0]["ipc_worker_timeouts"] == 0 and res[1]["ipc_worker_timeouts"] == 0
     if res[0]["rccl_world2"] == "communicator created":
         for rr in res:
             assert rr["rccl_allreduce_ok"] and rr["rccl_allgather_ok"]

@@ -116,6 +116,72 @@ def main():
         res["rccl_world2"] = f"refused: {type(e).__name__}: {e}"
     dist.barrier()
 
+    # ---- 1b. the library's one-shot collectives over IPC-mapped device memory: two real
+    # processes, kernels that wait for each other's flags
+    try:
+        ipc = parallel.IpcTensorParallelGroup(rank, world, max_message_bytes=1 << 20)
+        dist.barrier()
+        ok = True
+        g = torch.Generator(device="cuda").manual_seed(100 + rank)
+        for n in (8, 64, 4096, 4104, 50000 * 8, 524288):          # 16 B .. 1 MiB, odd slice counts
+            mine = (torch.randn(n, generator=g, device="cuda") * 3).to(torch.bfloat16)
+            both = [torch.empty_like(mine) for _ in range(world)]
+            host = [t.cpu() for t in both]
+            dist.all_gather(host, mine.cpu())                       # reference through gloo
+            want = sum(h.float() for h in host).to(torch.bfloat16)
+            for rep in range(3):                                    # repeated calls: both data regions
+                t = mine.clone()
+                ipc.all_reduce(t)
+                torch.cuda.synchronize()
+                ok = ok and torch.equal(t.cpu(), want)
+        res["ipc_allreduce_ok"] = ok
+        send = torch.arange(256, dtype=torch.int32, device="cuda") + 1000 * rank
+        recv = torch.empty(256 * world, dtype=torch.int32, device="cuda")
+        for rep in range(3):
+            ipc.all_gather(send, recv)
+        torch.cuda.synchronize()
+        res["ipc_allgather_ok"] = recv.view(world, 256)[:, 0].tolist() == [1000 * q for q in range(world)] \
+            and recv.view(world, 256)[:, 255].tolist() == [1000 * q + 255 for q in range(world)]
+        for graph in (False, True):
+            eng = SpecEngine(tw, dw, EngineConfig(k=3, max_batch=2, max_seq_len=120, split_tokens=128,
+                                                  use_graph=graph), tp_group=ipc)
+            res[f"ipc_stream_graph_{graph}"] = generate(eng, prompts, 24)
+            eng_ar = SpecEngine(tw, None, EngineConfig(k=0, max_batch=2, max_seq_len=120, split_tokens=128,
+                                                       use_graph=graph), tp_group=ipc)
+            res[f"ipc_ar_graph_{graph}"] = generate(eng_ar, prompts, 24)
+            del eng, eng_ar
+        torch.cuda.synchronize()
+        res["ipc_timeouts"] = ipc.timeouts()
+        dist.barrier()
+        ipc.close()
+        # the same through the worker: it builds the group, shards both state dicts itself
+        from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
+                                                            SpecDecodeConfig, SpecDecodeWorker)
+        dstate = {k: v.to(torch.bfloat16) for k, v in random_state(dc, seed=8).items()}
+        w = SpecDecodeWorker(SpecDecodeConfig(
+            target=(cfg, state), draft=(cfg_of(dc), dstate), num_speculative_tokens=3, max_num_seqs=2,
+            max_model_len=120, split_tokens=128, tensor_parallel_size=world,
+            tensor_parallel_collective="ipc", tensor_parallel_graph=True), local_rank=0, rank=rank)
+        w.init_device()
+        w.load_model()
+        out = w.execute_model(ExecuteModelRequest(
+            [SequenceGroupMetadata(f"r{i}", True, p) for i, p in enumerate(prompts)]))
+        got = {r: list(t) for r, t in zip(out.req_ids, out.sampled_token_ids)}
+        while min(len(t) for t in got.values()) < 24:
+            out = w.execute_model(ExecuteModelRequest(
+                [SequenceGroupMetadata(f"r{i}", False) for i in range(len(prompts))]))
+            for r, t in zip(out.req_ids, out.sampled_token_ids):
+                got[r] += t
+        res["ipc_worker_stream"] = [got[f"r{i}"][:24] for i in range(len(prompts))]
+        torch.cuda.synchronize()
+        res["ipc_worker_timeouts"] = w.tp_group.timeouts()
+        dist.barrier()
+        del w
+        res["ipc"] = "ran"
+    except Exception as e:  # noqa: BLE001
+        res["ipc"] = f"failed: {type(e).__name__}: {e}"
+    dist.barrier()
+
     # ---- 2. the same engines over a gloo-backed sd_allreduce_fn
     streams = {}
     for k in (0, 3):

@@ -129,6 +129,16 @@ SIGNATURES = {
     "sd_softmax_rows_split": (i32, [vp, i64, C.c_float, vp, i64, i32, i32, vp, vp]),
     "sd_sample_rows_split": (i32, [vp, i64, vp, vp, i32, i32, vp, vp]),
     "sd_rejection_sample_split": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "sd_ipc_buffer_bytes": (C.c_size_t, [C.c_size_t]),
+    "sd_ipc_buffer_create": (i32, [C.c_size_t, C.POINTER(vp), vp]),
+    "sd_ipc_buffer_open": (i32, [vp, C.POINTER(vp)]),
+    "sd_ipc_buffer_close": (i32, [vp]),
+    "sd_ipc_buffer_destroy": (i32, [vp]),
+    "sd_ipc_comm_create": (vp, [i32, i32, C.POINTER(vp), C.c_size_t]),
+    "sd_ipc_comm_destroy": (None, [vp]),
+    "sd_ipc_comm_errors": (i32, [vp, C.POINTER(i32)]),
+    "sd_ipc_allreduce": (i32, [vp, C.c_size_t, vp, vp]),
+    "sd_ipc_allgather": (i32, [vp, vp, C.c_size_t, vp, vp]),
     "sd_fill_uniforms": (i32, [vp, i32, C.c_uint64, vp, vp]),
     "sd_fill_uniforms_seq": (i32, [vp, vp, i32, vp, vp, i32, vp]),
     "sd_argmax_partial": (i32, [vp, i64, vp, vp, i32, i32, vp]),

@@ -1024,6 +1024,19 @@ extern "C" sd_tp_comm* sd_tp_comm_create(const void*, int, int) {
 extern "C" void sd_tp_comm_destroy(sd_tp_comm*) {}
 extern "C" int sd_tp_allreduce(void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_tp_allreduce"); }
 extern "C" int sd_tp_allgather(const void*, void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_tp_allgather"); }
+extern "C" size_t sd_ipc_buffer_bytes(size_t) { return 0; }
+extern "C" int sd_ipc_buffer_create(size_t, void**, void*) { UNSUPPORTED("sd_ipc_buffer_create"); }
+extern "C" int sd_ipc_buffer_open(const void*, void**) { UNSUPPORTED("sd_ipc_buffer_open"); }
+extern "C" int sd_ipc_buffer_close(void*) { UNSUPPORTED("sd_ipc_buffer_close"); }
+extern "C" int sd_ipc_buffer_destroy(void*) { UNSUPPORTED("sd_ipc_buffer_destroy"); }
+extern "C" sd_ipc_comm* sd_ipc_comm_create(int, int, void* const*, size_t) {
+  set_error("sd_ipc_comm_create: not provided by the CPU build of the library");
+  return nullptr;
+}
+extern "C" void sd_ipc_comm_destroy(sd_ipc_comm*) {}
+extern "C" int sd_ipc_comm_errors(sd_ipc_comm*, int*) { UNSUPPORTED("sd_ipc_comm_errors"); }
+extern "C" int sd_ipc_allreduce(void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_ipc_allreduce"); }
+extern "C" int sd_ipc_allgather(const void*, void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_ipc_allgather"); }
 extern "C" int sd_graph_begin(sd_stream_t) { UNSUPPORTED("sd_graph_begin"); }
 extern "C" int sd_graph_end(sd_stream_t, sd_graph**) { UNSUPPORTED("sd_graph_end"); }
 extern "C" int sd_graph_launch(sd_graph*, sd_stream_t) { UNSUPPORTED("sd_graph_launch"); }

@@ -125,6 +125,92 @@ class TensorParallelGroup:
             self._comm = None
 
 
+class IpcTensorParallelGroup:
+    """One-shot all-reduce / all-gather over peer-mapped device memory (sd_ipc_*): for the ranks
+    of one node, one process per GPU.  Every rank creates an exchange buffer, the 64-byte IPC
+    handles travel through `exchange` (default: torch.distributed.all_gather_object on the
+    default group, any backend), every rank maps its peers' buffers.  Same surface as
+    TensorParallelGroup (rank, world_size, allreduce_ptr, ctx_ptr, all_reduce, all_gather), so
+    an engine takes either.  max_message_bytes bounds rows x hidden x 2 of a pass (a
+    256-row prefill pass at hidden 8192 is 4 MiB)."""
+
+    def __init__(self, rank: int, world_size: int, max_message_bytes: int = 4 << 20,
+                 exchange: Optional[Callable[[bytes], List[bytes]]] = None):
+        from . import _lib
+        lib = _lib.load()
+        self.rank, self.world_size = rank, world_size
+        self._lib = lib
+        self._own = C.c_void_p()
+        self._peers: List[Optional[int]] = [None] * world_size
+        self._comm = None
+        handle = (C.c_ubyte * 64)()
+        nbytes = lib.sd_ipc_buffer_bytes(max_message_bytes)
+        _lib.check(lib.sd_ipc_buffer_create(nbytes, C.byref(self._own), handle), "sd_ipc_buffer_create")
+        handles = (exchange or _all_gather_bytes)(bytes(handle)) if world_size > 1 else [bytes(handle)]
+        if len(handles) != world_size or any(len(h) != 64 for h in handles):
+            raise RuntimeError("IPC handle exchange failed")
+        bufs = (C.c_void_p * world_size)()
+        for q in range(world_size):
+            if q == rank:
+                bufs[q] = self._own.value
+                continue
+            p = C.c_void_p()
+            _lib.check(lib.sd_ipc_buffer_open((C.c_ubyte * 64).from_buffer_copy(handles[q]), C.byref(p)),
+                       "sd_ipc_buffer_open")
+            self._peers[q] = p.value
+            bufs[q] = p.value
+        self._comm = lib.sd_ipc_comm_create(rank, world_size, bufs, max_message_bytes)
+        if not self._comm:
+            raise _lib.SdError(f"sd_ipc_comm_create failed: {_lib.last_error()}")
+        self.allreduce_ptr = C.cast(lib.sd_ipc_allreduce, C.c_void_p).value
+        self.ctx_ptr = self._comm
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        """In-place sum of a bf16 device tensor over the group (current stream)."""
+        from . import _lib
+        if t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous():
+            raise _lib.SdError("all_reduce: contiguous bf16 device tensor expected")
+        _lib.check(self._lib.sd_ipc_allreduce(t.data_ptr(), t.numel(), self._comm,
+                                              torch.cuda.current_stream().cuda_stream), "sd_ipc_allreduce")
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        """recv = the ranks' `send` buffers one after the other, in rank order (current stream)."""
+        from . import _lib
+        nbytes = send.numel() * send.element_size()
+        if not (send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()) \
+                or recv.numel() * recv.element_size() != nbytes * self.world_size:
+            raise _lib.SdError("all_gather: contiguous device tensors, recv = world_size x send")
+        _lib.check(self._lib.sd_ipc_allgather(send.data_ptr(), recv.data_ptr(), nbytes, self._comm,
+                                              torch.cuda.current_stream().cuda_stream), "sd_ipc_allgather")
+
+    def timeouts(self) -> int:
+        """Waits that gave up since the group was made (synchronises); 0 in a healthy run."""
+        from . import _lib
+        n = C.c_int(0)
+        _lib.check(self._lib.sd_ipc_comm_errors(self._comm, C.byref(n)), "sd_ipc_comm_errors")
+        return n.value
+
+    def close(self) -> None:
+        """Unmaps the peers' buffers and frees this rank's.  Every rank must have finished its
+        last collective (synchronise the ranks first): a peer may still be reading."""
+        if self._comm:
+            self._lib.sd_ipc_comm_destroy(self._comm)
+            self._comm = None
+        for q, p in enumerate(self._peers):
+            if p:
+                self._lib.sd_ipc_buffer_close(p)
+                self._peers[q] = None
+        if self._own.value:
+            self._lib.sd_ipc_buffer_destroy(self._own)
+            self._own = C.c_void_p()
+
+
+def _all_gather_bytes(payload: bytes) -> List[bytes]:
+    out: List = [None] * dist.get_world_size()
+    dist.all_gather_object(out, payload)
+    return out
+
+
 def _broadcast_bytes(payload: Optional[bytes]) -> bytes:
     """Rank 0's payload on every rank of the default process group."""
     box = [payload]

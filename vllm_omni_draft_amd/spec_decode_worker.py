@@ -423,6 +423,11 @@ class SpecDecodeConfig:
     # GPU), the draft stays whole on each.  `target` is then either this rank's shard or a
     # (ModelConfig, state_dict) pair that load_model shards itself.
     tensor_parallel_size: int = 1
+    # how the ranks' partial sums are combined: "rccl" (the library's RCCL group), or "ipc":
+    # one-shot all-reduce / all-gather kernels over peer-mapped device memory (the ranks of one
+    # node; every rank reads every peer once, in rank order: suited to the rows x hidden
+    # messages of decode and verify passes, bit-identical on all ranks)
+    tensor_parallel_collective: str = "rccl"
     # under tensor parallelism each rank holds vocab / tp rows of the LM head and the ranks
     # exchange slice maxima (greedy) or gather rows (sampling) instead of replicating the head
     vocab_parallel_lm_head: bool = True
@@ -497,7 +502,20 @@ class SpecDecodeWorker:
                                    "group (parallel.init_from_env) to exchange the RCCL id")
             if torch.distributed.get_world_size() != tp:
                 raise ValueError("tensor_parallel_size must equal the world size")
-            self.tp_group = parallel.TensorParallelGroup(self.rank, tp)
+            kind = self.config.tensor_parallel_collective
+            if kind == "rccl":
+                self.tp_group = parallel.TensorParallelGroup(self.rank, tp)
+            elif kind == "ipc":
+                tgt = self.config.target
+                mcfg = tgt[0] if isinstance(tgt, tuple) else tgt.cfg
+                # the largest messages: a 256-row prefill pass's hidden states, or (sampling) the
+                # gathered logit slices of a verify pass
+                rows = max(16, self.config.max_num_seqs * (self.config.num_speculative_tokens + 1))
+                need = max(256 * mcfg.hidden * 2, rows * (-(-mcfg.vocab // tp)) * 4)
+                self.tp_group = parallel.IpcTensorParallelGroup(self.rank, tp,
+                                                                max_message_bytes=min(need, 16 << 20))
+            else:
+                raise ValueError(f"tensor_parallel_collective must be 'rccl' or 'ipc', not {kind!r}")
 
     def load_model(self) -> None:
         c = self.config
