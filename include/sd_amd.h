@@ -111,6 +111,17 @@ int sd_softmax_rows(const float* logits, int64_t ld, float temperature,
 int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
                    int64_t* ids, int R, int V, sd_stream_t stream);
 
+/* top-k / top-p / min-p filtering of probability rows, in place, with per-sequence parameters
+ * (SamplingParams.top_k / top_p / min_p; upstream: vllm/v1/sample/ops/topk_topp_sampler.py
+ * apply_top_k_top_p and the sampler's min-p step; not in the reference tree).  Row r belongs to
+ * sequence r / rows_per_seq.  Order: top-k (keep entries >= the k-th largest value), min-p (keep
+ * entries >= min_p x the row maximum), then top-p on what is left (keep entries >= the largest
+ * value t for which the entries >= t hold at least top_p of the remaining mass); the kept entries
+ * are renormalised.  Entries equal to a cut-off are kept.  top_k[s] <= 0, top_p[s] >= 1,
+ * min_p[s] <= 0 switch a filter off; any of the arrays may be NULL.  One workgroup per row. */
+int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_k, const float* top_p,
+                        const float* min_p, int rows_per_seq, int R, int V, sd_stream_t stream);
+
 /* sd_softmax_rows(_split) with one temperature per sequence (per-request SamplingParams.
  * temperature): row r uses temperatures[r / rows_per_seq] (device, f32).  A temperature of 0 asks
  * for the greedy distribution: probability 1 on the first maximum of the row, so that the

@@ -147,3 +147,31 @@ def softmax_rows(logits, temperature: float = 1.0) -> np.ndarray:
 def sample_rows(probs, uniforms) -> np.ndarray:
     p = np.asarray(probs, dtype=np.float32)
     return np.array([inverse_cdf(p[r], uniforms[r]) for r in range(p.shape[0])], dtype=np.int64)
+
+
+def filter_probs(p: np.ndarray, top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0) -> np.ndarray:
+    """top-k, min-p, then top-p on what is left, renormalised; one probability row (float64 in the
+    arithmetic).  Follows vllm/v1/sample/ops/topk_topp_sampler.py apply_top_k_top_p (top-k keeps
+    everything not below the k-th largest value; top-p drops the low tail whose cumulative mass
+    is at most 1 - top_p) and the sampler's min-p rule (keep p >= min_p * max p), with the one
+    stated difference that entries EQUAL to a cut-off value always stay together (upstream's
+    sort puts ties in an arbitrary order).  The reference tree does not contain the sampler."""
+    p = np.asarray(p, dtype=np.float64)
+    V = p.size
+    keep = p > 0
+    if 0 < top_k < V:
+        keep &= p >= np.sort(p)[::-1][top_k - 1]
+    if min_p > 0:
+        keep &= p >= np.float32(min_p) * np.float32(p.max())
+    if top_p < 1.0:
+        base = p[keep].sum()
+        vals = np.unique(p[keep])[::-1]                  # distinct kept values, largest first
+        acc, cut = 0.0, vals[-1]
+        for v in vals:
+            acc += p[keep & (p == v)].sum()
+            if acc >= top_p * base:
+                cut = v
+                break
+        keep &= p >= cut
+    out = np.where(keep, p, 0.0)
+    return out / out.sum()

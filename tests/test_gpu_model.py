@@ -641,6 +641,52 @@ def test_requests_with_their_own_temperatures_share_a_batch(use_graph):
         eng.add_requests([pa], temperatures=[-1.0])
 
 
+def test_top_k_top_p_requests_follow_the_filtered_target_distribution():
+    """Requests with top_k / top_p: every emitted token is a draw from the oracle's FILTERED target
+    distribution given its predecessor (the draft proposes from its whole distribution, rejection
+    sampling corrects it), tokens outside the filter never appear, and top_k = 1 on a sampling
+    engine is greedy decoding."""
+    from oracle import sampling as osamp
+    cfg, (ts, ds) = _markov_pair()
+    P = _transition_matrix(cfg, ts, 1.0)
+    Pf = np.stack([osamp.filter_probs(row, top_k=6, top_p=0.9) for row in P])
+    assert ((Pf > 0).sum(axis=1) <= 6).all() and (Pf > 0).sum() < 0.25 * P.size
+    tw, dw = _product(cfg, ts), _product(cfg, ds)
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    B = 4
+    eng = SpecEngine(tw, dw, EngineConfig(k=3, max_batch=B, max_seq_len=900, split_tokens=128,
+                                          temperature=1.0, seed=3))
+    counts = np.zeros((cfg.vocab, cfg.vocab))
+    rounds = 0
+    while counts.sum() < 21000:
+        eng.reset()
+        seqs = [[(7 * b + rounds) % cfg.vocab] for b in range(B)]
+        firsts = eng.add_requests(seqs, filters=[dict(top_k=6, top_p=0.9)] * B)
+        for sq, f in zip(seqs, firsts):
+            sq.append(f)
+        for _ in range(280):
+            for b, new in enumerate(eng.step()):
+                seqs[b].extend(new)
+        for sq in seqs:
+            np.add.at(counts, (sq[:-1], sq[1:]), 1)
+        rounds += 1
+    assert counts[Pf == 0].sum() == 0                       # nothing outside the filter, ever
+    _check_transitions(counts, Pf)
+    with pytest.raises(AssertionError):
+        _check_transitions(counts, P)                       # and it is not the unfiltered one
+    # top_k = 1 (and a nucleus smaller than the most likely token) leave only that token
+    tcfg = MODELS["llama"]
+    tw2 = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    prompt = [5, 9, 200, 31, 7]
+    greedy = _generate(_engine(tw2, None, 0), [prompt], 30)[0]
+    for flt in (dict(top_k=1), dict(top_p=1e-4)):
+        e2 = _engine(tw2, tw2, 3, temperature=0.9)
+        out = [e2.add_request(0, prompt, seed=1, **flt)]
+        while len(out) < 30:
+            out += e2.step()[0]
+        assert out[:30] == greedy, flt
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_typical_acceptance_engine_known_answers(use_graph):
     """Typical acceptance at its two extremes.  A threshold nothing can exceed rejects every

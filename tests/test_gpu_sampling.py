@@ -392,3 +392,42 @@ def test_softmax_with_one_temperature_per_sequence(split):
     sub = ops.softmax_rows(logits.cuda(), temps.cuda(), row_offset=2, row_step=3, scratch=scratch).cpu()
     for b in range(n_seq):
         assert torch.equal(sub[b], out[3 * b + 2]) or temps[b] != temps[(3 * b + 2) // per]
+
+
+@pytest.mark.parametrize("V", [1000, 50272, 128256, 151936])
+def test_top_k_top_p_min_p_filter_matches_oracle(V):
+    """sd_filter_probs_seq against the oracle's restatement of upstream's top-k / min-p / top-p, per
+    sequence parameters, three row-storage tiers (registers, LDS, global: the largest vocabulary),
+    ties at the cut-off, filters off, and a greedy (one-hot) row."""
+    from vllm_omni_draft_amd import ops
+    rng = np.random.default_rng(V)
+    params = [dict(top_k=50), dict(top_p=0.9), dict(min_p=0.05), dict(top_k=20, top_p=0.8),
+              dict(top_k=1000, top_p=0.95, min_p=0.01), dict(), dict(top_k=1), dict(top_p=0.3)]
+    per = 2
+    rows = []
+    for i in range(len(params) * per):
+        logits = rng.normal(size=V) * (2.0 + i % 3)
+        p = np.exp(logits - logits.max())
+        rows.append((p / p.sum()).astype(np.float32))
+    rows[0][5] = rows[0][7] = np.sort(rows[0])[::-1][49]          # a tie exactly at the top-k cut-off
+    rows[-1][:] = 0.0
+    rows[-1][V // 3] = 1.0                                         # a greedy request's row
+    probs = torch.tensor(np.stack(rows)).cuda()
+    tk = torch.tensor([q.get("top_k", 0) for q in params], dtype=torch.int32).cuda()
+    tp = torch.tensor([q.get("top_p", 1.0) for q in params], dtype=torch.float32).cuda()
+    mp = torch.tensor([q.get("min_p", 0.0) for q in params], dtype=torch.float32).cuda()
+    ops.filter_probs(probs, tk, tp, mp, rows_per_seq=per)
+    torch.cuda.synchronize()
+    got = probs.cpu().numpy()
+    for r, row in enumerate(rows):
+        q = params[r // per]
+        if not q:
+            assert np.array_equal(got[r], row)                     # untouched
+            continue
+        # f32 mass sums on the device: the nucleus may end one value earlier or later when the
+        # cumulative mass lands within rounding of the bound
+        cands = [sampling.filter_probs(row, q.get("top_k", 0), q.get("top_p", 1.0) + d, q.get("min_p", 0.0))
+                 for d in ((0.0, -2e-6, 2e-6) if "top_p" in q else (0.0,))]
+        assert any(np.array_equal(got[r] > 0, c > 0) and np.allclose(got[r], c, rtol=2e-5, atol=1e-9)
+                   for c in cands), (r, q, (got[r] > 0).sum(), [(c > 0).sum() for c in cands])
+        assert abs(got[r].sum() - 1.0) < 1e-5

@@ -6,6 +6,7 @@
 // i, lanes past the proposal length vote "accepted", and the first rejected
 // position is the lowest clear bit of the 64-bit mask.
 #include <climits>
+#include <mutex>
 
 #include "sd_common.h"
 
@@ -407,6 +408,152 @@ __global__ __launch_bounds__(kSampleThreads) void softmax_rows_kernel(
   const double total = block_sum_f64(sum, s_d);
   const float inv = (float)(1.0 / total);
   for (int i = tid; i < V; i += blockDim.x) out[i] = expf(row[i] * inv_t - mx) * inv;
+}
+
+// ---------------------------------------------------------------------------------------
+// top-k / top-p / min-p of probability rows, in place.  One workgroup per row finds the cut-off
+// VALUE by bisection on the bit pattern of a positive float (which orders like the float): the
+// k-th largest value is the largest t with count(p >= t) >= k; the nucleus bound is the largest
+// t with mass(p >= t) >= top_p x the mass left by top-k and min-p.  Entries equal to the cut-off
+// are kept (ties stay together).  The row lives in three tiers: kFilterRegs values per thread in
+// registers, up to kFilterLdsMax more per thread in LDS, the rest (vocabularies beyond ~123k
+// entries) re-read from global memory (L2) in every pass.
+struct FilterArgs {
+  const int32_t* top_k;   // [n_seq] or null; <= 0: off
+  const float* top_p;     // [n_seq] or null; >= 1: off
+  const float* min_p;     // [n_seq] or null; <= 0: off
+  int rows_per_seq;
+};
+constexpr int kFilterRegs = 84;
+constexpr int kFilterLdsMax = 36;   // x 1024 threads x 4 B = 144 KiB
+
+__global__ __launch_bounds__(kSampleThreads) void filter_probs_kernel(float* __restrict__ probs, int64_t ld,
+                                                                      FilterArgs f, int V, int n_lds) {
+  extern __shared__ float s_row[];   // [n_lds][kSampleThreads]
+  __shared__ float s_f[kSampleWaves];
+  __shared__ int s_i[kSampleWaves];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = r / f.rows_per_seq;
+  const int k = f.top_k ? f.top_k[seq] : 0;
+  const float P = f.top_p ? f.top_p[seq] : 1.f;
+  const float mp = f.min_p ? f.min_p[seq] : 0.f;
+  const bool use_k = k > 0 && k < V, use_p = P < 1.f, use_m = mp > 0.f;
+  if (!use_k && !use_p && !use_m) return;   // block-uniform
+  float* row = probs + (size_t)r * ld;
+  const int vpt = (V + kSampleThreads - 1) / kSampleThreads;
+  float v[kFilterRegs];
+  float mx = 0.f;
+#pragma unroll
+  for (int j = 0; j < kFilterRegs; ++j) {
+    const int i = j * kSampleThreads + tid;
+    v[j] = i < V ? row[i] : 0.f;
+    mx = fmaxf(mx, v[j]);
+  }
+  for (int j = 0; j < n_lds; ++j) {
+    const int i = (kFilterRegs + j) * kSampleThreads + tid;
+    const float x = i < V ? row[i] : 0.f;
+    s_row[j * kSampleThreads + tid] = x;   // read back by this thread only
+    mx = fmaxf(mx, x);
+  }
+  for (int j = kFilterRegs + n_lds; j < vpt; ++j) {
+    const int i = j * kSampleThreads + tid;
+    if (i < V) mx = fmaxf(mx, row[i]);
+  }
+  // (count, mass) of the entries >= t, over the whole row
+  auto stats_ge = [&](float t, int& count, float& mass) {
+    int c = 0;
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < kFilterRegs; ++j) {
+      const bool in = v[j] >= t;
+      c += in ? 1 : 0;
+      m += in ? v[j] : 0.f;
+    }
+    for (int j = 0; j < n_lds; ++j) {
+      const float x = s_row[j * kSampleThreads + tid];
+      const bool in = x >= t;
+      c += in ? 1 : 0;
+      m += in ? x : 0.f;
+    }
+    for (int j = kFilterRegs + n_lds; j < vpt; ++j) {
+      const int i = j * kSampleThreads + tid;
+      const float x = i < V ? row[i] : 0.f;
+      const bool in = x >= t;
+      c += in ? 1 : 0;
+      m += in ? x : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    m = wave_sum(m);
+    __syncthreads();
+    if (lane == 0) {
+      s_i[wave] = c;
+      s_f[wave] = m;
+    }
+    __syncthreads();
+    count = 0;
+    mass = 0.f;
+    for (int w = 0; w < kSampleWaves; ++w) {
+      count += s_i[w];
+      mass += s_f[w];
+    }
+  };
+  mx = wave_max(mx);
+  if (lane == 0) s_f[wave] = mx;
+  __syncthreads();
+  mx = s_f[0];
+  for (int w = 1; w < kSampleWaves; ++w) mx = fmaxf(mx, s_f[w]);
+  if (!(mx > 0.f)) return;
+  const unsigned mx_bits = __float_as_uint(mx);
+  int cnt;
+  float mass;
+  float tau = 0.f;
+  if (use_k) {
+    unsigned cand = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+      const unsigned t = cand | (1u << bit);
+      if (t > mx_bits) continue;   // block-uniform
+      stats_ge(__uint_as_float(t), cnt, mass);
+      if (cnt >= k) cand = t;
+    }
+    tau = __uint_as_float(cand);
+  }
+  if (use_m) tau = fmaxf(tau, mp * mx);
+  // the smallest positive float stands for "every entry with mass" when no other filter is on
+  const float base = fmaxf(tau, __uint_as_float(1u));
+  if (use_p) {
+    stats_ge(base, cnt, mass);
+    const float target = P * mass;
+    unsigned cand = 0;
+    for (int bit = 30; bit >= 0; --bit) {
+      const unsigned t = cand | (1u << bit);
+      if (t > mx_bits) continue;
+      stats_ge(fmaxf(__uint_as_float(t), base), cnt, mass);
+      if (mass >= target) cand = t;
+    }
+    tau = fmaxf(base, __uint_as_float(cand));
+  } else {
+    tau = base;
+  }
+  stats_ge(tau, cnt, mass);
+  const float inv = mass > 0.f ? 1.f / mass : 0.f;
+#pragma unroll
+  for (int j = 0; j < kFilterRegs; ++j) {
+    const int i = j * kSampleThreads + tid;
+    if (i < V) row[i] = v[j] >= tau ? v[j] * inv : 0.f;
+  }
+  for (int j = 0; j < n_lds; ++j) {
+    const int i = (kFilterRegs + j) * kSampleThreads + tid;
+    const float x = s_row[j * kSampleThreads + tid];
+    if (i < V) row[i] = x >= tau ? x * inv : 0.f;
+  }
+  for (int j = kFilterRegs + n_lds; j < vpt; ++j) {
+    const int i = j * kSampleThreads + tid;
+    if (i < V) {
+      const float x = row[i];
+      row[i] = x >= tau ? x * inv : 0.f;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1205,6 +1352,32 @@ extern "C" int sd_sample_rows(const float* probs, int64_t ld, const float* unifo
   hipLaunchKernelGGL(sample_rows_kernel, dim3(R), dim3(kSampleThreads), 0,
                      (hipStream_t)stream, probs, ld, uniforms, ids, V);
   SD_CHECK_LAUNCH("sd_sample_rows");
+  return SD_OK;
+}
+
+extern "C" int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_k, const float* top_p,
+                                   const float* min_p, int rows_per_seq, int R, int V,
+                                   sd_stream_t stream) {
+  SD_REQUIRE(probs && R >= 0 && V >= 1 && ld >= V && rows_per_seq >= 1, SD_ERR_INVALID,
+             "sd_filter_probs_seq: bad arguments (R=%d V=%d rows_per_seq=%d)", R, V, rows_per_seq);
+  if (R == 0 || (!top_k && !top_p && !min_p)) return SD_OK;
+  const FilterArgs f{top_k, top_p, min_p, rows_per_seq};
+  const int vpt = (V + kSampleThreads - 1) / kSampleThreads;
+  int n_lds = vpt - kFilterRegs;
+  n_lds = n_lds < 0 ? 0 : (n_lds > kFilterLdsMax ? kFilterLdsMax : n_lds);
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_probs_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kFilterLdsMax * kSampleThreads * (int)sizeof(float));
+  });
+  SD_REQUIRE(attr_err == hipSuccess, SD_ERR_HIP, "sd_filter_probs_seq: hipFuncSetAttribute: %s",
+             hipGetErrorString(attr_err));
+  hipLaunchKernelGGL(filter_probs_kernel, dim3(R), dim3(kSampleThreads),
+                     (size_t)n_lds * kSampleThreads * sizeof(float), (hipStream_t)stream, probs, ld, f, V,
+                     n_lds);
+  SD_CHECK_LAUNCH("sd_filter_probs_seq");
   return SD_OK;
 }
 

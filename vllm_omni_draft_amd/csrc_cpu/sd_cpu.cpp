@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <limits>
+#include <functional>
 #include <vector>
 
 #include <omp.h>
@@ -495,6 +497,52 @@ extern "C" int sd_sample_rows(const float* probs, int64_t ld, const float* u, in
 }
 
 extern "C" size_t sd_sampling_scratch_bytes(int R) { return R > 0 ? 64 : 0; }
+extern "C" int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_k, const float* top_p,
+                                   const float* min_p, int rows_per_seq, int R, int V, sd_stream_t) {
+  REQUIRE(probs && R >= 0 && V >= 1 && ld >= V && rows_per_seq >= 1, SD_ERR_INVALID,
+          "sd_filter_probs_seq: bad arguments");
+  std::vector<float> sorted(V);
+  for (int r = 0; r < R; ++r) {
+    const int s = r / rows_per_seq;
+    const int k = top_k ? top_k[s] : 0;
+    const float P = top_p ? top_p[s] : 1.f, mp = min_p ? min_p[s] : 0.f;
+    const bool use_k = k > 0 && k < V, use_p = P < 1.f, use_m = mp > 0.f;
+    if (!use_k && !use_p && !use_m) continue;
+    float* row = probs + (size_t)r * ld;
+    std::copy(row, row + V, sorted.begin());
+    std::sort(sorted.begin(), sorted.end(), std::greater<float>());
+    if (!(sorted[0] > 0.f)) continue;
+    float tau = 0.f;
+    if (use_k) tau = sorted[k - 1];
+    if (use_m) tau = std::max(tau, mp * sorted[0]);
+    tau = std::max(tau, std::numeric_limits<float>::denorm_min());
+    if (use_p) {
+      double base = 0.0;
+      for (int i = 0; i < V && sorted[i] >= tau; ++i) base += sorted[i];
+      const double target = (double)P * base;
+      double acc = 0.0;
+      float cut = tau;
+      for (int i = 0; i < V && sorted[i] >= tau; ++i) {   // distinct values, largest first
+        int j = i;
+        double group = 0.0;
+        while (j < V && sorted[j] == sorted[i]) group += sorted[j++];
+        acc += group;
+        if (acc >= target) {
+          cut = sorted[i];
+          break;
+        }
+        i = j - 1;
+      }
+      tau = std::max(tau, cut);
+    }
+    double kept = 0.0;
+    for (int i = 0; i < V; ++i) kept += row[i] >= tau ? row[i] : 0.f;
+    const float inv = kept > 0.0 ? (float)(1.0 / kept) : 0.f;
+    for (int i = 0; i < V; ++i) row[i] = row[i] >= tau ? row[i] * inv : 0.f;
+  }
+  return SD_OK;
+}
+
 extern "C" int sd_softmax_rows_seq(const float* logits, int64_t ld, const float* temps, int rows_per_seq,
                                    float* probs, int64_t ldp, int R, int V, void*, sd_stream_t s) {
   REQUIRE(logits && probs && temps && R >= 0 && V >= 1 && rows_per_seq >= 1, SD_ERR_INVALID,

@@ -307,6 +307,11 @@ class SpecEngine:
             # on its batch mates
             # one temperature per sequence (its request's, or cfg.temperature); 0 = greedy
             self.temps = torch.full((B,), float(cfg.temperature), **f32)
+            # per-sequence filters of the target distribution (off: 0, 1.0, 0.0); the draft's
+            # distribution stays whole, which costs acceptance at most, never correctness
+            self.top_k = torch.zeros(B, dtype=torch.int32, device=dev)
+            self.top_p = torch.ones(B, **f32)
+            self.min_p = torch.zeros(B, **f32)
             self.u_seeds = torch.zeros(B, dtype=torch.int64, device=dev)
             self.u_counters = torch.zeros(B, dtype=torch.int64, device=dev)
             self.host_seeds: List[int] = [0] * B
@@ -377,7 +382,8 @@ class SpecEngine:
                     input_embeds: Optional[torch.Tensor] = None,
                     rope_positions: Optional[torch.Tensor] = None,
                     truth_row: Optional[Sequence[int]] = None,
-                    seed: Optional[int] = None, temperature: Optional[float] = None) -> int:
+                    seed: Optional[int] = None, temperature: Optional[float] = None,
+                    top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
         first token from the target and returns it (this synchronises).
         Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
@@ -389,23 +395,31 @@ class SpecEngine:
         (sampling): the request's own random stream; the tokens it samples are then the same
         whatever else is in the batch (None: a stream derived from EngineConfig.seed and the
         order of admission).  temperature (sampling engines): the request's own temperature,
-        0 for a greedy request among sampling ones (None: EngineConfig.temperature)."""
+        0 for a greedy request among sampling ones (None: EngineConfig.temperature); top_k /
+        top_p / min_p filter the target distribution the request samples from (0 / 1.0 / 0.0: off)."""
         with _rt.stream_ctx(self.stream):
             if truth_row is not None:
                 if self.truth is None:
                     raise ValueError("truth_row needs set_synthetic_acceptance first")
                 row = torch.tensor(list(truth_row)[:self.truth.shape[1]], dtype=torch.int32)
                 self.truth[slot, :row.numel()].copy_(row)
-            self._set_temperature(slot, temperature)
+            self._set_temperature(slot, temperature, top_k, top_p, min_p)
             return self._add_request(slot, prompt, input_embeds, rope_positions, seed)
 
-    def _set_temperature(self, slot: int, temperature: Optional[float]) -> None:
+    def _set_temperature(self, slot: int, temperature: Optional[float], top_k: int = 0,
+                         top_p: float = 1.0, min_p: float = 0.0) -> None:
+        top_k = 0 if top_k is None or top_k < 0 else int(top_k)
+        top_p = 1.0 if top_p is None else float(top_p)
+        min_p = 0.0 if min_p is None else float(min_p)
+        if not 0.0 < top_p <= 1.0 or not 0.0 <= min_p <= 1.0:
+            raise ValueError(f"top_p {top_p} must be in (0, 1], min_p {min_p} in [0, 1]")
         if self.sampling:
             t = self.cfg.temperature if temperature is None else float(temperature)
             if not t >= 0.0:
                 raise ValueError(f"temperature {temperature} must be >= 0")
             if 0 <= slot < self.cfg.max_batch:
                 self.temps[slot] = t
+                self.top_k[slot], self.top_p[slot], self.min_p[slot] = top_k, top_p, min_p
         elif temperature not in (None, 0, 0.0):
             raise ValueError("a greedy engine (EngineConfig.temperature == 0) cannot sample; build "
                              "the engine with a temperature > 0 to mix sampling and greedy requests")
@@ -473,6 +487,8 @@ class SpecEngine:
             self._target_full_rows(1)
             u = torch.tensor([self._seed_slot(slot, seed)], dtype=torch.float32).to(self.device)
             probs = ops.softmax_rows(self.t_logits[:1], self.temps[slot:slot + 1])
+            ops.filter_probs(probs, self.top_k[slot:slot + 1], self.top_p[slot:slot + 1],
+                             self.min_p[slot:slot + 1])
             first = ops.sample_rows(probs, u)
         else:
             first = self._target_argmax(1, torch.empty(1, dtype=torch.int64, device=self.device))
@@ -492,7 +508,8 @@ class SpecEngine:
     def add_requests(self, prompts: Sequence[Sequence[int]],
                      truth_rows: Optional[Sequence[Sequence[int]]] = None,
                      seeds: Optional[Sequence[Optional[int]]] = None,
-                     temperatures: Optional[Sequence[Optional[float]]] = None) -> List[int]:
+                     temperatures: Optional[Sequence[Optional[float]]] = None,
+                     filters: Optional[Sequence[Optional[dict]]] = None) -> List[int]:
         """Prefills several text prompts in the same passes and returns their first tokens (one
         synchronisation for all of them).  The prompts take the next free slots in order.
         Every pass carries a chunk of each prompt (prefill_rows // len(prompts) tokens per
@@ -511,8 +528,11 @@ class SpecEngine:
                 raise ValueError("one seed (or None) per prompt")
             if temperatures is not None and len(temperatures) != len(prompts):
                 raise ValueError("one temperature (or None) per prompt")
+            if filters is not None and len(filters) != len(prompts):
+                raise ValueError("one filter dict {top_k, top_p, min_p} (or None) per prompt")
             for i in range(len(prompts)):
-                self._set_temperature(self.active + i, None if temperatures is None else temperatures[i])
+                self._set_temperature(self.active + i, None if temperatures is None else temperatures[i],
+                                      **((filters[i] or {}) if filters is not None else {}))
             return self._add_requests([list(p) for p in prompts], seeds)
 
     def _add_requests(self, prompts: List[List[int]], seeds=None) -> List[int]:
@@ -572,6 +592,8 @@ class SpecEngine:
             u = torch.tensor([self._seed_slot(slot0 + i, None if seeds is None else seeds[i])
                               for i in range(Bp)], dtype=torch.float32).to(self.device)
             probs = ops.softmax_rows(self.t_logits[:Bp], self.temps[slot0:slot0 + Bp])
+            ops.filter_probs(probs, self.top_k[slot0:slot0 + Bp], self.top_p[slot0:slot0 + Bp],
+                             self.min_p[slot0:slot0 + Bp])
             first = ops.sample_rows(probs, u)
         else:
             first = self._target_argmax(Bp, torch.empty(Bp, dtype=torch.int64, device=self.device))
@@ -712,6 +734,7 @@ class SpecEngine:
             self._target_full_rows(B)
             ops.softmax_rows(self.t_logits[:B], self.temps[:B], out=self.t_probs.view(-1, self.V),
                              scratch=self.samp_scratch)
+            ops.filter_probs(self.t_probs.view(-1, self.V)[:B], self.top_k, self.top_p, self.min_p)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
             ops.advance_state(self.ids_tmp[:B].view(-1, 1), self.seq_lens[:B], self.tok_buf[:B],
@@ -739,6 +762,7 @@ class SpecEngine:
             self._target_full_rows(B)
             ops.softmax_rows(self.t_logits[:B], self.temps[:B],
                              out=self.t_probs.view(-1, self.V)[:B], scratch=self.samp_scratch)
+            ops.filter_probs(self.t_probs.view(-1, self.V)[:B], self.top_k, self.top_p, self.min_p)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B], self.u_bonus, out=self.ids_tmp,
                             scratch=self.samp_scratch)
         else:
@@ -886,6 +910,8 @@ class SpecEngine:
             self._target_full_rows(B * (k + 1))
             ops.softmax_rows(rows, self.temps[:B], rows_per_seq=k + 1, out=self.t_probs.view(-1, self.V),
                              scratch=self.samp_scratch)
+            ops.filter_probs(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.top_k, self.top_p,
+                             self.min_p, rows_per_seq=k + 1)
             ops.sample_rows(self.t_probs.view(-1, self.V)[:B * (k + 1)], self.u_bonus,
                             out=self.bonus_ids, row_offset=k, row_step=k + 1,
                             scratch=self.samp_scratch)
@@ -935,7 +961,7 @@ class SpecEngine:
                 moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta,
                          self.force_ctr]
                 if self.sampling:
-                    moved += [self.u_seeds, self.u_counters, self.temps]
+                    moved += [self.u_seeds, self.u_counters, self.temps, self.top_k, self.top_p, self.min_p]
                     self.host_seeds[slot] = self.host_seeds[last]
                 if self.truth is not None:
                     moved.append(self.truth)

@@ -184,6 +184,23 @@ def softmax_rows(logits: torch.Tensor, temperature=1.0, out=None, *, row_offset=
     return out
 
 
+def filter_probs(probs: torch.Tensor, top_k=None, top_p=None, min_p=None, rows_per_seq: int = 1) -> None:
+    """In-place top-k / min-p / top-p filtering of probability rows [R, V] with per-sequence
+    parameters (int32 / float32 / float32 device tensors, row r -> sequence r // rows_per_seq;
+    see sd_filter_probs_seq)."""
+    _need(probs, torch.float32, "probs")
+    R, V = probs.shape
+    n_seq = -(-R // rows_per_seq)
+    for t, dt, name in ((top_k, torch.int32, "top_k"), (top_p, torch.float32, "top_p"),
+                        (min_p, torch.float32, "min_p")):
+        if t is not None:
+            _need(t, dt, name)
+            if t.numel() < n_seq:
+                raise _lib.SdError(f"filter_probs: {name} shorter than the number of sequences")
+    _lib.check(_lib.load().sd_filter_probs_seq(_p(probs), probs.stride(0), _p(top_k), _p(top_p), _p(min_p),
+                                               rows_per_seq, R, V, _stream()), "sd_filter_probs_seq")
+
+
 def sample_rows(probs: torch.Tensor, uniforms: torch.Tensor, out=None, *, row_offset=0,
                 row_step=1, scratch=None) -> torch.Tensor:
     """Inverse-CDF draw from rows row_offset, row_offset+row_step, ... of probs [*, V]."""

@@ -49,6 +49,12 @@ class SamplingParams:
     # and among any batch mates.  None: a stream derived from SpecDecodeConfig.seed and the order
     # of admission.  Greedy workers ignore it.
     seed: Optional[int] = None
+    # Filters of the distribution a sampling request draws from (0 / -1, 1.0, 0.0: off); applied
+    # to the target's probabilities before acceptance, in upstream's order top-k, min-p, top-p.
+    # Greedy decoding is unaffected by them (the most likely token always survives).
+    top_k: int = 0
+    top_p: float = 1.0
+    min_p: float = 0.0
     ignore_eos: bool = True
 
 
@@ -150,6 +156,8 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
         params = SamplingParams(temperature=_get(sp, "temperature", None),
                                 max_tokens=_get(sp, "max_tokens", 16) or 16,
                                 seed=_get(sp, "seed", None),
+                                top_k=_get(sp, "top_k", 0) or 0, top_p=_get(sp, "top_p", 1.0) or 1.0,
+                                min_p=_get(sp, "min_p", 0.0) or 0.0,
                                 ignore_eos=bool(_get(sp, "ignore_eos", True))) if sp is not None \
             else SamplingParams()
         mm = None
@@ -642,6 +650,9 @@ class SpecDecodeWorker:
                                      f"to serve sampling and greedy requests together)")
             if sp.seed is not None and not isinstance(sp.seed, int):
                 raise ValueError(f"request {g.request_id}: seed must be an integer")
+            if not 0.0 < float(sp.top_p) <= 1.0 or not 0.0 <= float(sp.min_p) <= 1.0:
+                raise ValueError(f"request {g.request_id}: top_p {sp.top_p} must be in (0, 1] and "
+                                 f"min_p {sp.min_p} in [0, 1]")
             if g.request_id in self._slot_of and g.request_id not in finished:
                 raise KeyError(f"request {g.request_id} is already running")
             n = len(g.prompt_token_ids)
@@ -688,12 +699,15 @@ class SpecDecodeWorker:
             if j - i >= 2:
                 group = prompts[i:j]
                 kw = dict(seeds=[g.sampling_params.seed for g in group],
-                          temperatures=[g.sampling_params.temperature for g in group]) if seeded else {}
+                          temperatures=[g.sampling_params.temperature for g in group],
+                          filters=[dict(top_k=g.sampling_params.top_k, top_p=g.sampling_params.top_p,
+                                        min_p=g.sampling_params.min_p) for g in group]) if seeded else {}
                 firsts = eng.add_requests([g.prompt_token_ids for g in group], **kw)
             else:
                 group = prompts[i:i + 1]
-                kw = dict(seed=group[0].sampling_params.seed,
-                          temperature=group[0].sampling_params.temperature) if seeded else {}
+                sp0 = group[0].sampling_params
+                kw = dict(seed=sp0.seed, temperature=sp0.temperature, top_k=sp0.top_k, top_p=sp0.top_p,
+                          min_p=sp0.min_p) if seeded else {}
                 firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
                                           **mm_inputs[group[0].request_id], **kw)]
             for g, first in zip(group, firsts):
