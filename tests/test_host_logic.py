@@ -402,6 +402,27 @@ def test_worker_accepts_the_v1_scheduler_output():
         w.execute_model(_sched(cached=["b", "c"], spec={"b": [1, 2]}))
     with pytest.raises(TypeError):
         w.execute_model(object())
+    # what the worker does not implement is refused before anything runs, not served wrongly
+    steps = eng.steps
+    so = _sched(cached=["b", "c"])
+    so.grammar_bitmask = [[0]]
+    with pytest.raises(ValueError, match="structured output"):
+        w.execute_model(so)
+    so = _sched(cached=["b", "c"])
+    so.kv_connector_metadata = object()
+    with pytest.raises(ValueError, match="connector"):
+        w.execute_model(so)
+    for bad in ({"logprobs": 3}, {"repetition_penalty": 1.2}, {"logit_bias": {5: 1.0}},
+                {"allowed_token_ids": [1, 2]}, {"presence_penalty": 0.5}):
+        with pytest.raises(ValueError, match="not supported"):
+            w.execute_model(_sched(new=[_NewRequestData("z", [1, 2], sampling_params=bad)], cached=["b", "c"]))
+    assert eng.steps == steps
+    # neutral values of the same fields are fine, and the filters travel to the engine's request
+    ok = {"logprobs": None, "repetition_penalty": 1.0, "top_k": 40, "top_p": 0.9, "min_p": 0.0}
+    from vllm_omni_draft_amd.spec_decode_worker import request_from_scheduler_output
+    req = request_from_scheduler_output(_sched(new=[_NewRequestData("z", [1, 2], sampling_params=ok)]))
+    sp = req.seq_group_metadata_list[0].sampling_params
+    assert (sp.top_k, sp.top_p, sp.min_p) == (40, 0.9, 0.0)
 
 
 def test_a_refused_step_loses_no_tokens():

@@ -134,6 +134,12 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
     list of objects with `req_id`: both layouts exist upstream), `finished_req_ids` is passed
     through, `scheduled_spec_decode_tokens` (req_id -> proposed token ids) become the step's
     external proposals.  Running requests come first, in the scheduler's order."""
+    # what a V1 scheduler may ask of a model runner and this worker does not do is refused
+    # here, before anything runs, rather than served wrongly
+    if _get(so, "grammar_bitmask", None) is not None or _get(so, "structured_output_request_ids", None):
+        raise ValueError("structured output (a grammar bitmask over the logits) is not supported")
+    if _get(so, "kv_connector_metadata", None) is not None:
+        raise ValueError("KV-cache connectors (transfers to or from another worker) are not supported")
     new = list(_get(so, "scheduled_new_reqs", None) or [])
     cached = _get(so, "scheduled_cached_reqs", None)
     if cached is None:
@@ -153,6 +159,16 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
         if _get(r, "num_computed_tokens", 0):
             raise ValueError(f"request {rid}: prefix-cached prompt tokens are not supported")
         sp = _get(r, "sampling_params", None)
+        for name, off in (("logprobs", None), ("prompt_logprobs", None), ("logit_bias", None),
+                          ("bad_words", None), ("allowed_token_ids", None), ("repetition_penalty", 1.0),
+                          ("presence_penalty", 0.0), ("frequency_penalty", 0.0)):
+            val = _get(sp, name, off) if sp is not None else off
+            if val is not None and val != off and val != [] and val != {}:
+                raise ValueError(f"request {rid}: sampling_params.{name}={val!r} is not supported")
+        if _get(r, "pooling_params", None) is not None:
+            raise ValueError(f"request {rid}: pooling requests are not supported")
+        if _get(r, "lora_request", None) is not None:
+            raise ValueError(f"request {rid}: LoRA adapters are not supported")
         params = SamplingParams(temperature=_get(sp, "temperature", None),
                                 max_tokens=_get(sp, "max_tokens", 16) or 16,
                                 seed=_get(sp, "seed", None),
