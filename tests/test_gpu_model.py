@@ -373,6 +373,75 @@ def test_draft_head_over_a_vocabulary_subset(use_graph):
                 dw, 3)
 
 
+@pytest.mark.parametrize("temperature", [0.0, 0.8])
+def test_prompts_prefilled_in_pieces_between_steps(temperature):
+    """prefill_begin / prefill_advance (a scheduler with chunked prefill): prompts enter piece by
+    piece while the running sequences keep stepping, two prompts at once finishing in the other
+    order than they began, a whole prompt admitted in between, a neighbour leaving; every stream
+    equals the one the request gets alone."""
+    tcfg, dcfg = MODELS["llama"], MODELS["opt"]
+    dcfg = OracleConfig(**{**vars(dcfg), "vocab": tcfg.vocab})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)))
+    rng = np.random.default_rng(8)
+    P = [[int(t) for t in rng.integers(0, tcfg.vocab, n)] for n in (9, 70, 33, 12, 1)]
+    kw = dict(temperature=temperature)
+
+    def alone(i, n=26):
+        eng = _engine(tw, dw, 3, max_batch=1, **kw)
+        out = [eng.add_request(0, P[i], seed=100 + i)]
+        while len(out) < n:
+            out += eng.step()[0]
+        return out[:n]
+
+    want = [alone(i) for i in range(len(P))]
+    eng = _engine(tw, dw, 3, max_batch=4, **kw)
+    outs = {0: [eng.add_request(0, P[0], seed=100)]}
+    order = [0]                                            # request at each active slot
+
+    def step():
+        for i, new in zip(order, eng.step()):
+            outs[i].extend(new)
+
+    h1 = eng.prefill_begin(P[1], seed=101)                 # 70 tokens in pieces of 32, 30, 8
+    h2 = eng.prefill_begin(P[2], seed=102)                 # 33 tokens in pieces of 32, 1
+    assert eng.prefill_advance(h1, 32) is None
+    step()
+    assert eng.prefill_advance(h2, 32) is None
+    outs[3] = [eng.add_request(eng.active, P[3], seed=103)]   # a whole prompt in between
+    order.append(3)
+    step()
+    assert eng.prefill_advance(h1, 30) is None
+    first = eng.prefill_advance(h2, 1)                     # the later prompt finishes first
+    assert first is not None
+    outs[2] = [first]
+    order.append(2)
+    step()
+    eng.remove_request(0)                                  # request 0 leaves: the last active moves in
+    order[0] = order.pop()
+    step()
+    outs[1] = [eng.prefill_advance(h1, 8)]
+    order.append(1)
+    with pytest.raises(KeyError):
+        eng.prefill_advance(h1, 1)
+    h4 = eng.prefill_begin(P[4], seed=104)                 # a one-token prompt: one piece
+    outs[4] = [eng.prefill_advance(h4, 1)]
+    order.append(4)
+    with pytest.raises(ValueError):
+        eng.prefill_begin(P[0])                            # the batch is full
+    while min(len(outs[i]) for i in (1, 2, 3, 4)) < 26:
+        step()
+    for i in (1, 2, 3, 4):
+        assert outs[i][:26] == want[i], i
+    assert outs[0] == want[0][:len(outs[0])]
+    # abort frees the slot
+    eng.remove_request(0)
+    h = eng.prefill_begin(P[1])
+    eng.prefill_advance(h, 10)
+    eng.prefill_abort(h)
+    assert eng.prefill_begin(P[0]) is not None
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_wide_batch_spec_equals_ar(use_graph):
     """8 sequences x (k+1 = 6) rows = 48 rows per verify pass: the wide kernel family.  The

@@ -199,6 +199,11 @@ class SpecEngine:
         self.d_kv = (PagedKVCache(draft.cfg, pages, B, self.max_ctx, dev)
                      if self.draft is not None else None)
         self._pending_props: Optional[List[List[int]]] = None
+        # prompts that are being prefilled piece by piece (prefill_begin / prefill_advance):
+        # handle -> {prompt, done, slot, sampling arguments}; they hold batch slots behind the
+        # active sequences, taken from the top of the batch
+        self._prefilling: dict = {}
+        self._next_handle = 1
         if self.ngram:
             self.history: List[List[int]] = [[] for _ in range(B)]   # prompt + emitted tokens
         if self.host_props:
@@ -353,6 +358,7 @@ class SpecEngine:
         self.gen_counts.zero_()
         self.counters.zero_()
         self.active = 0
+        self._prefilling.clear()
 
     def set_synthetic_acceptance(self, truth: Optional[torch.Tensor], accept_prob: float = 0.0,
                                  seed: int = 0, pattern: Optional[Sequence[int]] = None,
@@ -436,8 +442,117 @@ class SpecEngine:
         self.u_counters[slot] = 0
         return ops.uniform24(seed, 1 << 63, 0)    # a counter value no step reaches
 
+    # ---- prompts prefilled in pieces (a scheduler with chunked prefill)
+    def prefill_begin(self, prompt: Sequence[int], seed: Optional[int] = None,
+                      temperature: Optional[float] = None, top_k: int = 0, top_p: float = 1.0,
+                      min_p: float = 0.0) -> int:
+        """Reserves a batch slot for a text prompt that will be prefilled piece by piece and
+        returns its handle.  The sequence joins the batch when prefill_advance has consumed the
+        whole prompt; until then steps of the active sequences go on as usual."""
+        n = len(prompt)
+        if n < 1 or n + 1 > self.cfg.max_seq_len:
+            raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
+        if self.active + len(self._prefilling) + 1 > self.cfg.max_batch:
+            raise ValueError("no free batch slot for another prompt")
+        self._set_temperature(-1, temperature, top_k, top_p, min_p)   # validates only
+        used = {e["slot"] for e in self._prefilling.values()}
+        slot = max(s for s in range(self.active, self.cfg.max_batch) if s not in used)
+        h, self._next_handle = self._next_handle, self._next_handle + 1
+        self._prefilling[h] = dict(prompt=[int(t) for t in prompt], done=0, slot=slot, seed=seed,
+                                   sampling=(temperature, top_k, top_p, min_p))
+        with _rt.stream_ctx(self.stream):
+            self.t_kv.ensure_capacity(slot, n + self._slack)
+            if self.d_kv is not None:
+                self.d_kv.ensure_capacity(slot, n + self._slack)
+        return h
+
+    def prefill_advance(self, handle: int, n_tokens: int) -> Optional[int]:
+        """Runs the next n_tokens prompt tokens of a prefill_begin prompt through both models.
+        Returns None while prompt tokens remain; with the last one the sequence becomes the next
+        active one (slot == the number of active sequences before the call) and its first
+        generated token is returned (this synchronises).  A row's bits do not depend on how the
+        prompt was cut, so the stream equals that of add_request."""
+        if self._inflight is not None:
+            raise RuntimeError("flush() the step in flight before changing the batch")
+        e = self._prefilling.get(handle)
+        if e is None:
+            raise KeyError(f"no prompt is being prefilled under handle {handle}")
+        prompt, done = e["prompt"], e["done"]
+        n = len(prompt)
+        if n_tokens < 1 or done + n_tokens > n:
+            raise ValueError(f"{n_tokens} tokens asked for, {n - done} of the prompt remain")
+        end = done + n_tokens
+        with _rt.stream_ctx(self.stream):
+            if end == n:
+                self._vacate_active_slot(keep=handle)
+                if e["slot"] != self.active:
+                    for kv in (self.t_kv, self.d_kv):
+                        if kv is not None:
+                            kv.swap_slots(e["slot"], self.active)
+                    e["slot"] = self.active
+                del self._prefilling[handle]
+                temperature, top_k, top_p, min_p = e["sampling"]
+                self._set_temperature(self.active, temperature, top_k, top_p, min_p)
+                return self._add_request(self.active, prompt, seed=e["seed"], start=done)
+            self._prefill_range(e["slot"], prompt, done, end, final=False)
+            e["done"] = end
+            return None
+
+    def prefill_abort(self, handle: int) -> None:
+        """Drops a prompt that is being prefilled and frees its pages."""
+        e = self._prefilling.pop(handle, None)
+        if e is not None:
+            for kv in (self.t_kv, self.d_kv):
+                if kv is not None:
+                    kv.release(e["slot"])
+
+    def _vacate_active_slot(self, keep: Optional[int] = None) -> None:
+        """Slot `active` is about to be filled: a prompt still being prefilled there (other than
+        `keep`) moves to a free slot further up."""
+        for h, e in self._prefilling.items():
+            if e["slot"] == self.active and h != keep:
+                used = {x["slot"] for x in self._prefilling.values()}
+                free = [s for s in range(self.active + 1, self.cfg.max_batch) if s not in used]
+                if not free:
+                    raise ValueError("no free batch slot: finish or abort a prompt being prefilled")
+                for kv in (self.t_kv, self.d_kv):
+                    if kv is not None:
+                        kv.swap_slots(e["slot"], free[-1])
+                e["slot"] = free[-1]
+
+    def _prefill_range(self, slot: int, prompt: Sequence[int], c_from: int, c_to: int, final: bool,
+                       rope_positions=None, input_embeds=None) -> None:
+        """Passes over prompt tokens c_from..c_to-1 of the sequence in `slot` (both models, chunks
+        of prefill_rows tokens on the wide family).  final: c_to is the prompt's end; its last
+        token gets a pass of its own whose logits (target) land in t_out[0]."""
+        n = len(prompt)
+        self.prompt_buf[c_from:c_to].copy_(torch.tensor(list(prompt[c_from:c_to]), dtype=torch.int32))
+        self._ctx = self._ctx_bucket(n + self._slack)
+        zl = self.zero_lens[slot:slot + 1]
+        body_end = c_to - 1 if final else c_to
+        for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
+            if model is None:
+                continue
+            # only the last token's logits are needed, so the prompt ends with a 1-token pass
+            chunk = model.prefill_rows
+            wide = chunk > MAX_ROWS or self.wide
+            bounds = list(range(c_from, body_end, chunk)) + ([body_end] if final else [])
+            ends = bounds[1:] + [c_to]
+            for c0, c1 in zip(bounds, ends):
+                if c1 <= c0:
+                    continue
+                want = final and c1 == n and model is self.target
+                view = _KvView(kv, slot)
+                mm = {}
+                if rope_positions is not None and model.cfg.mrope_section:
+                    mm["rope_pos"] = rope_positions[:, c0:c1].contiguous()
+                if input_embeds is not None and model is self.target:
+                    mm["input_embeds"] = input_embeds[c0:c1].contiguous()
+                model.forward(view, self.prompt_buf, 0, c0, zl, c0, 1, c1 - c0,
+                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=wide, **mm)
+
     def _add_request(self, slot: int, prompt: Sequence[int], input_embeds=None,
-                     rope_positions=None, seed: Optional[int] = None) -> int:
+                     rope_positions=None, seed: Optional[int] = None, start: int = 0) -> int:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
         n = len(prompt)
@@ -445,10 +560,10 @@ class SpecEngine:
             raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
         if slot != self.active:
             raise ValueError("slots must be filled in order (slot == number of active sequences)")
+        self._vacate_active_slot()
         self.t_kv.ensure_capacity(slot, n + self._slack)
         if self.d_kv is not None:
             self.d_kv.ensure_capacity(slot, n + self._slack)
-        self.prompt_buf[:n].copy_(torch.tensor(list(prompt), dtype=torch.int32))
         delta = 0
         if rope_positions is not None:
             if not self.target.cfg.mrope_section:
@@ -462,26 +577,9 @@ class SpecEngine:
                 raise ValueError(f"input_embeds must be [{n}, {self.target.cfg.hidden}]")
             input_embeds = input_embeds.to(device=self.device, dtype=torch.bfloat16)
         self.rope_delta[slot] = delta
-        self._ctx = self._ctx_bucket(n + self._slack)
-        zl = self.zero_lens[slot:slot + 1]
-        for model, kv in ((self.target, self.t_kv), (self.draft, self.d_kv)):
-            if model is None:
-                continue
-            # prefill in chunks of the model's prefill_rows tokens (wide kernel family); only
-            # the last token's logits are needed, so the last chunk ends with a 1-token pass
-            chunk = model.prefill_rows
-            wide = chunk > MAX_ROWS or self.wide
-            bounds = list(range(0, n - 1, chunk)) + [n - 1]
-            for c0, c1 in zip(bounds, bounds[1:] + [n]):
-                want = c1 == n and model is self.target
-                view = _KvView(kv, slot)
-                mm = {}
-                if rope_positions is not None and model.cfg.mrope_section:
-                    mm["rope_pos"] = rope_positions[:, c0:c1].contiguous()
-                if input_embeds is not None and model is self.target:
-                    mm["input_embeds"] = input_embeds[c0:c1].contiguous()
-                model.forward(view, self.prompt_buf, 0, c0, zl, c0, 1, c1 - c0,
-                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=wide, **mm)
+        # (start > 0: the tokens before it went through prefill_advance already)
+        self._prefill_range(slot, prompt, start, n, final=True, rope_positions=rope_positions,
+                            input_embeds=input_embeds)
         # first generated token from the last prompt row (a 1-token pass: row 0)
         if self.sampling:
             self._target_full_rows(1)
@@ -541,8 +639,13 @@ class SpecEngine:
         Bp, slot0 = len(prompts), self.active
         if Bp == 0:
             return []
-        if slot0 + Bp > self.cfg.max_batch:
+        if slot0 + Bp + len(self._prefilling) > self.cfg.max_batch:
             raise ValueError(f"{Bp} prompts do not fit behind {slot0} active sequences")
+        if self._prefilling:      # slots active.. must be free: one at a time moves the others up
+            out = []
+            for i, p in enumerate(prompts):   # (sampling arguments were stored for slot0 + i)
+                out.append(self._add_request(self.active, p, seed=None if seeds is None else seeds[i]))
+            return out
         lens = [len(p) for p in prompts]
         for n in lens:
             if n < 1 or n + 1 > self.cfg.max_seq_len:

@@ -93,6 +93,15 @@ class PagedKVCache:
         self._host_tables[src] = []
         self.block_tables[dst].copy_(self.block_tables[src])
 
+    def swap_slots(self, a: int, b: int) -> None:
+        """Batch slots a and b exchange their pages (either may be empty)."""
+        if a == b:
+            return
+        self._host_tables[a], self._host_tables[b] = self._host_tables[b], self._host_tables[a]
+        row = self.block_tables[a].clone()
+        self.block_tables[a].copy_(self.block_tables[b])
+        self.block_tables[b].copy_(row)
+
     @staticmethod
     def pages_for(cfg: ModelConfig, max_batch: int, max_seq_len: int) -> int:
         return max_batch * ((max_seq_len + PAGE - 1) // PAGE)
