@@ -351,6 +351,44 @@ def test_v1_scheduler_output_path_gives_the_autoregressive_streams(use_graph):
         assert got[r][:n] == want[r][:n], r
 
 
+def test_v1_chunked_prefill_through_the_worker():
+    """A V1 scheduler with chunked prefill: a long prompt arrives as num_scheduled_tokens pieces
+    over several steps (first as a new request, then among the cached ones) while another request
+    keeps decoding; a piece emits no token, the last one the first token; a prompt can be dropped
+    half-way.  Streams equal the autoregressive ones."""
+    from tests.test_host_logic import _NewRequestData, _sched
+    tw, dw = _llama_pair()
+    prompts = {"r0": [5, 9, 200, 31, 7], "long": [int(t) for t in np.random.default_rng(1).integers(0, 256, 90)],
+               "gone": list(range(60, 110))}
+    want = {r: _generate(_engine(tw, None, 0), [p], 24)[0] for r, p in prompts.items()}
+    w = _worker(tw, dw, 3, True)
+    got = {r: [] for r in prompts}
+    N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0})
+
+    def run(new=(), cached=(), pieces=None, finished=()):
+        so = _sched(new=list(new), cached=list(cached), finished=finished)
+        so.num_scheduled_tokens.update(pieces or {})
+        out = w.execute_model(so)
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            got[r].extend(toks)
+        return dict(zip(out.req_ids, out.sampled_token_ids))
+
+    run(new=[N("r0")])
+    o = run(new=[N("long")], cached=["r0"], pieces={"long": 40})          # first piece
+    assert o["long"] == [] and len(o["r0"]) >= 1
+    o = run(new=[N("gone")], cached=["r0", "long"], pieces={"long": 30, "gone": 20})
+    assert o["long"] == [] and o["gone"] == []
+    with pytest.raises(ValueError):
+        run(cached=["r0", "long"], pieces={"long": 21})                    # more than what remains
+    o = run(cached=["r0", "long"], pieces={"long": 20}, finished=["gone"])  # last piece; "gone" dropped
+    assert len(o["long"]) == 1 and w.engine.active == 2 and not w._prefill_of
+    while min(len(got[r]) for r in ("r0", "long")) < 24:
+        run(cached=["long", "r0"])
+    for r in ("r0", "long"):
+        assert got[r][:24] == want[r], r
+    assert got["gone"] == []
+
+
 class _StubProposer:
     """A proposer made outside the worker: it knows the target's true stream and proposes a
     continuation of `lens[r]` tokens for request r, with an error injected at position

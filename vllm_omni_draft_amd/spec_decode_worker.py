@@ -70,6 +70,10 @@ class SequenceGroupMetadata:
     # layout) or "image_embeds" (the vision tower's output rows); the prompt holds one run of
     # placeholder tokens per image.
     multi_modal_data: Optional[dict] = None
+    # Chunked prefill: how many prompt tokens this step may compute (None: the whole prompt in
+    # this step).  A prompt that is not finished emits nothing; it is continued by naming the
+    # request again (is_prompt False) with the next piece's size.
+    num_prompt_tokens: Optional[int] = None
 
 
 @dataclass
@@ -149,13 +153,17 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
     else:
         cached_ids = [_get(c, "req_id") for c in cached]
     n_tok = _get(so, "num_scheduled_tokens", None) or {}
-    metas = [SequenceGroupMetadata(rid, False) for rid in cached_ids]
+    # (for a running request the count is 1 + its speculative tokens and means nothing here; for
+    # a prompt still being prefilled it is the next piece, which the worker picks up)
+    metas = [SequenceGroupMetadata(rid, False, num_prompt_tokens=n_tok.get(rid)) for rid in cached_ids]
     for r in new:
         rid = _get(r, "req_id")
         prompt = list(_get(r, "prompt_token_ids", None) or [])
+        piece = None
         if rid in n_tok and n_tok[rid] != len(prompt):
-            raise ValueError(f"request {rid}: {n_tok[rid]} of {len(prompt)} prompt tokens scheduled; "
-                             "this worker prefills a prompt in one step (no chunked prefill)")
+            if not 1 <= n_tok[rid] < len(prompt):
+                raise ValueError(f"request {rid}: {n_tok[rid]} tokens scheduled for a prompt of {len(prompt)}")
+            piece = int(n_tok[rid])          # chunked prefill: the first piece
         if _get(r, "num_computed_tokens", 0):
             raise ValueError(f"request {rid}: prefix-cached prompt tokens are not supported")
         sp = _get(r, "sampling_params", None)
@@ -184,7 +192,8 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
                     mm = item if isinstance(item, dict) else {
                         k: _get(item, k) for k in ("image_grid_thw", "pixel_values", "image_embeds")
                         if _get(item, k, None) is not None}
-        metas.append(SequenceGroupMetadata(rid, True, prompt, params, multi_modal_data=mm))
+        metas.append(SequenceGroupMetadata(rid, True, prompt, params, multi_modal_data=mm,
+                                           num_prompt_tokens=piece))
     spec = _get(so, "scheduled_spec_decode_tokens", None) or {}
     return ExecuteModelRequest(metas, finished_requests_ids=list(_get(so, "finished_req_ids", None) or []),
                                external_proposals={rid: list(t) for rid, t in spec.items()} or None)
@@ -508,6 +517,8 @@ class SpecDecodeWorker:
         self.metrics: Optional[AsyncMetricsCollector] = None
         self._slot_of: Dict[str, int] = {}
         self._req_at: List[str] = []
+        self._prefill_of: Dict[str, int] = {}     # request id -> engine handle of a prompt in pieces
+        self._prefill_left: Dict[str, int] = {}   # request id -> prompt tokens not yet computed
         if engine is not None:
             self._wire()
 
@@ -642,9 +653,14 @@ class SpecDecodeWorker:
             req = request_from_scheduler_output(req)
         eng = self.engine
         metas = req.seq_group_metadata_list
-        running = [g for g in metas if not g.is_prompt]
-        prompts = [g for g in metas if g.is_prompt]
+        # prompts that arrive in pieces (chunked prefill): first pieces and continuations
+        continued = [g for g in metas if not g.is_prompt and g.request_id in self._prefill_of]
+        running = [g for g in metas if not g.is_prompt and g.request_id not in self._prefill_of]
+        pieces = [g for g in metas if g.is_prompt and g.num_prompt_tokens is not None
+                  and g.num_prompt_tokens < len(g.prompt_token_ids)]
+        prompts = [g for g in metas if g.is_prompt and g not in pieces]
         finished = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._slot_of]
+        dropped = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._prefill_of]
 
         # ---- validation (nothing has run yet)
         have = getattr(getattr(eng, "cfg", None), "temperature", None)
@@ -654,7 +670,21 @@ class SpecDecodeWorker:
             if g.request_id in seen:
                 raise KeyError(f"request {g.request_id} is listed twice")
             seen.add(g.request_id)
-        for g in prompts:
+        if (pieces or continued) and not hasattr(eng, "prefill_begin"):
+            raise ValueError("this engine prefills a prompt in one step (no chunked prefill)")
+        for g in pieces:
+            if g.multi_modal_data:
+                raise ValueError(f"request {g.request_id}: a prompt with images is prefilled in one step")
+            if g.num_prompt_tokens < 1:
+                raise ValueError(f"request {g.request_id}: a piece of {g.num_prompt_tokens} prompt tokens")
+        for g in continued:
+            left = self._prefill_left[g.request_id]
+            if g.num_prompt_tokens is None or not 1 <= g.num_prompt_tokens <= left:
+                raise ValueError(f"request {g.request_id}: {left} prompt tokens remain, the step "
+                                 f"schedules {g.num_prompt_tokens}")
+            if g.request_id in dropped:
+                raise ValueError(f"request {g.request_id} is continued and listed as finished")
+        for g in prompts + pieces:
             sp = g.sampling_params
             if sp.temperature is not None and have is not None:
                 t = float(sp.temperature)
@@ -669,7 +699,8 @@ class SpecDecodeWorker:
             if not 0.0 < float(sp.top_p) <= 1.0 or not 0.0 <= float(sp.min_p) <= 1.0:
                 raise ValueError(f"request {g.request_id}: top_p {sp.top_p} must be in (0, 1] and "
                                  f"min_p {sp.min_p} in [0, 1]")
-            if g.request_id in self._slot_of and g.request_id not in finished:
+            if (g.request_id in self._slot_of and g.request_id not in finished) or (
+                    g.request_id in self._prefill_of and g.request_id not in dropped):
                 raise KeyError(f"request {g.request_id} is already running")
             n = len(g.prompt_token_ids)
             if n < 1 or (max_len is not None and n + 1 > max_len):
@@ -684,7 +715,8 @@ class SpecDecodeWorker:
         if len(running) != n_after:
             raise ValueError(f"{n_after} sequences are running but the step names {len(running)}: "
                              "list every running request or finish it")
-        if n_after + len(prompts) > eng.cfg.max_batch:
+        n_prefilling = len(self._prefill_of) - len(dropped)
+        if n_after + n_prefilling + len(prompts) + len(pieces) > eng.cfg.max_batch:
             raise RuntimeError("no free sequence slot (max_num_seqs reached)")
         ext = req.external_proposals
         if ext is not None and not getattr(eng, "external", False):
@@ -696,6 +728,9 @@ class SpecDecodeWorker:
         # ---- the step
         for rid in finished:
             self._finish(rid)
+        for rid in dropped:
+            eng.prefill_abort(self._prefill_of.pop(rid))
+            self._prefill_left.pop(rid, None)
         out: Dict[str, List[int]] = {}
         if running:
             if ext is not None:
@@ -731,6 +766,24 @@ class SpecDecodeWorker:
                 self._req_at.append(g.request_id)
                 out[g.request_id] = [first]
             i += len(group)
+        # prompts in pieces: a piece emits nothing; the last one admits the sequence and emits
+        # its first token
+        seeded = bool(getattr(eng, "sampling", False))
+        for g in pieces:
+            sp = g.sampling_params
+            kw = dict(seed=sp.seed, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
+                      min_p=sp.min_p) if seeded else {}
+            self._prefill_of[g.request_id] = eng.prefill_begin(g.prompt_token_ids, **kw)
+            self._prefill_left[g.request_id] = len(g.prompt_token_ids)
+        for g in pieces + continued:
+            first = eng.prefill_advance(self._prefill_of[g.request_id], g.num_prompt_tokens)
+            self._prefill_left[g.request_id] -= g.num_prompt_tokens
+            out[g.request_id] = []
+            if first is not None:
+                del self._prefill_of[g.request_id], self._prefill_left[g.request_id]
+                self._slot_of[g.request_id] = len(self._req_at)
+                self._req_at.append(g.request_id)
+                out[g.request_id] = [first]
         ids = [g.request_id for g in metas]
         return ModelRunnerOutput(
             req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
