@@ -122,6 +122,21 @@ int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
 int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_k, const float* top_p,
                         const float* min_p, int rows_per_seq, int R, int V, sd_stream_t stream);
 
+/* Log-probabilities of chosen tokens, for ModelRunnerOutput.logprobs
+ * (/root/reference/src/doc/engine_core.md:326-329: token ids, log-probabilities and ranks per
+ * sampled token, max_num_logprobs + 1 columns).  Row r of logits [R, ld] (f32, raw: no
+ * temperature, no filters) and tokens[r] give out_ids[r, 0] = tokens[r], out_logprobs[r, 0] =
+ * logits[r, tokens[r]] - logsumexp(row) and out_ranks[r] = the number of entries >= the chosen
+ * one (1 for the most likely token; upstream counts ties the same way); columns 1..n_top hold
+ * the n_top largest entries of the row, largest first, ties by lower index (id -1 and -inf past
+ * the row's finite entries).  A token id outside 0..V-1 skips row r (its outputs are left alone).
+ * out_ids / out_logprobs are [R, n_top + 1]; 0 <= n_top <= SD_LOGPROBS_TOP_MAX.  One workgroup
+ * per row; n_top + 3 passes over the row.                                                   */
+#define SD_LOGPROBS_TOP_MAX 32
+int sd_token_logprobs(const float* logits, int64_t ld, const int32_t* tokens, int R, int V,
+                      int n_top, int32_t* out_ids, float* out_logprobs, int32_t* out_ranks,
+                      sd_stream_t stream);
+
 /* sd_softmax_rows(_split) with one temperature per sequence (per-request SamplingParams.
  * temperature): row r uses temperatures[r / rows_per_seq] (device, f32).  A temperature of 0 asks
  * for the greedy distribution: probability 1 on the first maximum of the row, so that the

@@ -175,3 +175,32 @@ def filter_probs(p: np.ndarray, top_k: int = 0, top_p: float = 1.0, min_p: float
         keep &= p >= cut
     out = np.where(keep, p, 0.0)
     return out / out.sum()
+
+
+def token_logprobs(logits: np.ndarray, tokens, n_top: int = 0):
+    """Log-probability and rank of tokens[r] under raw logits row r, plus the n_top most likely
+    entries of the row.  Follows upstream's sampler (vllm/v1/sample/sampler.py compute_logprobs /
+    gather_logprobs: log_softmax of the raw logits in float32, top-n by value, rank = number of
+    entries >= the chosen token's), the layout of ModelRunnerOutput.logprobs at
+    /root/reference/src/doc/engine_core.md:326-329 (column 0 the sampled token, then the top
+    max_num_logprobs).  Ties among the top entries are ordered by lower index (upstream's topk
+    leaves that order unspecified).  float64 arithmetic.
+    Returns (ids [R, n_top+1] int64, logprobs [R, n_top+1] float64, ranks [R] int64)."""
+    x = np.asarray(logits, dtype=np.float64)
+    R, V = x.shape
+    mx = x.max(axis=1, keepdims=True)
+    lp = x - (mx + np.log(np.exp(x - mx).sum(axis=1, keepdims=True)))
+    ids = np.full((R, n_top + 1), -1, dtype=np.int64)
+    out = np.full((R, n_top + 1), -np.inf)
+    ranks = np.zeros(R, dtype=np.int64)
+    for r in range(R):
+        t = int(tokens[r])
+        if not 0 <= t < V:
+            continue
+        ids[r, 0], out[r, 0] = t, lp[r, t]
+        ranks[r] = int((x[r] >= x[r, t]).sum())
+        order = np.lexsort((np.arange(V), -x[r]))[:n_top]      # value descending, index ascending
+        order = order[np.isfinite(x[r, order])]
+        ids[r, 1:1 + order.size] = order
+        out[r, 1:1 + order.size] = lp[r, order]
+    return ids, out, ranks

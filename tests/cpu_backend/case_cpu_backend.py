@@ -93,6 +93,21 @@ def test_acceptance_entry_points_match_the_oracle():
     assert ops.argmax_from_partials(pv, pi, 6).tolist() == sampling.argmax_rows(x).tolist()
 
 
+def test_token_logprobs_match_the_oracle():
+    from vllm_omni_draft_amd import ops
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((5, 1000)) * 3).astype(np.float32)
+    x[1, 17] = x[1, 900] = x[1].max() + 1.0
+    x[4, 3:] = -np.inf
+    toks = np.array([int(x[0].argmax()), 900, -1, 123, 1], dtype=np.int32)
+    ids, lps, ranks = ops.token_logprobs(torch.from_numpy(x), torch.from_numpy(toks), 4)
+    w_ids, w_lps, w_ranks = sampling.token_logprobs(x, toks, 4)
+    assert np.array_equal(ids.numpy(), w_ids) and np.array_equal(ranks.numpy(), w_ranks)
+    fin = np.isfinite(w_lps)
+    assert np.array_equal(np.isfinite(lps.numpy()), fin)
+    assert np.abs(lps.numpy()[fin] - w_lps[fin]).max() < 2e-5
+
+
 def test_config1_plumbing_opt125m_shapes_through_the_worker():
     """BASELINE.json configs[0]: facebook/opt-125m target + opt-125m draft (the same weights),
     k = 3, greedy, batch 8, one process, no GPU.  The draft IS the target, so every proposal is

@@ -431,3 +431,47 @@ def test_top_k_top_p_min_p_filter_matches_oracle(V):
         assert any(np.array_equal(got[r] > 0, c > 0) and np.allclose(got[r], c, rtol=2e-5, atol=1e-9)
                    for c in cands), (r, q, (got[r] > 0).sum(), [(c > 0).sum() for c in cands])
         assert abs(got[r].sum() - 1.0) < 1e-5
+
+
+@pytest.mark.parametrize("V", [1000, 50272, 128256, 151936])
+def test_token_logprobs_match_oracle(V):
+    """sd_token_logprobs against the oracle (float64 log-softmax): chosen token's log-probability
+    and rank, the top entries in (value, index) order, with exact ties in the top, a skipped row,
+    the most and the least likely token chosen, and a row with -inf entries."""
+    ops, DEV = _ops(), "cuda"
+    g = torch.Generator().manual_seed(V)
+    R, n_top = 7, 5
+    x = (torch.randn(R, V, generator=g) * 3.0).float()
+    x[1, 17] = x[1, 900] = x[1].max() + 1.0          # a tie at the top: lower index first
+    x[2, 5] = x[2, 6] = x[2, 7] = x[2].max() + 0.5   # three equal
+    x[5, 10:] = float("-inf")                        # ten finite entries
+    x[6, 3:] = float("-inf")                         # fewer finite entries than n_top
+    toks = torch.randint(0, V, (R,), generator=g, dtype=torch.int32)
+    toks[0] = int(x[0].argmax())
+    toks[1] = 900
+    toks[3] = -1                                     # skipped
+    toks[4] = int(x[4].argmin())
+    toks[5] = 4
+    toks[6] = 1
+    ids, lps, ranks = ops.token_logprobs(x.to(DEV), toks.to(DEV), n_top)
+    ids, lps, ranks = ids.cpu().numpy(), lps.cpu().numpy().astype(np.float64), ranks.cpu().numpy()
+    w_ids, w_lps, w_ranks = sampling.token_logprobs(x.numpy(), toks.numpy(), n_top)
+    w_lps[3], w_ids[3] = -np.inf, -1                 # the skipped row keeps the wrapper's fill
+    np.testing.assert_array_equal(ids, w_ids)
+    np.testing.assert_array_equal(ranks, w_ranks)
+    finite = np.isfinite(w_lps)
+    assert (np.isfinite(lps) == finite).all()
+    # tolerance: float32 logsumexp (f64 sum of f32 exponentials) against the float64 oracle
+    np.testing.assert_allclose(lps[finite], w_lps[finite], rtol=0, atol=2e-5)
+    assert ranks[0] == 1 and ranks[1] == 2 and ranks[4] == V
+
+
+def test_token_logprobs_without_top_entries():
+    ops, DEV = _ops(), "cuda"
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 4096, generator=g).float()
+    toks = torch.tensor([0, 4095, 77, 1234], dtype=torch.int32)
+    ids, lps, ranks = ops.token_logprobs(x.to(DEV), toks.to(DEV), 0)
+    want = torch.log_softmax(x, dim=-1)[torch.arange(4), toks.long()]
+    assert ids.shape == (4, 1) and ids[:, 0].cpu().tolist() == toks.tolist()
+    torch.testing.assert_close(lps[:, 0].cpu(), want, rtol=0, atol=2e-5)

@@ -412,10 +412,15 @@ def test_worker_accepts_the_v1_scheduler_output():
     so.kv_connector_metadata = object()
     with pytest.raises(ValueError, match="connector"):
         w.execute_model(so)
-    for bad in ({"logprobs": 3}, {"repetition_penalty": 1.2}, {"logit_bias": {5: 1.0}},
+    for bad in ({"prompt_logprobs": 3}, {"repetition_penalty": 1.2}, {"logit_bias": {5: 1.0}},
                 {"allowed_token_ids": [1, 2]}, {"presence_penalty": 0.5}):
         with pytest.raises(ValueError, match="not supported"):
             w.execute_model(_sched(new=[_NewRequestData("z", [1, 2], sampling_params=bad)], cached=["b", "c"]))
+    # (log-probabilities of emitted tokens need an engine that computes them; this stub does not)
+    for n, msg in ((3, "computes no log-probabilities"), (99, "outside"), (-1, "outside")):
+        with pytest.raises(ValueError, match=msg):
+            w.execute_model(_sched(new=[_NewRequestData("z", [1, 2], sampling_params={"logprobs": n})],
+                                   cached=["b", "c"]))
     assert eng.steps == steps
     # neutral values of the same fields are fine, and the filters travel to the engine's request
     ok = {"logprobs": None, "repetition_penalty": 1.0, "top_k": 40, "top_p": 0.9, "min_p": 0.0}

@@ -410,6 +410,81 @@ __global__ __launch_bounds__(kSampleThreads) void softmax_rows_kernel(
   for (int i = tid; i < V; i += blockDim.x) out[i] = expf(row[i] * inv_t - mx) * inv;
 }
 
+// Log-probability and rank of one chosen token per row, and the row's n_top largest entries in
+// (value descending, index ascending) order: each is the maximum of what comes after the previous
+// one in that order, so n_top passes over a row that sits in L2 and no sort.
+__global__ __launch_bounds__(kSampleThreads) void token_logprobs_kernel(
+    const float* __restrict__ logits, int64_t ld, const int32_t* __restrict__ tokens, int V, int n_top,
+    int32_t* __restrict__ out_ids, float* __restrict__ out_lp, int32_t* __restrict__ out_rank) {
+  __shared__ float s_f[kSampleWaves];
+  __shared__ int s_i[kSampleWaves];
+  __shared__ double s_d[kSampleWaves];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tok = tokens[r];
+  if (tok < 0 || tok >= V) return;  // block-uniform
+  const float* row = logits + (size_t)r * ld;
+  float mx = -INFINITY;
+  for (int i = tid; i < V; i += blockDim.x) mx = fmaxf(mx, row[i]);
+  mx = wave_max(mx);
+  if (lane == 0) s_f[wave] = mx;
+  __syncthreads();
+  mx = s_f[0];
+  for (int w = 1; w < kSampleWaves; ++w) mx = fmaxf(mx, s_f[w]);
+  const float chosen = row[tok];
+  double sum = 0.0, ge = 0.0;
+  for (int i = tid; i < V; i += blockDim.x) {
+    sum += (double)expf(row[i] - mx);
+    ge += row[i] >= chosen ? 1.0 : 0.0;
+  }
+  const double total = block_sum_f64(sum, s_d);
+  const double n_ge = block_sum_f64(ge, s_d);
+  const float lse = mx + (float)log(total);
+  const size_t o = (size_t)r * (n_top + 1);
+  if (tid == 0) {
+    out_ids[o] = tok;
+    out_lp[o] = chosen - lse;
+    out_rank[r] = (int)n_ge;
+  }
+  float pv = INFINITY;
+  int pi = -1;
+  for (int j = 0; j < n_top; ++j) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += blockDim.x) {
+      const float v = row[i];
+      if ((v < pv || (v == pv && i > pi)) && (v > best || (v == best && i < bi))) {
+        best = v;
+        bi = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(best, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { s_f[wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    best = s_f[0];
+    bi = s_i[0];
+    for (int w = 1; w < kSampleWaves; ++w)
+      if (s_f[w] > best || (s_f[w] == best && s_i[w] < bi)) { best = s_f[w]; bi = s_i[w]; }
+    const bool none = bi == 0x7fffffff || best == -INFINITY;   // nothing finite is left
+    if (tid == 0) {
+      out_ids[o + 1 + j] = none ? -1 : bi;
+      out_lp[o + 1 + j] = none ? -INFINITY : best - lse;
+    }
+    if (none) {
+      pv = -INFINITY;
+      pi = 0x7fffffff;
+    } else {
+      pv = best;
+      pi = bi;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // top-k / top-p / min-p of probability rows, in place.  One workgroup per row finds the cut-off
 // VALUE by bisection on the bit pattern of a positive float (which orders like the float): the
@@ -1378,6 +1453,20 @@ extern "C" int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_
                      (size_t)n_lds * kSampleThreads * sizeof(float), (hipStream_t)stream, probs, ld, f, V,
                      n_lds);
   SD_CHECK_LAUNCH("sd_filter_probs_seq");
+  return SD_OK;
+}
+
+extern "C" int sd_token_logprobs(const float* logits, int64_t ld, const int32_t* tokens, int R, int V,
+                                 int n_top, int32_t* out_ids, float* out_logprobs, int32_t* out_ranks,
+                                 sd_stream_t stream) {
+  SD_REQUIRE(logits && tokens && out_ids && out_logprobs && out_ranks && R >= 0 && V >= 1 && ld >= V,
+             SD_ERR_INVALID, "sd_token_logprobs: bad arguments (R=%d V=%d)", R, V);
+  SD_REQUIRE(n_top >= 0 && n_top <= SD_LOGPROBS_TOP_MAX, SD_ERR_INVALID,
+             "sd_token_logprobs: n_top %d outside 0..%d", n_top, SD_LOGPROBS_TOP_MAX);
+  if (R == 0) return SD_OK;
+  hipLaunchKernelGGL(token_logprobs_kernel, dim3(R), dim3(kSampleThreads), 0, (hipStream_t)stream,
+                     logits, ld, tokens, V, n_top, out_ids, out_logprobs, out_ranks);
+  SD_CHECK_LAUNCH("sd_token_logprobs");
   return SD_OK;
 }
 

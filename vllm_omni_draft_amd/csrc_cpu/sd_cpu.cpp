@@ -496,6 +496,53 @@ extern "C" int sd_sample_rows(const float* probs, int64_t ld, const float* u, in
   return SD_OK;
 }
 
+extern "C" int sd_token_logprobs(const float* logits, int64_t ld, const int32_t* tokens, int R, int V,
+                                 int n_top, int32_t* out_ids, float* out_lp, int32_t* out_ranks,
+                                 sd_stream_t) {
+  REQUIRE(logits && tokens && out_ids && out_lp && out_ranks && R >= 0 && V >= 1 && ld >= V &&
+              n_top >= 0 && n_top <= SD_LOGPROBS_TOP_MAX,
+          SD_ERR_INVALID, "sd_token_logprobs: bad arguments");
+#pragma omp parallel for
+  for (int r = 0; r < R; ++r) {
+    const int tok = tokens[r];
+    if (tok < 0 || tok >= V) continue;
+    const float* row = logits + (size_t)r * ld;
+    float mx = -INFINITY;
+    for (int i = 0; i < V; ++i) mx = fmaxf(mx, row[i]);
+    const float chosen = row[tok];
+    double sum = 0.0;
+    int ge = 0;
+    for (int i = 0; i < V; ++i) {
+      sum += (double)expf(row[i] - mx);
+      ge += row[i] >= chosen;
+    }
+    const float lse = mx + (float)log(sum);
+    const size_t o = (size_t)r * (n_top + 1);
+    out_ids[o] = tok;
+    out_lp[o] = chosen - lse;
+    out_ranks[r] = ge;
+    float pv = INFINITY;
+    int pi = -1;
+    for (int j = 0; j < n_top; ++j) {   // successive maxima in (value desc, index asc) order
+      float best = -INFINITY;
+      int bi = -1;
+      for (int i = 0; i < V; ++i) {
+        const float v = row[i];
+        if ((v < pv || (v == pv && i > pi)) && v > best) {
+          best = v;
+          bi = i;
+        }
+      }
+      const bool none = bi < 0;
+      out_ids[o + 1 + j] = none ? -1 : bi;
+      out_lp[o + 1 + j] = none ? -INFINITY : best - lse;
+      pv = none ? -INFINITY : best;
+      pi = none ? V : bi;
+    }
+  }
+  return SD_OK;
+}
+
 extern "C" size_t sd_sampling_scratch_bytes(int R) { return R > 0 ? 64 : 0; }
 extern "C" int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_k, const float* top_p,
                                    const float* min_p, int rows_per_seq, int R, int V, sd_stream_t) {

@@ -326,6 +326,14 @@ class SpecEngine:
                 (2 * kk * B + B * (k + 1), 1, 0, 1)])
             self.bonus_ids = torch.zeros(B, dtype=torch.int64, device=dev)
             self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * (k + 1)), dev)
+        # Log-probabilities of the emitted tokens (ModelRunnerOutput.logprobs): off (None) unless
+        # the caller sets logprobs_top = the number of most likely tokens to report beside each
+        # emitted one (0: the emitted token's own log-probability and rank only).  While it is
+        # set, every synchronous step and every admission leaves last_logprobs: per sequence (in
+        # the order of the call's return value), per emitted token, (token ids [1 + top], their
+        # log-probabilities under the target's raw logits, the emitted token's rank).
+        self.logprobs_top: Optional[int] = None
+        self.last_logprobs: Optional[List[List[tuple]]] = None
         # synthetic acceptance control (benchmarks with random weights)
         self.truth: Optional[torch.Tensor] = None
         self.accept_pattern: List[int] = []
@@ -601,6 +609,8 @@ class SpecEngine:
             self.history[slot] = list(prompt) + [first_tok]
         self.host_gen[slot] = 1
         self.active += 1
+        if self.logprobs_top is not None:
+            self._logprob_rows([[0]], [[first_tok]])
         return first_tok
 
     def add_requests(self, prompts: Sequence[Sequence[int]],
@@ -642,9 +652,12 @@ class SpecEngine:
         if slot0 + Bp + len(self._prefilling) > self.cfg.max_batch:
             raise ValueError(f"{Bp} prompts do not fit behind {slot0} active sequences")
         if self._prefilling:      # slots active.. must be free: one at a time moves the others up
-            out = []
+            out, lp = [], []
             for i, p in enumerate(prompts):   # (sampling arguments were stored for slot0 + i)
                 out.append(self._add_request(self.active, p, seed=None if seeds is None else seeds[i]))
+                lp += self.last_logprobs or []
+            if self.logprobs_top is not None:
+                self.last_logprobs = lp
             return out
         lens = [len(p) for p in prompts]
         for n in lens:
@@ -654,9 +667,13 @@ class SpecEngine:
         if Bp > min(m.prefill_rows for m in (self.target, self.draft) if m is not None):
             # more prompts than rows in a pass: in groups
             out: List[int] = []
+            lp: List[List[tuple]] = []
             per = min(m.prefill_rows for m in (self.target, self.draft) if m is not None)
             for i in range(0, Bp, per):
                 out += self._add_requests(prompts[i:i + per], None if seeds is None else seeds[i:i + per])
+                lp += self.last_logprobs or []
+            if self.logprobs_top is not None:
+                self.last_logprobs = lp
             return out
         if self._prompt_rows is None or self._prompt_rows.shape[0] < Bp:
             self._prompt_rows = torch.zeros(self.cfg.max_batch, max(self.cfg.max_seq_len, 8),
@@ -714,7 +731,42 @@ class SpecEngine:
             if self.ngram:
                 self.history[slot0 + i] = prompts[i] + [firsts[i]]
         self.active += Bp
+        if self.logprobs_top is not None:
+            self._logprob_rows([[i] for i in range(Bp)], [[t] for t in firsts])
         return firsts
+
+    # ------------------------------------------------------------------ log-probabilities
+    def _logprob_rows(self, rows: List[List[int]], toks: List[List[int]]) -> None:
+        """last_logprobs[b][j] for token toks[b][j] chosen from row rows[b][j] of the target's
+        logits of the pass just run (synchronises)."""
+        n = 1 + max((r for rs in rows for r in rs), default=-1)
+        if n == 0:
+            self.last_logprobs = [[] for _ in rows]
+            return
+        if self.vp and not self.sampling:
+            self._target_full_rows(n)     # greedy passes exchanged slice maxima only
+        host = torch.full((n,), -1, dtype=torch.int32)
+        for rs, ts in zip(rows, toks):
+            for r, t in zip(rs, ts):
+                host[r] = int(t)
+        ids, lps, ranks = ops.token_logprobs(self.t_logits[:n], host.to(self.device), int(self.logprobs_top))
+        ids, lps, ranks = ids.tolist(), lps.tolist(), ranks.tolist()
+        self.last_logprobs = [[(ids[r], lps[r], ranks[r]) for r in rs] for rs in rows]
+
+    def _emitted_logprobs(self, out: List[List[int]]) -> None:
+        """Log-probabilities of the tokens the step just read back emitted: token j of a sequence
+        was chosen from the logits row of the position before it."""
+        B, k = self.active, self.k
+        if k == 0 or self._spec_disabled():
+            rows = [[b] if out[b] else [] for b in range(B)]
+        elif self.tree:
+            q = self.tree_nodes + 1
+            path = self.tree_path[:B].tolist()    # rows of the accepted nodes; the root is row 0
+            rows = [[b * q + (0 if j == 0 else path[b][j - 1]) for j in range(len(out[b]))]
+                    for b in range(B)]
+        else:
+            rows = [[b * (k + 1) + j for j in range(len(out[b]))] for b in range(B)]
+        self._logprob_rows(rows, out)
 
     # ------------------------------------------------------------------ passes
     def _forward(self, model: DecoderModel, kv: PagedKVCache, tokens, tok_stride, tok_offset,
@@ -1215,6 +1267,9 @@ class SpecEngine:
         flight.  Not with prompt lookup (its proposals come from the tokens read back)."""
         if self.host_props:
             raise RuntimeError("step_overlapped: host-made proposals need each step's tokens")
+        if self.logprobs_top is not None:
+            raise RuntimeError("step_overlapped: log-probabilities are read from the step's logits, "
+                               "which the next step overwrites")
         if not _rt.on_gpu():
             raise RuntimeError("step_overlapped needs the GPU library (the CPU build is synchronous)")
         with _rt.stream_ctx(self.stream):
@@ -1293,7 +1348,12 @@ class SpecEngine:
                 self.host_lens[b] = rec[b][1]
                 if self.ngram:
                     self.history[b].extend(out[-1])
+            if self.logprobs_top is not None:
+                self._emitted_logprobs(out)
             return out
+        if self.logprobs_top is not None and pending > 1:
+            raise RuntimeError("log-probabilities need a read-back after every step (the logits of "
+                               "earlier steps are gone)")
         counts = self.gen_counts[:B].tolist()
         lens = self.seq_lens[:B].tolist()
         out: List[List[int]] = []

@@ -184,6 +184,27 @@ def softmax_rows(logits: torch.Tensor, temperature=1.0, out=None, *, row_offset=
     return out
 
 
+LOGPROBS_TOP_MAX = 32   # SD_LOGPROBS_TOP_MAX
+
+
+def token_logprobs(logits: torch.Tensor, tokens: torch.Tensor, n_top: int = 0):
+    """Log-probabilities of tokens[r] under raw logits rows [R, V] (float32), the n_top most
+    likely entries of each row and the chosen token's rank (sd_token_logprobs).  tokens: int32
+    [R] on the logits' device; an id outside the vocabulary skips its row.  Returns
+    (ids [R, n_top + 1] int32, logprobs [R, n_top + 1] float32, ranks [R] int32)."""
+    _need(logits, torch.float32, "logits")
+    _need(tokens, torch.int32, "tokens")
+    R, V = logits.shape
+    if tokens.numel() != R:
+        raise _lib.SdError(f"token_logprobs: {tokens.numel()} tokens for {R} rows")
+    ids = torch.full((R, n_top + 1), -1, dtype=torch.int32, device=logits.device)
+    lps = torch.full((R, n_top + 1), float("-inf"), dtype=torch.float32, device=logits.device)
+    ranks = torch.zeros(R, dtype=torch.int32, device=logits.device)
+    _lib.check(_lib.load().sd_token_logprobs(_p(logits), logits.stride(0), _p(tokens), R, V, n_top,
+                                             _p(ids), _p(lps), _p(ranks), _stream()), "sd_token_logprobs")
+    return ids, lps, ranks
+
+
 def filter_probs(probs: torch.Tensor, top_k=None, top_p=None, min_p=None, rows_per_seq: int = 1) -> None:
     """In-place top-k / min-p / top-p filtering of probability rows [R, V] with per-sequence
     parameters (int32 / float32 / float32 device tensors, row r -> sequence r // rows_per_seq;

@@ -56,6 +56,10 @@ class SamplingParams:
     top_p: float = 1.0
     min_p: float = 0.0
     ignore_eos: bool = True
+    # None: no log-probabilities.  n >= 0: ModelRunnerOutput.logprobs carries, for every token
+    # the request emits, its log-probability under the target's raw logits (no temperature, no
+    # filters: upstream's default "raw_logprobs"), its rank, and the n most likely tokens.
+    logprobs: Optional[int] = None
 
 
 @dataclass
@@ -105,16 +109,30 @@ class SpeculativeScores:
 
 
 @dataclass
+class LogprobsLists:
+    """ModelRunnerOutput.logprobs (/root/reference/src/doc/engine_core.md:326-329): one row per
+    emitted token, requests in req_ids order, a request's tokens in order; rows
+    cu_num_generated_tokens[i] .. cu_num_generated_tokens[i + 1] - 1 belong to request i (a
+    speculative step emits a variable number).  Column 0 is the emitted token, columns 1.. the
+    most likely tokens, largest first."""
+    logprob_token_ids: List[List[int]]
+    logprobs: List[List[float]]
+    sampled_token_ranks: List[int]
+    cu_num_generated_tokens: List[int]
+
+
+@dataclass
 class ModelRunnerOutput:
     """What a V1 worker returns from execute_model: the fields of
     /root/reference/src/doc/engine_core.md:316-340, in that order.  This worker fills the
-    request index and the variable-length token lists; it computes no log-probabilities,
-    pooled outputs or KV-connector output (None / empty, as a model runner that was not
-    asked for them returns)."""
+    request index, the variable-length token lists and, when a request of the step asks for
+    them, the emitted tokens' log-probabilities (LogprobsLists); it computes no prompt
+    log-probabilities, pooled outputs or KV-connector output (None / empty, as a model runner
+    that was not asked for them returns)."""
     req_ids: List[str]
     req_id_to_index: Dict[str, int]
     sampled_token_ids: List[List[int]]
-    logprobs: Optional[object] = None
+    logprobs: Optional[LogprobsLists] = None
     prompt_logprobs_dict: Dict[str, Optional[object]] = field(default_factory=dict)
     pooler_output: List[Optional[torch.Tensor]] = field(default_factory=list)
     kv_connector_output: Optional[object] = None
@@ -167,7 +185,7 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
         if _get(r, "num_computed_tokens", 0):
             raise ValueError(f"request {rid}: prefix-cached prompt tokens are not supported")
         sp = _get(r, "sampling_params", None)
-        for name, off in (("logprobs", None), ("prompt_logprobs", None), ("logit_bias", None),
+        for name, off in (("prompt_logprobs", None), ("logit_bias", None),
                           ("bad_words", None), ("allowed_token_ids", None), ("repetition_penalty", 1.0),
                           ("presence_penalty", 0.0), ("frequency_penalty", 0.0)):
             val = _get(sp, name, off) if sp is not None else off
@@ -182,7 +200,8 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
                                 seed=_get(sp, "seed", None),
                                 top_k=_get(sp, "top_k", 0) or 0, top_p=_get(sp, "top_p", 1.0) or 1.0,
                                 min_p=_get(sp, "min_p", 0.0) or 0.0,
-                                ignore_eos=bool(_get(sp, "ignore_eos", True))) if sp is not None \
+                                ignore_eos=bool(_get(sp, "ignore_eos", True)),
+                                logprobs=_get(sp, "logprobs", None)) if sp is not None \
             else SamplingParams()
         mm = None
         for cand in (_get(r, "mm_inputs", None), _get(r, "mm_kwargs", None)):
@@ -519,6 +538,7 @@ class SpecDecodeWorker:
         self._req_at: List[str] = []
         self._prefill_of: Dict[str, int] = {}     # request id -> engine handle of a prompt in pieces
         self._prefill_left: Dict[str, int] = {}   # request id -> prompt tokens not yet computed
+        self._logprobs_of: Dict[str, int] = {}    # request id -> SamplingParams.logprobs, if asked
         if engine is not None:
             self._wire()
 
@@ -696,6 +716,12 @@ class SpecDecodeWorker:
                                      f"to serve sampling and greedy requests together)")
             if sp.seed is not None and not isinstance(sp.seed, int):
                 raise ValueError(f"request {g.request_id}: seed must be an integer")
+            if sp.logprobs is not None:
+                if not isinstance(sp.logprobs, int) or not 0 <= sp.logprobs <= ops.LOGPROBS_TOP_MAX:
+                    raise ValueError(f"request {g.request_id}: logprobs {sp.logprobs!r} outside "
+                                     f"0..{ops.LOGPROBS_TOP_MAX}")
+                if not hasattr(eng, "logprobs_top"):
+                    raise ValueError("this engine computes no log-probabilities")
             if not 0.0 < float(sp.top_p) <= 1.0 or not 0.0 <= float(sp.min_p) <= 1.0:
                 raise ValueError(f"request {g.request_id}: top_p {sp.top_p} must be in (0, 1] and "
                                  f"min_p {sp.min_p} in [0, 1]")
@@ -731,13 +757,24 @@ class SpecDecodeWorker:
         for rid in dropped:
             eng.prefill_abort(self._prefill_of.pop(rid))
             self._prefill_left.pop(rid, None)
+            self._logprobs_of.pop(rid, None)
         out: Dict[str, List[int]] = {}
+        # log-probabilities: computed for the whole step as soon as one of its requests asks
+        for g in prompts + pieces:
+            if g.sampling_params.logprobs is not None:
+                self._logprobs_of[g.request_id] = int(g.sampling_params.logprobs)
+        asked = [self._logprobs_of[g.request_id] for g in metas if g.request_id in self._logprobs_of]
+        lp: Dict[str, List[tuple]] = {}
+        if hasattr(eng, "logprobs_top"):
+            eng.logprobs_top = max(asked) if asked else None
         if running:
             if ext is not None:
                 eng.set_external_proposals([ext.get(r, []) for r in self._req_at])
             emitted = self._run_speculative_decoding_step(req)
             for slot, toks in enumerate(emitted):
                 out[self._req_at[slot]] = toks
+                if asked:
+                    lp[self._req_at[slot]] = eng.last_logprobs[slot]
         # text prompts that arrive together are prefilled in the same passes (one
         # synchronisation for the group); a prompt with images goes alone
         i = 0
@@ -761,10 +798,12 @@ class SpecDecodeWorker:
                           min_p=sp0.min_p) if seeded else {}
                 firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
                                           **mm_inputs[group[0].request_id], **kw)]
-            for g, first in zip(group, firsts):
+            for n, (g, first) in enumerate(zip(group, firsts)):
                 self._slot_of[g.request_id] = len(self._req_at)
                 self._req_at.append(g.request_id)
                 out[g.request_id] = [first]
+                if asked:
+                    lp[g.request_id] = eng.last_logprobs[n]
             i += len(group)
         # prompts in pieces: a piece emits nothing; the last one admits the sequence and emits
         # its first token
@@ -784,10 +823,19 @@ class SpecDecodeWorker:
                 self._slot_of[g.request_id] = len(self._req_at)
                 self._req_at.append(g.request_id)
                 out[g.request_id] = [first]
+                if asked:
+                    lp[g.request_id] = eng.last_logprobs[0]
         ids = [g.request_id for g in metas]
+        logprobs = None
+        if asked:
+            rows = [e for r in ids for e in lp.get(r, [])]
+            cu = [0]
+            for r in ids:
+                cu.append(cu[-1] + len(lp.get(r, [])))
+            logprobs = LogprobsLists([e[0] for e in rows], [e[1] for e in rows], [e[2] for e in rows], cu)
         return ModelRunnerOutput(
             req_ids=ids, req_id_to_index={r: i for i, r in enumerate(ids)},
-            sampled_token_ids=[out[r] for r in ids],
+            sampled_token_ids=[out[r] for r in ids], logprobs=logprobs,
             prompt_logprobs_dict={r: None for r in ids}, pooler_output=[None] * len(ids),
             spec_decode_metrics=self.metrics.maybe_collect() if self.metrics else None)
 
@@ -826,6 +874,7 @@ class SpecDecodeWorker:
             self.engine._enqueue_accept()
 
     def _finish(self, request_id: str) -> None:
+        self._logprobs_of.pop(request_id, None)
         slot = self._slot_of.pop(request_id, None)
         if slot is None:
             return
