@@ -483,3 +483,26 @@ def test_scheduler_supplied_spec_tokens_are_verified(use_graph):
             got[r].extend(toks)
     for r in prompts:
         assert got[r] == want[r][:len(got[r])], r
+
+
+def test_metrics_are_copied_on_a_side_stream():
+    """AsyncMetricsCollector on the GPU: the interval starts a copy of the counters behind the
+    steps enqueued so far, a later step returns them; they equal a synchronous read."""
+    import time
+    from vllm_omni_draft_amd.spec_decode_worker import ExecuteModelRequest, SequenceGroupMetadata
+    tw, dw = _llama_pair()
+    w = _worker(tw, dw, 3, True)
+    w.metrics.interval = 0.0
+    out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("a", True, [5, 9, 200, 31, 7])]))
+    assert out.spec_decode_metrics is None            # the copy was only started
+    seen = None
+    for _ in range(50):
+        out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata("a", False)]))
+        if out.spec_decode_metrics is not None and out.spec_decode_metrics.draft_tokens > 0:
+            seen = out.spec_decode_metrics           # (the first copy predates the first step)
+            break
+        time.sleep(0.001)
+    assert seen is not None and seen.num_spec_tokens == 3
+    now = w.metrics.maybe_collect(force=True)
+    assert 0 < seen.draft_tokens <= now.draft_tokens and seen.emitted_tokens <= now.emitted_tokens
+    assert seen.draft_tokens % 3 == 0

@@ -60,6 +60,26 @@ def test_metrics_definitions():
     assert col.maybe_collect().accept_len == 5.0
     assert col.maybe_collect() is None and col.maybe_collect(force=True) is not None
 
+    # an engine that copies its counters on a side stream: the interval starts a copy, a later
+    # call hands the numbers out once the copy has landed; no call waits
+    class AsyncEng(Eng):
+        begun, landed = 0, False
+        def metrics_begin(self):
+            self.begun += 1
+        def metrics_poll(self):
+            return {"accepted": 10, "emitted": 12, "draft": 10} if self.landed else None
+    eng, now[0] = AsyncEng(), 0.0
+    col = AsyncMetricsCollector(eng, collect_interval_s=5.0, timer=lambda: now[0])
+    assert col.maybe_collect() is None and eng.begun == 0
+    now[0] = 6.0
+    assert col.maybe_collect() is None and eng.begun == 1       # copy started
+    assert col.maybe_collect() is None and eng.begun == 1       # still in flight
+    eng.landed = True
+    assert col.maybe_collect().accepted_tokens == 10
+    assert col.maybe_collect() is None and eng.begun == 1       # next interval not reached
+    now[0] = 12.0
+    assert col.maybe_collect() is None and eng.begun == 2
+
 
 class FakeEngine:
     """Emits token 100*slot_owner + step for every running sequence; records calls."""

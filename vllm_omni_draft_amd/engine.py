@@ -1372,6 +1372,37 @@ class SpecEngine:
             acc, emit, draft = self.counters.tolist()
         return {"accepted": acc, "emitted": emit, "draft": draft}
 
+    def metrics_begin(self) -> None:
+        """Starts a copy of the acceptance counters into pinned host memory on a side stream
+        (ordered behind the steps enqueued so far); does not wait for the GPU."""
+        if not _rt.on_gpu():
+            self._metrics_copy = (None, self.counters.clone())
+            return
+        if getattr(self, "_metrics_stream", None) is None:
+            self._metrics_stream = torch.cuda.Stream(device=self.device)
+            self._metrics_host = _rt.pin(torch.zeros(3, dtype=torch.int64))
+        seen = torch.cuda.Event()
+        seen.record(self.stream)
+        with torch.cuda.stream(self._metrics_stream):
+            self._metrics_stream.wait_event(seen)
+            self._metrics_host.copy_(self.counters, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self._metrics_stream)
+        self._metrics_copy = (done, self._metrics_host)
+
+    def metrics_poll(self) -> Optional[dict]:
+        """The counters of the last metrics_begin once its copy has landed, else None; never
+        waits."""
+        pending = getattr(self, "_metrics_copy", None)
+        if pending is None:
+            return None
+        done, host = pending
+        if done is not None and not done.query():
+            return None
+        self._metrics_copy = None
+        acc, emit, draft = host.tolist()
+        return {"accepted": acc, "emitted": emit, "draft": draft}
+
 
 class _KvView:
     """PagedKVCache seen from batch slot `slot0` on (block-table rows shifted)."""

@@ -34,20 +34,37 @@ class SpecDecodeWorkerMetrics:
 
 
 class AsyncMetricsCollector:
-    """Reads the engine's counters at most once per interval; reading costs a
-    small device-to-host copy, so it stays off the per-step path."""
+    """Reads the engine's counters at most once per interval without stalling a step: when the
+    interval has elapsed the counters are copied to pinned host memory on a side stream
+    (engine.metrics_begin), and a later call hands them out once the copy has landed
+    (engine.metrics_poll), as upstream's collector of the same name does.  force=True, or an
+    engine without the two calls, reads synchronously."""
 
     def __init__(self, engine, collect_interval_s: float = 5.0, timer=time.monotonic):
         self.engine = engine
         self.interval = collect_interval_s
         self._timer = timer
         self._last = timer()
+        self._copying = False
+
+    def _from(self, m: dict) -> SpecDecodeWorkerMetrics:
+        return SpecDecodeWorkerMetrics.from_counts(m["accepted"], m["emitted"], m["draft"],
+                                                   self.engine.k)
 
     def maybe_collect(self, force: bool = False) -> Optional[SpecDecodeWorkerMetrics]:
         now = self._timer()
-        if not force and now - self._last < self.interval:
-            return None
-        self._last = now
-        m = self.engine.metrics()
-        return SpecDecodeWorkerMetrics.from_counts(m["accepted"], m["emitted"], m["draft"],
-                                                   self.engine.k)
+        if force or not hasattr(self.engine, "metrics_begin"):
+            if not force and now - self._last < self.interval:
+                return None
+            self._last, self._copying = now, False
+            return self._from(self.engine.metrics())
+        if self._copying:
+            m = self.engine.metrics_poll()
+            if m is None:
+                return None
+            self._copying = False
+            return self._from(m)
+        if now - self._last >= self.interval:
+            self._last, self._copying = now, True
+            self.engine.metrics_begin()
+        return None
