@@ -331,6 +331,23 @@ int sd_tree_accept_greedy(const int64_t* target_ids, const int32_t* tree_tok,
                           const int32_t* tree_parent, const int32_t* tree_len, int q_len,
                           int k, int64_t* out_ids, int32_t* path, int32_t* n_path,
                           int64_t* counters, int B, sd_stream_t stream);
+/* Acceptance over a tree under sampling, for candidates without a draft
+ * distribution (prompt lookup, proposals made outside: point-mass proposals; the
+ * multi-step speculative sampling of SpecInfer, Miao et al. 2024, section 4.3,
+ * with q = one-hot; not in the reference tree).  target_probs [B*q_len, ld]: the
+ * target's distribution after every tree row (temperature and filters applied).
+ * At the current node, with r = its row: the children are tried in row order;
+ * child x stands iff u_accept[b, row of x] * (1 - removed) < r(x) in f64, where
+ * removed is the mass of the children rejected so far at this node; a rejected
+ * child's token leaves r.  With no child standing, or k accepted, the emitted
+ * token is the inverse-CDF draw (u_final[b], f64 running sum as in
+ * sd_rejection_sample) from r without the rejected tokens.  Outputs and counters
+ * as sd_tree_accept_greedy.  u_accept [B, q_len], u_final [B] f32 in [0, 1).    */
+int sd_tree_accept_sample(const float* target_probs, int64_t ld, const int32_t* tree_tok,
+                          const int32_t* tree_parent, const int32_t* tree_len, int q_len,
+                          int k, const float* u_accept, const float* u_final,
+                          int64_t* out_ids, int32_t* path, int32_t* n_path,
+                          int64_t* counters, int B, int V, sd_stream_t stream);
 /* Moves the accepted rows' K/V (every layer, every KV head) from slot
  * seq_lens[b] + pos_offset + path[b][d] to slot seq_lens[b] + pos_offset + d + 1,
  * d = 0..n_path[b]-1, in that order.  Call before seq_lens advances.        */

@@ -106,3 +106,44 @@ def lookup_candidates(history: Sequence[int], k: int, ngram_max: int, ngram_min:
                     if len(out) >= n_candidates:
                         return out
     return out
+
+
+def accept_sample(probs, tokens: Sequence[int], parents: Sequence[int], length: int, k: int,
+                  u_accept: Sequence[float], u_final: float) -> Tuple[List[int], List[int]]:
+    """Acceptance walk under sampling for candidates that carry no draft distribution (prompt
+    lookup, proposals made outside): SpecInfer's multi-step speculative sampling (Miao et al.,
+    2023, section 4.3, Algorithm 2) with a point mass as every candidate's proposal
+    distribution.  With q = one-hot(x): the acceptance probability min(1, r(x) / q(x)) is r(x)
+    and the residual norm(max(r - q, 0)) is r with x removed, so at a node with target
+    distribution r the children are tried in row order, child x stands with probability
+    r(x) / mass(r), a rejected child's token leaves r, and when no child stands the emitted token
+    is drawn from what is left of r.  probs: [rows, V] float32 (the target's distribution after
+    every tree row); u_accept: one uniform per row.  float64 arithmetic on float32 inputs, the
+    mass written as 1 - (sum of the removed entries).  Returns (emitted tokens, accepted rows).
+    Parity unpinned (no fixture anywhere covers it): the tests pin the emitted distribution
+    against the target's instead."""
+    import numpy as np
+    from oracle.sampling import inverse_cdf
+    p = np.asarray(probs, dtype=np.float32)
+    cur, out, path = 0, [], []
+    while True:
+        removed, excl, nxt = np.float64(0.0), [], -1
+        if len(path) < k:
+            for c in range(1, length):
+                if parents[c] != cur:
+                    continue
+                x = int(tokens[c])
+                px = np.float64(p[cur, x])
+                if np.float64(np.float32(u_accept[c])) * (np.float64(1.0) - removed) < px:
+                    nxt = c
+                    break
+                removed += px
+                excl.append(x)
+        if nxt < 0:
+            r = p[cur].astype(np.float64)
+            r[excl] = 0.0
+            out.append(int(inverse_cdf(r, float(np.float32(u_final)), fallback=p[cur])))
+            return out, path
+        out.append(int(tokens[nxt]))
+        path.append(nxt)
+        cur = nxt

@@ -211,3 +211,59 @@ def test_token_trees_on_the_cpu_build():
     assert eng.tree_tok[0, 1:n].tolist() == t[1:] and eng.tree_parent[0, :n].tolist() == p
     assert eng.tree_depth[0, :n].tolist() == d
     assert eng.tree_mask[0, :n].tolist() == otree.ancestor_masks(p)
+
+
+def test_tree_sampling_walk_matches_the_oracle():
+    """sd_tree_accept_sample of the CPU build against the oracle (ids, rows and counters equal),
+    and a sampling engine with prompt-lookup trees steps through it."""
+    from oracle import tree as otree
+    from vllm_omni_draft_amd import ops
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    rng = np.random.default_rng(9)
+    B, k, N, V = 8, 3, 8, 64
+    q = N + 1
+    tok = torch.zeros(B, q, dtype=torch.int32)
+    par = torch.zeros(B, q, dtype=torch.int32)
+    lens = torch.ones(B, dtype=torch.int32)
+    probs = rng.dirichlet(np.full(V, 0.05), size=(B, q)).astype(np.float32)
+    trees = []
+    for b in range(B):
+        pool = rng.integers(0, V, 4)
+        cands = [[int(t) for t in rng.choice(pool, rng.integers(1, k + 2))] for _ in range(rng.integers(0, 4))]
+        t, p, _ = otree.build_tree(cands, k, N)
+        trees.append((t, p))
+        n = len(t)
+        tok[b, :n], par[b, :n], lens[b] = torch.tensor(t), torch.tensor(p), n
+        for r in range(1, n):
+            if rng.random() < 0.7:
+                probs[b, p[r], t[r]] += rng.choice([0.5, 2.0, 10.0])
+    probs = (probs / probs.sum(axis=2, keepdims=True, dtype=np.float64)).astype(np.float32)
+    ua, uf = rng.random((B, q), dtype=np.float32), rng.random(B, dtype=np.float32)
+    out = torch.full((B, k + 1), -7, dtype=torch.int64)
+    path = torch.full((B, k), -7, dtype=torch.int32)
+    npath = torch.zeros(B, dtype=torch.int32)
+    counters = torch.zeros(3, dtype=torch.int64)
+    ops.tree_accept_sample(torch.from_numpy(probs).view(B * q, V), tok, par, lens, k, torch.from_numpy(ua),
+                           torch.from_numpy(uf), out, path, npath, counters)
+    acc = 0
+    for b in range(B):
+        t, p = trees[b]
+        want_out, want_path = otree.accept_sample(probs[b], t, p, len(t), k, ua[b], uf[b])
+        assert out[b].tolist() == want_out + [-1] * (k + 1 - len(want_out)), b
+        assert path[b].tolist() == want_path + [-1] * (k - len(want_path)), b
+        acc += len(want_path)
+    assert counters[0].item() == acc and acc > 0
+    oc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64, ffn=128,
+                      vocab=32, max_pos=200)
+    w = _product(oc, _bf(random_state(oc, seed=4)))
+    eng = SpecEngine(w, None, EngineConfig(k=3, max_batch=2, max_seq_len=150, split_tokens=128,
+                                           temperature=1.0, seed=3, ngram_max=2, ngram_min=1,
+                                           tree_candidates=3))
+    seqs = [[1, 2, 3, 1, 2], [5, 5, 5]]
+    for b, s in enumerate(seqs):
+        s.append(eng.add_request(b, s))
+    for _ in range(20):
+        for b, new in enumerate(eng.step()):
+            assert 1 <= len(new) <= 4 and all(0 <= t < 32 for t in new)
+            seqs[b].extend(new)
+    assert eng.metrics()["emitted"] >= 40

@@ -322,13 +322,117 @@ def test_external_candidate_sets_are_verified_as_a_tree():
     assert len(eng.step(proposals=[[]])[0]) == 1
 
 
+@pytest.mark.parametrize("V", [64, 1000, 128256])
+def test_sampling_walk_matches_oracle(V):
+    """sd_tree_accept_sample against the oracle's restatement of multi-step speculative sampling
+    with point-mass proposals: emitted tokens, accepted rows and counters are equal bit for bit,
+    over trees with several children per node, rows whose mass sits on the children (accepted),
+    rows that reject every child (draw from what is left), chains accepted to the depth limit."""
+    from vllm_omni_draft_amd import ops
+    rng = np.random.default_rng(V)
+    B, k, N = 12, 4, 11
+    q = N + 1
+    tok = torch.zeros(B, q, dtype=torch.int32)
+    par = torch.zeros(B, q, dtype=torch.int32)
+    lens = torch.ones(B, dtype=torch.int32)
+    probs = rng.dirichlet(np.full(V, 0.05 if V < 2000 else 0.002), size=(B, q)).astype(np.float32)
+    trees = []
+    for b in range(B):
+        pool = rng.integers(0, V, 5)
+        cands = [[int(t) for t in rng.choice(pool, rng.integers(1, k + 2))] for _ in range(rng.integers(0, 5))]
+        if b == 0:
+            cands = []
+        if b == 1:
+            cands = [[1, 2, 3, 4], [1, 2, 5, 5], [9, 9]]
+        t, p, _ = otree.build_tree(cands, k, N)
+        trees.append((t, p))
+        n = len(t)
+        tok[b, :n], par[b, :n], lens[b] = torch.tensor(t), torch.tensor(p), n
+        # put mass on the children of some rows, so that walks go deep
+        for r in range(1, n):
+            if rng.random() < 0.6:
+                probs[b, p[r], t[r]] += rng.choice([0.5, 2.0, 10.0])
+        if b == 1:                       # one chain stands to the depth limit, whatever the uniforms
+            for row, x in ((0, 1), (1, 2), (2, 3), (3, 4)):
+                probs[b, row] = 0.0
+                probs[b, row, x] = 1.0
+        if b == 2 and n > 1:             # the root's children hold ALL of its mass, the first one none
+            kids = [r for r in range(1, n) if p[r] == 0]
+            probs[b, 0] = 0.0
+            for r in kids[1:] or kids:
+                probs[b, 0, t[r]] = 1.0
+    probs = (probs / probs.sum(axis=2, keepdims=True, dtype=np.float64)).astype(np.float32)
+    ua = rng.random((B, q), dtype=np.float32)
+    uf = rng.random(B, dtype=np.float32)
+    out = torch.full((B, k + 1), -7, dtype=torch.int64).cuda()
+    path = torch.full((B, k), -7, dtype=torch.int32).cuda()
+    npath = torch.zeros(B, dtype=torch.int32).cuda()
+    counters = torch.zeros(3, dtype=torch.int64).cuda()
+    ops.tree_accept_sample(torch.from_numpy(probs).view(B * q, V).cuda(), tok.cuda(), par.cuda(), lens.cuda(),
+                           k, torch.from_numpy(ua).cuda(), torch.from_numpy(uf).cuda(), out, path, npath,
+                           counters)
+    torch.cuda.synchronize()
+    acc = emit = depth = 0
+    for b in range(B):
+        t, p = trees[b]
+        want_out, want_path = otree.accept_sample(probs[b], t, p, len(t), k, ua[b], uf[b])
+        assert out[b].tolist() == want_out + [-1] * (k + 1 - len(want_out)), b
+        assert path[b].tolist() == want_path + [-1] * (k - len(want_path)), b
+        assert npath[b].item() == len(want_path)
+        acc, emit = acc + len(want_path), emit + len(want_out)
+        d = [0] * len(t)
+        for r in range(1, len(t)):
+            d[r] = d[p[r]] + 1
+        depth += min(max(d), k)
+    assert counters.tolist() == [acc, emit, depth]
+    assert out[1].tolist()[:4] == [1, 2, 3, 4] and npath[1].item() == 4
+    assert acc >= 6                      # walks did descend beyond the forced chain
+
+
+def test_tree_sampling_follows_the_target_distribution():
+    """Prompt-lookup trees under sampling (T = 1): every emitted token, accepted candidate or final
+    draw, is distributed as the ORACLE's target distribution given its predecessor (the
+    tolerance stated for the sampling path), while candidates are accepted and rejected."""
+    from tests.test_gpu_model import _check_transitions, _markov_pair, _transition_matrix
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    cfg, (ts, ds) = _markov_pair()
+    P = _transition_matrix(cfg, ts, 1.0)
+    Q = _transition_matrix(cfg, ds, 1.0)
+    tw = _product(cfg, ts)
+    B = 4
+    eng = SpecEngine(tw, None, EngineConfig(k=3, max_batch=B, max_seq_len=900, split_tokens=128,
+                                            temperature=1.0, seed=13, ngram_max=2, ngram_min=1,
+                                            tree_candidates=4))
+    assert eng.tree and eng.sampling
+    counts = np.zeros((cfg.vocab, cfg.vocab))
+    rounds = 0
+    while counts.sum() < 21000:
+        eng.reset()
+        seqs = [[(5 * b + rounds) % cfg.vocab] for b in range(B)]
+        for b in range(B):
+            seqs[b].append(eng.add_request(b, seqs[b]))
+        for _ in range(200):
+            for b, new in enumerate(eng.step()):
+                assert 1 <= len(new) <= 4 and all(0 <= t < cfg.vocab for t in new)
+                seqs[b].extend(new)
+        for sq in seqs:
+            np.add.at(counts, (sq[:-1], sq[1:]), 1)
+        rounds += 1
+    m = eng.metrics()
+    assert m["accepted"] > 500 and m["emitted"] - m["accepted"] > 500    # both paths ran
+    _check_transitions(counts, P)
+    with pytest.raises(AssertionError):
+        _check_transitions(counts, Q)
+
+
 def test_tree_mode_refuses_what_it_cannot_do():
     oc = MODELS["llama"]
     tw = _product(oc, _bf(random_state(oc, seed=21)))
     with pytest.raises(ValueError):
         _engine(tw, tw, 3, tree_candidates=2)                             # a draft model
-    with pytest.raises(ValueError):
-        _engine(tw, None, 3, ngram_max=2, tree_candidates=2, temperature=0.7)
+    with pytest.raises(ValueError):                                       # typical acceptance walks chains
+        _engine(tw, None, 3, ngram_max=2, tree_candidates=2, temperature=0.7,
+                acceptance_method="typical_acceptance_sampler")
     ocfg = OracleConfig(**{**vars(MODELS["opt"])})
     ow = _product(ocfg, _bf(random_state(ocfg, seed=3)))
     with pytest.raises(ValueError):

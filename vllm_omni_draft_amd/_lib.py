@@ -92,6 +92,7 @@ SIGNATURES = {
     "sd_map_tokens": (i32, [vp, i64, i32, vp, i32, i32, vp]),
     "sd_tree_prepare": (i32, [vp, i64, i32, vp, vp, vp, i32, vp, i32, i32, vp]),
     "sd_tree_accept_greedy": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "sd_tree_accept_sample": (i32, [vp, i64, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]),
     "sd_kv_compact": (i32, [vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, vp]),
     "sd_linear": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
     "sd_norm_linear": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32, vp]),

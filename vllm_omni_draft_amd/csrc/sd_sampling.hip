@@ -81,8 +81,10 @@ __device__ int block_argmax(const float* __restrict__ row, int V, float* smem_v,
 // the first index whose f64 running sum exceeds u * total; if rounding leaves
 // none, the last index with positive mass; if the mass is zero, argmax(p).
 // Must be called by every thread of the block.
+// excl / n_excl: indices whose mass counts as zero (a short list, every thread sees the same).
 __device__ int block_sample_residual(const float* __restrict__ p,
-                                     const float* __restrict__ q, int V, float u) {
+                                     const float* __restrict__ q, int V, float u,
+                                     const int* excl = nullptr, int n_excl = 0) {
   __shared__ double s_d[kSampleWaves];
   __shared__ int s_i[kSampleWaves];
   __shared__ float s_f[kSampleWaves];
@@ -96,8 +98,12 @@ __device__ int block_sample_residual(const float* __restrict__ p,
     const float4 pv = *reinterpret_cast<const float4*>(p + i);
     float4 qv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q) qv = *reinterpret_cast<const float4*>(q + i);
-    const float r[4] = {fmaxf(pv.x - qv.x, 0.f), fmaxf(pv.y - qv.y, 0.f),
-                        fmaxf(pv.z - qv.z, 0.f), fmaxf(pv.w - qv.w, 0.f)};
+    float r[4] = {fmaxf(pv.x - qv.x, 0.f), fmaxf(pv.y - qv.y, 0.f),
+                  fmaxf(pv.z - qv.z, 0.f), fmaxf(pv.w - qv.w, 0.f)};
+    for (int e = 0; e < n_excl; ++e) {
+      const unsigned d = (unsigned)(excl[e] - i);
+      if (d < 4u) r[d] = 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       local += (double)r[j];
@@ -124,6 +130,10 @@ __device__ int block_sample_residual(const float* __restrict__ p,
       r[1] = fmaxf(pv.y - qv.y, 0.f);
       r[2] = fmaxf(pv.z - qv.z, 0.f);
       r[3] = fmaxf(pv.w - qv.w, 0.f);
+      for (int e = 0; e < n_excl; ++e) {
+        const unsigned d = (unsigned)(excl[e] - i);
+        if (d < 4u) r[d] = 0.f;
+      }
     }
     const double s = (double)r[0] + (double)r[1] + (double)r[2] + (double)r[3];
     // inclusive scan of s over the block
@@ -354,6 +364,76 @@ __global__ __launch_bounds__(SD_WAVE) void tree_accept_greedy_kernel(
   }
   if (lane > j && lane <= k) out_ids[(size_t)b * (k + 1) + lane] = -1;
   if (lane >= j && lane < k) path[(size_t)b * k + lane] = -1;
+}
+
+// Multi-candidate speculative sampling down a token tree whose candidates carry no draft
+// distribution (point-mass proposals).  At a node with remaining target distribution r (the
+// node's probability row, tokens of rejected children zeroed) the children are tried in row
+// order: child x stands with probability r(x) / mass(r); a rejected child's token leaves r.
+// When no child stands (or the depth limit is reached) the emitted token is drawn from r.
+// Every thread walks the same scalar chain; only the final draw uses the whole workgroup.
+__global__ __launch_bounds__(kSampleThreads) void tree_accept_sample_kernel(
+    const float* __restrict__ probs, int64_t ld, const int32_t* __restrict__ tree_tok,
+    const int32_t* __restrict__ tree_parent, const int32_t* __restrict__ tree_len, int q_len, int k,
+    const float* __restrict__ u_accept, const float* __restrict__ u_final, int V,
+    int64_t* __restrict__ out_ids, int32_t* __restrict__ path, int32_t* __restrict__ n_path,
+    unsigned long long* __restrict__ counters) {
+  __shared__ int s_excl[SD_WAVE];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int len = min(max(tree_len[b], 1), q_len);
+  const int32_t* tok = tree_tok + (size_t)b * q_len;
+  const int32_t* par = tree_parent + (size_t)b * q_len;
+  const float* ua = u_accept + (size_t)b * q_len;
+  int cur = 0, j = 0, n_excl = 0;
+  for (;;) {
+    const float* row = probs + ((size_t)b * q_len + cur) * ld;
+    double removed = 0.0;
+    n_excl = 0;
+    int next = -1;
+    if (j < k) {
+      for (int c = 1; c < len; ++c) {
+        if (par[c] != cur) continue;
+        const int x = tok[c];
+        if (x < 0 || x >= V) continue;
+        const double px = (double)row[x];
+        if ((double)ua[c] * (1.0 - removed) < px) {
+          next = c;
+          break;
+        }
+        removed += px;
+        if (tid == 0) s_excl[n_excl] = x;   // read after the barrier below
+        ++n_excl;
+      }
+    }
+    if (next < 0) break;
+    if (tid == 0) {
+      out_ids[(size_t)b * (k + 1) + j] = tok[next];
+      path[(size_t)b * k + j] = next;
+    }
+    cur = next;
+    ++j;
+  }
+  __syncthreads();
+  const int last = block_sample_residual(probs + ((size_t)b * q_len + cur) * ld, nullptr, V, u_final[b],
+                                         s_excl, n_excl);
+  if (tid == 0) {
+    out_ids[(size_t)b * (k + 1) + j] = last;
+    n_path[b] = j;
+    // the longest chain of the tree counts as what was proposed
+    int max_depth = 0;
+    for (int c = 1; c < len; ++c) {
+      int d = 0;
+      for (int a = c; a > 0 && d <= q_len; a = par[a]) ++d;
+      max_depth = max(max_depth, d);
+    }
+    if (counters) {
+      atomicAdd(&counters[0], (unsigned long long)j);
+      atomicAdd(&counters[1], (unsigned long long)(j + 1));
+      atomicAdd(&counters[2], (unsigned long long)min(max_depth, k));
+    }
+  }
+  if (tid > j && tid <= k) out_ids[(size_t)b * (k + 1) + tid] = -1;
+  if (tid >= j && tid < k) path[(size_t)b * k + tid] = -1;
 }
 
 __global__ __launch_bounds__(kSampleThreads) void argmax_rows_kernel(
@@ -1361,6 +1441,26 @@ extern "C" int sd_tree_accept_greedy(const int64_t* target_ids, const int32_t* t
                      target_ids, tree_tok, tree_parent, tree_len, q_len, k, out_ids, path, n_path,
                      (unsigned long long*)counters);
   SD_CHECK_LAUNCH("sd_tree_accept_greedy");
+  return SD_OK;
+}
+
+extern "C" int sd_tree_accept_sample(const float* target_probs, int64_t ld, const int32_t* tree_tok,
+                                     const int32_t* tree_parent, const int32_t* tree_len, int q_len,
+                                     int k, const float* u_accept, const float* u_final,
+                                     int64_t* out_ids, int32_t* path, int32_t* n_path,
+                                     int64_t* counters, int B, int V, sd_stream_t stream) {
+  SD_REQUIRE(target_probs && tree_tok && tree_parent && tree_len && u_accept && u_final && out_ids &&
+                 path && n_path,
+             SD_ERR_INVALID, "sd_tree_accept_sample: null pointer");
+  SD_REQUIRE(B >= 0 && q_len >= 1 && q_len <= SD_WAVE && k >= 1 && k < SD_WAVE && V >= 4 && ld >= V,
+             SD_ERR_INVALID, "sd_tree_accept_sample: bad shape (q_len=%d k=%d V=%d)", q_len, k, V);
+  SD_REQUIRE(V % 4 == 0 && ld % 4 == 0 && sd_aligned16(target_probs), SD_ERR_UNSUPPORTED,
+             "sd_tree_accept_sample: V and ld must be multiples of 4, rows 16-byte aligned");
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(tree_accept_sample_kernel, dim3(B), dim3(kSampleThreads), 0, (hipStream_t)stream,
+                     target_probs, ld, tree_tok, tree_parent, tree_len, q_len, k, u_accept, u_final, V,
+                     out_ids, path, n_path, (unsigned long long*)counters);
+  SD_CHECK_LAUNCH("sd_tree_accept_sample");
   return SD_OK;
 }
 

@@ -299,11 +299,17 @@ int first_argmax(const float* row, int V) {
 }
 
 // Inverse-CDF draw from norm(max(p - q, 0)) with an f64 running sum (see sd_amd.h).
-int sample_residual(const float* p, const float* q, int V, float u) {
+int sample_residual(const float* p, const float* q, int V, float u, const int* excl = nullptr,
+                    int n_excl = 0) {
+  auto mass = [&](int i) {
+    for (int e = 0; e < n_excl; ++e)
+      if (excl[e] == i) return 0.f;
+    return fmaxf(p[i] - (q ? q[i] : 0.f), 0.f);
+  };
   double total = 0.0;
   int last_pos = -1;
   for (int i = 0; i < V; ++i) {
-    const float r = fmaxf(p[i] - (q ? q[i] : 0.f), 0.f);
+    const float r = mass(i);
     total += (double)r;
     if (r > 0.f) last_pos = i;
   }
@@ -311,7 +317,7 @@ int sample_residual(const float* p, const float* q, int V, float u) {
   const double thr = (double)u * total;
   double c = 0.0;
   for (int i = 0; i < V; ++i) {
-    c += (double)fmaxf(p[i] - (q ? q[i] : 0.f), 0.f);
+    c += (double)mass(i);
     if (c > thr) return i;
   }
   return last_pos;
@@ -754,6 +760,64 @@ extern "C" int sd_tree_prepare(const int32_t* tok_buf, int64_t tok_stride, int t
     tree_tok[(size_t)b * q_len] = tok_buf[(size_t)b * tok_stride + tok_col];
     for (int t = 0; t < q_len; ++t)
       rope_pos[(size_t)b * q_len + t] = seq_lens[b] + pos_offset + tree_depth[(size_t)b * q_len + t];
+  }
+  return SD_OK;
+}
+
+extern "C" int sd_tree_accept_sample(const float* probs, int64_t ld, const int32_t* tree_tok,
+                                     const int32_t* tree_parent, const int32_t* tree_len, int q_len, int k,
+                                     const float* u_accept, const float* u_final, int64_t* out_ids,
+                                     int32_t* path, int32_t* n_path, int64_t* counters, int B, int V,
+                                     sd_stream_t) {
+  REQUIRE(probs && tree_tok && tree_parent && tree_len && u_accept && u_final && out_ids && path &&
+              n_path && B >= 0 && q_len >= 1 && q_len <= 64 && k >= 1 && k < 64 && V >= 1 && ld >= V,
+          SD_ERR_INVALID, "sd_tree_accept_sample: bad arguments");
+  for (int b = 0; b < B; ++b) {
+    const int len = std::min(std::max(tree_len[b], 1), q_len);
+    const int32_t* tok = tree_tok + (size_t)b * q_len;
+    const int32_t* par = tree_parent + (size_t)b * q_len;
+    const float* ua = u_accept + (size_t)b * q_len;
+    int depth[64] = {0}, max_depth = 0;
+    for (int i = 1; i < len; ++i) {
+      depth[i] = depth[std::min(std::max(par[i], 0), i - 1)] + 1;
+      max_depth = std::max(max_depth, depth[i]);
+    }
+    int cur = 0, j = 0, n_excl = 0, excl[64];
+    for (;;) {
+      const float* row = probs + ((size_t)b * q_len + cur) * ld;
+      double removed = 0.0;
+      n_excl = 0;
+      int next = -1;
+      if (j < k) {
+        for (int c = 1; c < len; ++c) {
+          if (par[c] != cur) continue;
+          const int x = tok[c];
+          if (x < 0 || x >= V) continue;
+          const double px = (double)row[x];
+          if ((double)ua[c] * (1.0 - removed) < px) {
+            next = c;
+            break;
+          }
+          removed += px;
+          excl[n_excl++] = x;
+        }
+      }
+      if (next < 0) break;
+      out_ids[(size_t)b * (k + 1) + j] = tok[next];
+      path[(size_t)b * k + j] = next;
+      cur = next;
+      ++j;
+    }
+    out_ids[(size_t)b * (k + 1) + j] =
+        sample_residual(probs + ((size_t)b * q_len + cur) * ld, nullptr, V, u_final[b], excl, n_excl);
+    for (int i = j + 1; i <= k; ++i) out_ids[(size_t)b * (k + 1) + i] = -1;
+    for (int i = j; i < k; ++i) path[(size_t)b * k + i] = -1;
+    n_path[b] = j;
+    if (counters) {
+      counters[0] += j;
+      counters[1] += j + 1;
+      counters[2] += std::min(max_depth, k);
+    }
   }
   return SD_OK;
 }

@@ -78,11 +78,12 @@ class EngineConfig:
     acceptance_method: str = "rejection_sampler"
     posterior_threshold: float = 0.09
     posterior_alpha: float = 0.3
-    # Multi-candidate verification (greedy, host-made proposals only: prompt lookup or external).
+    # Multi-candidate verification (host-made proposals only: prompt lookup or external).
     # Up to tree_candidates continuations per sequence are merged into a token tree of at most
     # tree_nodes nodes (0: tree_candidates * k, capped by 64 / (Hq/Hkv) - 1) and scored by ONE
-    # verify pass; the longest root path that matches the target's own tokens is accepted.  1 =
-    # a single chain of k proposals.
+    # verify pass.  Greedy: the longest root path that matches the target's own tokens is
+    # accepted.  Sampling: multi-step speculative sampling with the candidates as point-mass
+    # proposals (sd_tree_accept_sample).  1 = a single chain of k proposals.
     tree_candidates: int = 1
     tree_nodes: int = 0
 
@@ -156,8 +157,9 @@ class SpecEngine:
             if not self.host_props:
                 raise ValueError("tree_candidates > 1 needs host-made proposals (prompt lookup or "
                                  "external_proposals) and no draft model")
-            if cfg.temperature > 0.0:
-                raise ValueError("token trees are verified greedily (temperature 0)")
+            if cfg.temperature > 0.0 and cfg.acceptance_method != "rejection_sampler":
+                raise ValueError("token trees under sampling use the rejection sampler "
+                                 "(typical acceptance walks chains only)")
             if target.cfg.arch != "llama" or target.cfg.mrope_section:
                 raise ValueError("token trees need a rotary target without mrope_section")
             cap = min(64 // (target.cfg.n_heads // target.cfg.n_kv_heads) - 1, 63)
@@ -296,15 +298,16 @@ class SpecEngine:
         self.sampling = cfg.temperature > 0.0
         if self.sampling:
             f32 = dict(dtype=torch.float32, device=dev)
-            self.t_probs = torch.empty(B, k + 1, self.V, **f32)
+            self.t_probs = torch.empty(B, q_max, self.V, **f32)   # (q_max = k + 1 without trees)
             self.d_probs = torch.empty(B, max(k, 1), self.V, **f32)
             # one flat buffer of uniforms, refilled on the device at the start of every step
             kk = max(k, 1)
-            sizes = [kk * B, B * kk, B * (k + 1), B]
+            ka = self.tree_nodes + 1 if self.tree else kk   # acceptance tests: one per tree row
+            sizes = [kk * B, B * ka, B * (k + 1), B]
             self.u_all = torch.zeros(sum(sizes), **f32)
             parts = torch.split(self.u_all, sizes)
             self.u_draft = parts[0].view(kk, B)
-            self.u_accept = parts[1].view(B, kk)
+            self.u_accept = parts[1].view(B, ka)
             self.u_recover = parts[2].view(B, k + 1)
             self.u_bonus = parts[3]
             # every sequence draws from a stream of its own (its request's seed, or one derived
@@ -322,10 +325,10 @@ class SpecEngine:
             self.host_seeds: List[int] = [0] * B
             self._admitted = 0
             self.u_regions = ops.uniform_regions([
-                (0, kk, B, 1), (kk * B, kk, 1, kk), (2 * kk * B, k + 1, 1, k + 1),
-                (2 * kk * B + B * (k + 1), 1, 0, 1)])
+                (0, kk, B, 1), (kk * B, ka, 1, ka), ((kk + ka) * B, k + 1, 1, k + 1),
+                ((kk + ka) * B + B * (k + 1), 1, 0, 1)])
             self.bonus_ids = torch.zeros(B, dtype=torch.int64, device=dev)
-            self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * (k + 1)), dev)
+            self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * q_max), dev)
         # Log-probabilities of the emitted tokens (ModelRunnerOutput.logprobs): off (None) unless
         # the caller sets logprobs_top = the number of most likely tokens to report beside each
         # emitted one (0: the emitted token's own log-probability and rank only).  While it is
@@ -836,10 +839,23 @@ class SpecEngine:
                          self.seq_lens[:B], -1, self.tree_rope)
         self._forward(self.target, self.t_kv, self.tree_tok, q, 0, self.seq_lens, -1, B, q,
                       self.t_out, tree=(self.tree_mask, self.tree_rope))
-        self._target_argmax(B * q, self.tree_ids[:B * q])
-        ops.tree_accept_greedy(self.tree_ids, self.tree_tok[:B], self.tree_parent[:B],
-                               self.tree_len[:B], k, self.out_ids[:B], self.tree_path[:B],
-                               self.tree_npath[:B], self.counters)
+        if self.sampling:
+            # the target's distribution after every tree row (per-sequence temperature and
+            # filters), then the walk with point-mass proposals: the candidates have no draft
+            # distribution (sd_tree_accept_sample)
+            self._target_full_rows(B * q)
+            probs = self.t_probs.view(-1, self.V)[:B * q]
+            ops.softmax_rows(self.t_logits[:B * q], self.temps[:B], rows_per_seq=q, out=probs,
+                             scratch=self.samp_scratch)
+            ops.filter_probs(probs, self.top_k, self.top_p, self.min_p, rows_per_seq=q)
+            ops.tree_accept_sample(probs, self.tree_tok[:B], self.tree_parent[:B], self.tree_len[:B], k,
+                                   self.u_accept[:B], self.u_bonus[:B], self.out_ids[:B],
+                                   self.tree_path[:B], self.tree_npath[:B], self.counters)
+        else:
+            self._target_argmax(B * q, self.tree_ids[:B * q])
+            ops.tree_accept_greedy(self.tree_ids, self.tree_tok[:B], self.tree_parent[:B],
+                                   self.tree_len[:B], k, self.out_ids[:B], self.tree_path[:B],
+                                   self.tree_npath[:B], self.counters)
         kv, c = self.t_kv, self.target.cfg
         ops.kv_compact(kv.k, kv.v, kv.layer_stride_bytes, c.n_layers, kv.block_tables[:B],
                        self.seq_lens[:B], -1, self.tree_path[:B], self.tree_npath[:B],

@@ -377,6 +377,29 @@ def tree_accept_greedy(target_ids, tree_tok, tree_parent, tree_len, k, out_ids, 
                "sd_tree_accept_greedy")
 
 
+def tree_accept_sample(target_probs, tree_tok, tree_parent, tree_len, k, u_accept, u_final, out_ids,
+                       path, n_path, counters=None) -> None:
+    """Acceptance walk over a token tree under sampling, for candidates without a draft
+    distribution (see sd_tree_accept_sample).  target_probs [B * q_len, V] float32."""
+    _need(target_probs, torch.float32, "target_probs")
+    for t, n in ((tree_tok, "tree_tok"), (tree_parent, "tree_parent"), (tree_len, "tree_len"),
+                 (path, "path"), (n_path, "n_path")):
+        _need(t, torch.int32, n)
+    _need(u_accept, torch.float32, "u_accept")
+    _need(u_final, torch.float32, "u_final")
+    _need(out_ids, torch.int64, "out_ids")
+    B, q_len = tree_tok.shape
+    if (target_probs.dim() != 2 or target_probs.shape[0] < B * q_len
+            or tuple(tree_parent.shape) != (B, q_len) or tuple(u_accept.shape) != (B, q_len)
+            or u_final.numel() < B or tuple(out_ids.shape) != (B, k + 1) or tuple(path.shape) != (B, k)
+            or tree_len.numel() < B or n_path.numel() < B):
+        raise _lib.SdError("tree_accept_sample: inconsistent shapes")
+    _lib.check(_lib.load().sd_tree_accept_sample(
+        _p(target_probs), target_probs.stride(0), _p(tree_tok), _p(tree_parent), _p(tree_len), q_len, k,
+        _p(u_accept), _p(u_final), _p(out_ids), _p(path), _p(n_path), _p(counters), B,
+        target_probs.shape[1], _stream()), "sd_tree_accept_sample")
+
+
 def kv_compact(k_cache, v_cache, layer_stride_bytes, n_layers, block_tables, seq_lens, pos_offset,
                path, n_path, Hkv, D) -> None:
     """Moves the accepted tree rows' K/V to their chain slots (see sd_kv_compact)."""

@@ -456,7 +456,8 @@ class SpecDecodeConfig:
     external_proposals: bool = False
     # multi-candidate verification of host-made proposals (prompt lookup / external): up to
     # this many continuations per sequence are merged into a token tree and scored by one
-    # verify pass (greedy only); see EngineConfig.tree_candidates
+    # verify pass (greedy, or under sampling with the rejection sampler); see
+    # EngineConfig.tree_candidates
     speculative_tree_candidates: int = 1
     speculative_tree_nodes: int = 0
     max_num_seqs: int = 1
