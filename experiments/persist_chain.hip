@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 typedef __bf16 bf16_t;
@@ -31,6 +32,7 @@ struct Args {
   float* xb[2];         // activations, f32, alternating by phase parity
   unsigned* flags;      // one per workgroup
   unsigned* failed;
+  unsigned long long* xt[2];  // LL exchange: {f32 value, u32 tag} words, alternating by phase parity
   int prefetch_across;  // request the next phase's weights before the barrier
   int idle_phase;       // index of a phase in which only 40 workgroups have (latency-bound) work, or -1
 };
@@ -64,8 +66,27 @@ __device__ bool barrier_wait(const Args& a, unsigned epoch, int* ok_s) {
   return *ok_s != 0;
 }
 
-template <bool PERSIST>
+__device__ __forceinline__ unsigned long long ll_pack(float v, unsigned tag) {
+  return ((unsigned long long)tag << 32) | __float_as_uint(v);
+}
+
+// Waits until word idx of buf carries `tag`, returns its value (bounded; *ok cleared on time-out).
+__device__ __forceinline__ float ll_read(const unsigned long long* buf, int idx, unsigned tag, bool* ok) {
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const unsigned long long w = __hip_atomic_load(buf + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(w >> 32) == tag) return __uint_as_float((unsigned)w);
+    if (wall_clock64() - t0 > 200000000ull) {
+      *ok = false;
+      return 0.f;
+    }
+  }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void chain_kernel(Args a, int g_lo, int g_hi) {
+  constexpr bool PERSIST = MODE != 0;
+  constexpr bool LL = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem);                       // [2][kMaxK + 8]: row 0 = x, row 1 = 0
   float* red = reinterpret_cast<float*>(smem + 2 * (kMaxK + 8) * 2);  // [2][waves][256]
@@ -99,9 +120,13 @@ __global__ __launch_bounds__(kThreads) void chain_kernel(Args a, int g_lo, int g
     const Phase& p = a.ph[g % a.n_phases];
     const int K = p.ksteps * 32, n_seg = p.ksteps / kSeg;
     const bool idle = (g % a.n_phases) == a.idle_phase;
-    if (PERSIST && g > g_lo) {
+    if (MODE == 1 && g > g_lo) {
       if (!barrier_wait(a, (unsigned)(g - g_lo), ok_s)) return;
     }
+    bool ll_ok = true;
+    const unsigned long long* tin = a.xt[g & 1];
+    unsigned long long* tout = a.xt[(g + 1) & 1];
+    const unsigned tag_in = (unsigned)g, tag_out = (unsigned)(g + 1);
     const float* xin = a.xb[g & 1];
     float* xout = a.xb[(g + 1) & 1];
     if (idle) {
@@ -111,17 +136,32 @@ __global__ __launch_bounds__(kThreads) void chain_kernel(Args a, int g_lo, int g
         float v = 0.f;
         int idx = tid;
         for (int hop = 0; hop < 3; ++hop) {
-          v = __hip_atomic_load(xin + (idx & 2047), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v = LL ? ll_read(tin, idx & 2047, tag_in, &ll_ok)
+                 : __hip_atomic_load(xin + (idx & 2047), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           idx = (int)(v * 0.f) + tid + hop;  // dependent address
         }
-        for (int c = blockIdx.x * kThreads + tid; c < 2048; c += 40 * kThreads)
-          __hip_atomic_store(xout + c, 2.f * __hip_atomic_load(xin + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.f * v,
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int c = blockIdx.x * kThreads + tid; c < 2048; c += 40 * kThreads) {
+          if (LL) {
+            const float xv = ll_read(tin, c, tag_in, &ll_ok);
+            __hip_atomic_store(tout + c, ll_pack(2.f * xv + 0.f * v, tag_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            __hip_atomic_store(xout + c, 2.f * __hip_atomic_load(xin + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 0.f * v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
       }
       if (PERSIST && g + 1 < g_hi && a.prefetch_across) first_load(g + 1);
     } else {
-      for (int c = tid; c < K; c += kThreads)
-        xs[c] = (bf16_t)__hip_atomic_load(xin + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (LL) {
+        for (int c = tid; c < K; c += kThreads) xs[c] = (bf16_t)ll_read(tin, c, tag_in, &ll_ok);
+      } else {
+        for (int c = tid; c < K; c += kThreads)
+          xs[c] = (bf16_t)__hip_atomic_load(xin + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (LL && !__syncthreads_and(ll_ok)) {
+        if (tid == 0) __hip_atomic_store(a.failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
       __syncthreads();
       const int n_units = p.n_tiles;
       for (int unit = blockIdx.x; unit < n_units; unit += gridDim.x, parity ^= 1) {
@@ -146,12 +186,13 @@ __global__ __launch_bounds__(kThreads) void chain_kernel(Args a, int g_lo, int g
           float s = 0.f;
 #pragma unroll
           for (int w = 0; w < kWaves; ++w) s += rbuf[w * 256 + tid];
-          __hip_atomic_store(xout + unit * 16 + nl, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (LL) __hip_atomic_store(tout + unit * 16 + nl, ll_pack(s, tag_out), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else __hip_atomic_store(xout + unit * 16 + nl, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       if ((int)blockIdx.x >= n_units && PERSIST && g + 1 < g_hi && a.prefetch_across) first_load(g + 1);
     }
-    if (PERSIST && g + 1 < g_hi) {
+    if (MODE == 1 && g + 1 < g_hi) {
       if (!a.prefetch_across) {
         // the comparison case: nothing in flight across the barrier
       }
@@ -161,6 +202,7 @@ __global__ __launch_bounds__(kThreads) void chain_kernel(Args a, int g_lo, int g
         __hip_atomic_store(a.flags + blockIdx.x, (unsigned)(g - g_lo + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!a.prefetch_across) first_load(g + 1);  // requested only after arriving
     }
+    if (LL && g + 1 < g_hi && !a.prefetch_across) first_load(g + 1);  // after publishing, before the wait
   }
 }
 
@@ -195,8 +237,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(a.failed, 0, 4));
     const int G = layers * a.n_phases;
     const size_t lds = 2 * (kMaxK + 8) * 2 + 2 * kWaves * 256 * 4 + 16 + (per_cu == 1 ? 64 * 1024 : 0);  // > 80 KB: one workgroup per CU
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     std::vector<float> ones(16384, 1.0f), back(16384);
     auto check = [&](const char* what) {
       CK(hipMemcpy(back.data(), a.xb[G & 1], 2048 * 4, hipMemcpyDeviceToHost));
@@ -215,7 +257,7 @@ int main(int argc, char** argv) {
       for (int g = 0; g < G; ++g) {
         const Phase& p = a.ph[g % a.n_phases];
         const int blocks = (g % a.n_phases) == a.idle_phase ? 40 : (p.n_tiles < 256 * per_cu ? p.n_tiles : 256 * per_cu);
-        hipLaunchKernelGGL(chain_kernel<false>, dim3(blocks), dim3(kThreads), lds, st, a, g, g + 1);
+        hipLaunchKernelGGL(chain_kernel<0>, dim3(blocks), dim3(kThreads), lds, st, a, g, g + 1);
       }
       CK(hipStreamEndCapture(st, &gr));
       CK(hipGraphInstantiate(&ex, gr, nullptr, nullptr, 0));
@@ -239,7 +281,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpyAsync(a.xb[0], ones.data(), 16384 * 4, hipMemcpyHostToDevice, st));
         CK(hipMemsetAsync(a.flags, 0, 512 * 4, st));
         CK(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(chain_kernel<true>, dim3(256 * per_cu), dim3(kThreads), lds, st, a, 0, G);
+        hipLaunchKernelGGL(chain_kernel<1>, dim3(256 * per_cu), dim3(kThreads), lds, st, a, 0, G);
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
         ok = check("resident");
@@ -247,6 +289,41 @@ int main(int argc, char** argv) {
       printf("    resident kernel, weights requested %s the barrier: %.2f us per layer (%.2f TB/s)%s\n",
              across ? "before" : "after", best * 1e3f / layers, total * layers / (best * 1e-3) / 1e12, ok ? "" : "  FAILED");
       if (!ok) return 1;
+    }
+    // (3) one resident kernel, no barrier: activations travel as {value, tag} words and every
+    // reader polls the words it needs
+    {
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(chain_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      CK(hipMalloc(&a.xt[0], 16384 * 8)); CK(hipMalloc(&a.xt[1], 16384 * 8));
+      std::vector<unsigned long long> init(16384);
+      for (auto& w : init) w = ((unsigned long long)0u << 32) | 0x3f800000u;   // tag 0, value 1.0
+      for (int across = 0; across < 2; ++across) {
+        a.prefetch_across = across;
+        float best = 1e9f;
+        bool ok = true;
+        for (int r = 0; r < 5 && ok; ++r) {
+          CK(hipMemcpyAsync(a.xt[0], init.data(), 16384 * 8, hipMemcpyHostToDevice, st));
+          CK(hipMemsetAsync(a.xt[1], 0xff, 16384 * 8, st));
+          CK(hipEventRecord(e0, st));
+          hipLaunchKernelGGL(chain_kernel<2>, dim3(256 * per_cu), dim3(kThreads), lds, st, a, 0, G);
+          CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+          std::vector<unsigned long long> got(2048);
+          CK(hipMemcpy(got.data(), a.xt[G & 1], 2048 * 8, hipMemcpyDeviceToHost));
+          unsigned f; CK(hipMemcpy(&f, a.failed, 4, hipMemcpyDeviceToHost));
+          int bad = 0;
+          const float want = ldexpf(1.0f, G);
+          for (int i = 0; i < 2048; ++i) {
+            float v; unsigned u = (unsigned)got[i]; memcpy(&v, &u, 4);
+            bad += v != want || (unsigned)(got[i] >> 32) != (unsigned)G;
+          }
+          if (bad || f) { printf("  tagged words: %d wrong values, failed flag %u\n", bad, f); ok = false; }
+        }
+        printf("    resident kernel, tagged words (no barrier), next weights requested %s the wait: %.2f us per layer (%.2f TB/s)%s\n",
+               across ? "before" : "after", best * 1e3f / layers, total * layers / (best * 1e-3) / 1e12, ok ? "" : "  FAILED");
+        if (!ok) return 1;
+      }
+      CK(hipFree(a.xt[0])); CK(hipFree(a.xt[1]));
     }
     for (auto* w : bufs) CK(hipFree(w));
     CK(hipFree(a.xb[0])); CK(hipFree(a.xb[1])); CK(hipFree(a.flags)); CK(hipFree(a.failed));
