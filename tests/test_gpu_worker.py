@@ -506,3 +506,47 @@ def test_metrics_are_copied_on_a_side_stream():
     now = w.metrics.maybe_collect(force=True)
     assert 0 < seen.draft_tokens <= now.draft_tokens and seen.emitted_tokens <= now.emitted_tokens
     assert seen.draft_tokens % 3 == 0
+
+
+def test_v1_preempted_requests_are_rebuilt_when_they_return():
+    """A V1 scheduler preempts a request by not scheduling it and later names it again among the
+    cached requests: the worker frees its slot, keeps its tokens, and prefills prompt + emitted
+    tokens anew when it returns (whole, or in the pieces the scheduler grants).  Greedy streams are
+    the autoregressive ones, interruptions or not."""
+    from tests.test_host_logic import _NewRequestData, _sched
+    tw, dw = _llama_pair()
+    prompts = {"a": [5, 9, 200, 31, 7], "b": list(range(40, 73)), "c": [3, 3, 3]}
+    want = {r: _generate(_engine(tw, None, 0), [p], 40)[0] for r, p in prompts.items()}
+    w = _worker(tw, dw, 3, True)
+    got = {r: [] for r in prompts}
+    N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0})
+
+    def run(new=(), cached=(), pieces=None, finished=()):
+        so = _sched(new=list(new), cached=list(cached), finished=finished)
+        so.num_scheduled_tokens.update(pieces or {})
+        out = w.execute_model(so)
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            got[r].extend(toks)
+        return dict(zip(out.req_ids, out.sampled_token_ids))
+
+    run(new=[N("a"), N("b"), N("c")])
+    run(cached=["a", "b", "c"])
+    run(cached=["a", "c"])                               # "b" is preempted
+    assert w.engine.active == 2 and "b" in w._parked
+    run(cached=["c"])                                    # and "a"
+    assert w.engine.active == 1 and w._parked == {"a", "b"}
+    n_b = len(prompts["b"]) + len(got["b"])
+    o = run(cached=["c", "b"], pieces={"b": n_b})        # "b" returns whole
+    assert len(o["b"]) == 1 and w.engine.active == 2
+    n_a = len(prompts["a"]) + len(got["a"])
+    o = run(cached=["c", "b", "a"], pieces={"a": n_a - 3})   # "a" returns in two pieces
+    assert o["a"] == []
+    o = run(cached=["c", "b", "a"], pieces={"a": 3})
+    assert len(o["a"]) == 1 and w.engine.active == 3 and not w._parked
+    while min(len(got[r]) for r in prompts) < 40:
+        run(cached=["a", "b", "c"])
+    for r in prompts:
+        assert got[r][:40] == want[r], r
+    run(cached=["a"], finished=["b"])                    # "c" parked, "b" finished
+    run(cached=["a"], finished=["c"])                    # finished while parked
+    assert w.engine.active == 1 and set(w._tokens) == {"a"}

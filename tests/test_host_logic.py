@@ -97,6 +97,7 @@ class FakeEngine:
 
     def add_request(self, slot, prompt):
         assert slot == self.active
+        self.prompts = getattr(self, "prompts", []) + [list(prompt)]
         self.owners.append(prompt[0])
         self.active += 1
         return prompt[0] * 100
@@ -134,9 +135,21 @@ def test_worker_request_bookkeeping():
     assert eng.owners == [3, 2] and out.sampled_token_ids == [[302], [202, 202]]
     with pytest.raises(KeyError):
         w.execute_model(ExecuteModelRequest([R("zzz"), R("b"), R("c")]))
-    with pytest.raises(ValueError):
-        w.execute_model(ExecuteModelRequest([R("b")]))            # a running request is missing
-    w.execute_model(ExecuteModelRequest([R("b"), R("c"), P("d", 4)]))
+    # a running request the step does not name is parked (a V1 scheduler preempts this way): its
+    # slot is freed; named again, it is rebuilt from its prompt and the tokens it emitted
+    out = w.execute_model(ExecuteModelRequest([R("b")]))
+    assert eng.owners == [2] and "c" in w._parked and out.req_ids == ["b"]
+    toks_c = list(w._tokens["c"])
+    assert toks_c[:3] == [3, 1, 2] and len(toks_c) == 3 + 2       # prompt + [300] + [302]
+    out = w.execute_model(ExecuteModelRequest([R("b"), R("c")]))
+    assert eng.owners == [2, 3] and eng.prompts[-1] == toks_c and not w._parked
+    assert out.sampled_token_ids[1] == [300]                      # the rebuilt sequence's next token
+    with pytest.raises(KeyError):                                 # a new prompt under a parked id
+        w.execute_model(ExecuteModelRequest([R("b")]))
+        w.execute_model(ExecuteModelRequest([R("b"), P("c", 9)]))
+    w.execute_model(ExecuteModelRequest([R("b")], finished_requests_ids=["c"]))   # finished while parked
+    assert "c" not in w._tokens and not w._parked
+    w.execute_model(ExecuteModelRequest([R("b"), P("c", 3), P("d", 4)]))
     with pytest.raises(RuntimeError):
         w.execute_model(ExecuteModelRequest([R("b"), R("c"), R("d"), P("e", 5)]))  # no free slot
 

@@ -540,6 +540,13 @@ class SpecDecodeWorker:
         self._prefill_of: Dict[str, int] = {}     # request id -> engine handle of a prompt in pieces
         self._prefill_left: Dict[str, int] = {}   # request id -> prompt tokens not yet computed
         self._logprobs_of: Dict[str, int] = {}    # request id -> SamplingParams.logprobs, if asked
+        # what it takes to rebuild a sequence that a step left out (a V1 scheduler preempts a
+        # request by not scheduling it; it comes back among the cached requests later): the
+        # request's tokens so far (prompt + emitted), its parameters and multimodal inputs
+        self._tokens: Dict[str, List[int]] = {}
+        self._request: Dict[str, SequenceGroupMetadata] = {}
+        self._parked: Set[str] = set()             # requests without a slot, waiting to be named again
+        self._park_count: Dict[str, int] = {}      # request id -> times it was parked
         if engine is not None:
             self._wire()
 
@@ -674,6 +681,26 @@ class SpecDecodeWorker:
             req = request_from_scheduler_output(req)
         eng = self.engine
         metas = req.seq_group_metadata_list
+        # A running request that the step does not name (and does not finish) is parked: its
+        # slot is freed, its tokens are kept.  When it is named again it is rebuilt from them
+        # (prompt and emitted tokens prefilled anew, whole or in the pieces the step schedules)
+        # and goes on where it stopped: a V1 scheduler preempts and resumes requests this way.
+        named = {g.request_id for g in metas}
+        parked_now = [r for r in self._req_at if r not in named and r not in req.finished_requests_ids]
+        resumed = {g.request_id for g in metas if not g.is_prompt and g.request_id in self._parked}
+        if resumed:
+            metas = list(metas)
+            for i, g in enumerate(metas):
+                if g.request_id in resumed:
+                    first, toks = self._request[g.request_id], self._tokens[g.request_id]
+                    piece = g.num_prompt_tokens
+                    sp = first.sampling_params
+                    if sp.seed is not None:      # a stream of its own for every incarnation
+                        sp = SamplingParams(**{**vars(sp), "seed": (sp.seed + 0x9E3779B1 * self._park_count[g.request_id])
+                                               & 0x7FFFFFFFFFFFFFFF})
+                    metas[i] = SequenceGroupMetadata(
+                        g.request_id, True, list(toks), sp, multi_modal_data=first.multi_modal_data,
+                        num_prompt_tokens=piece if piece is not None and 1 <= piece < len(toks) else None)
         # prompts that arrive in pieces (chunked prefill): first pieces and continuations
         continued = [g for g in metas if not g.is_prompt and g.request_id in self._prefill_of]
         running = [g for g in metas if not g.is_prompt and g.request_id not in self._prefill_of]
@@ -726,6 +753,8 @@ class SpecDecodeWorker:
             if not 0.0 < float(sp.top_p) <= 1.0 or not 0.0 <= float(sp.min_p) <= 1.0:
                 raise ValueError(f"request {g.request_id}: top_p {sp.top_p} must be in (0, 1] and "
                                  f"min_p {sp.min_p} in [0, 1]")
+            if g.request_id in self._parked and g.request_id not in resumed:
+                raise KeyError(f"request {g.request_id} is parked on this worker; finish it first")
             if (g.request_id in self._slot_of and g.request_id not in finished) or (
                     g.request_id in self._prefill_of and g.request_id not in dropped):
                 raise KeyError(f"request {g.request_id} is already running")
@@ -738,10 +767,11 @@ class SpecDecodeWorker:
         gone = [g.request_id for g in running if g.request_id in finished]
         if gone:
             raise ValueError(f"requests {gone} are listed as running and as finished")
-        n_after = eng.active - len(finished)
-        if len(running) != n_after:
-            raise ValueError(f"{n_after} sequences are running but the step names {len(running)}: "
-                             "list every running request or finish it")
+        n_after = eng.active - len(finished) - len(parked_now)
+        if len(running) != n_after:      # (cannot happen: every slot is named, finished or parked)
+            raise ValueError(f"{n_after} sequences are running but the step names {len(running)}")
+        if parked_now and not all(r in self._tokens for r in parked_now):
+            raise ValueError(f"requests {parked_now} are running but not named by the step")
         n_prefilling = len(self._prefill_of) - len(dropped)
         if n_after + n_prefilling + len(prompts) + len(pieces) > eng.cfg.max_batch:
             raise RuntimeError("no free sequence slot (max_num_seqs reached)")
@@ -753,12 +783,18 @@ class SpecDecodeWorker:
         mm_inputs = {g.request_id: self._multimodal_inputs(g) for g in prompts}
 
         # ---- the step
+        for rid in dict.fromkeys(req.finished_requests_ids):
+            if rid in self._parked:          # finished while parked: nothing left but its log
+                self._forget(rid)
         for rid in finished:
             self._finish(rid)
+        for rid in parked_now:
+            self._park(rid)
+        self._parked -= resumed
         for rid in dropped:
             eng.prefill_abort(self._prefill_of.pop(rid))
             self._prefill_left.pop(rid, None)
-            self._logprobs_of.pop(rid, None)
+            self._forget(rid)
         out: Dict[str, List[int]] = {}
         # log-probabilities: computed for the whole step as soon as one of its requests asks
         for g in prompts + pieces:
@@ -827,6 +863,13 @@ class SpecDecodeWorker:
                 if asked:
                     lp[g.request_id] = eng.last_logprobs[0]
         ids = [g.request_id for g in metas]
+        for g in prompts + pieces:
+            if g.request_id not in self._tokens:
+                self._request[g.request_id] = g
+                self._tokens[g.request_id] = list(g.prompt_token_ids)
+        for r in ids:
+            if r in self._tokens:
+                self._tokens[r].extend(out[r])
         logprobs = None
         if asked:
             rows = [e for r in ids for e in lp.get(r, [])]
@@ -874,8 +917,22 @@ class SpecDecodeWorker:
         with _rt.stream_ctx(self.engine.stream):
             self.engine._enqueue_accept()
 
+    def _forget(self, request_id: str) -> None:
+        for d in (self._logprobs_of, self._tokens, self._request, self._park_count):
+            d.pop(request_id, None)
+        self._parked.discard(request_id)
+
+    def _park(self, request_id: str) -> None:
+        """Frees the slot of a running request the step left out; its token log stays."""
+        self._parked.add(request_id)
+        self._park_count[request_id] = self._park_count.get(request_id, 0) + 1
+        self._release_slot(request_id)
+
     def _finish(self, request_id: str) -> None:
-        self._logprobs_of.pop(request_id, None)
+        self._forget(request_id)
+        self._release_slot(request_id)
+
+    def _release_slot(self, request_id: str) -> None:
         slot = self._slot_of.pop(request_id, None)
         if slot is None:
             return
