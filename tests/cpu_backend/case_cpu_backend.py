@@ -267,3 +267,13 @@ def test_tree_sampling_walk_matches_the_oracle():
             assert 1 <= len(new) <= 4 and all(0 <= t < 32 for t in new)
             seqs[b].extend(new)
     assert eng.metrics()["emitted"] >= 40
+
+
+@pytest.mark.parametrize("seed", [0, 2, 3])
+def test_random_v1_schedules_on_the_cpu_build(seed, monkeypatch):
+    """The randomised V1 schedule of tests/test_gpu_fuzz.py (prompts whole and in pieces,
+    preemption and return, finishes anywhere, log-probabilities) through the CPU build: every
+    stream is the one the request gets alone."""
+    import tests.test_gpu_fuzz as fuzz
+    monkeypatch.setattr(fuzz, "_weights", lambda oc, s: _product(oc, _bf(random_state(oc, seed=s))))
+    fuzz.test_random_v1_schedules_with_pieces_and_preemption(seed, False, "wide")

@@ -177,3 +177,119 @@ def test_scheduled_streams_match_the_oracle_golden(rows):
             seq.append(want)
         n_tokens += len(case["tokens"])
     assert n_match >= 0.6 * n_tokens, (n_match, n_tokens)
+
+
+@pytest.mark.parametrize("seed,use_graph,rows", [(0, True, "wide"), (1, True, "wide"), (2, False, "wide"),
+                                                 (3, True, "wide"), (3, True, "narrow"), (4, False, "narrow")])
+def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
+    """A random V1 scheduler over the worker: prompts arrive whole or in pieces of random sizes,
+    running requests are preempted (left out of steps) and return whole or in pieces, requests
+    finish at random, also while they are parked or half prefilled; some ask for
+    log-probabilities.  Every request's stream is the autoregressive stream it gets alone, and
+    every reported entry belongs to the emitted token with rank 1 (greedy).  On the wide kernel
+    family (and the CPU build) that holds across preemptions bit for bit; an engine that decodes
+    on the <= 16-row family rebuilds a returning request's emitted tokens with the prefill
+    (wide) kernels, whose sums run in another order, so there the comparison stops at a
+    request's first return."""
+    from tests.test_host_logic import _NewRequestData, _sched
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
+    rnd = random.Random(100 + seed)
+    tw, dw = _weights(TARGET, 50), _weights(DRAFT, 51)
+    n_req, n_new, slots = 10, 24, 3
+    prompts = {f"q{i}": [rnd.randrange(TARGET.vocab) for _ in range(rnd.randint(1, 60))] for i in range(n_req)}
+    solo = SpecEngine(tw, None, EngineConfig(k=0, max_batch=1, max_seq_len=140, split_tokens=128, rows=rows))
+    want = {}
+    exact_until = {}     # narrow family: tokens a request had when it first returned
+    for r, p in prompts.items():
+        solo.reset()
+        out = [solo.add_request(0, p)]
+        while len(out) < n_new:
+            out.extend(solo.step()[0])
+        want[r] = out[:n_new]
+    del solo
+    w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=dw, num_speculative_tokens=3, max_num_seqs=slots,
+                                          max_model_len=140, split_tokens=128, use_graph=use_graph, rows=rows))
+    w.init_device()
+    w.load_model()
+    asks = {r: rnd.choice([None, None, 0, 2]) for r in prompts}
+    waiting = list(prompts)
+    got = {r: [] for r in prompts}
+    left = {}            # request -> tokens still to prefill (new or returning)
+    known = set()        # requests the worker has seen
+    active, parked, done = [], [], set()
+    steps = 0
+    while len(done) < n_req:
+        steps += 1
+        assert steps < 3000
+        new, cached, pieces, finished = [], [], {}, []
+        # requests that reached their length finish (wherever they are)
+        for r in list(active) + list(parked):
+            if len(got[r]) >= n_new:
+                finished.append(r)
+                (active if r in active else parked).remove(r)
+                left.pop(r, None)
+                done.add(r)
+        # a random request is dropped early now and then, even half prefilled or parked
+        pool = [r for r in active + parked if r not in finished]
+        if pool and rnd.random() < 0.04:
+            r = rnd.choice(pool)
+            finished.append(r)
+            (active if r in active else parked).remove(r)
+            left.pop(r, None)
+            done.add(r)
+            want[r] = want[r][:len(got[r])]
+        # return parked requests and admit new ones into the free slots
+        returning = list(parked)         # (a request preempted in this step returns in a later one)
+        # preempt
+        for r in list(active):
+            if r not in left and rnd.random() < 0.07:
+                active.remove(r)
+                parked.append(r)
+        while len(active) < slots and (returning or waiting) and rnd.random() < 0.7:
+            if returning and (not waiting or rnd.random() < 0.5):
+                r = returning.pop(rnd.randrange(len(returning)))
+                parked.remove(r)
+                left[r] = len(prompts[r]) + len(got[r])
+                if rows != "wide":
+                    exact_until.setdefault(r, len(got[r]))
+            else:
+                r = waiting.pop(0)
+                left[r] = len(prompts[r])
+            active.append(r)
+        for r in active:
+            if r in left:
+                n = left[r] if rnd.random() < 0.5 else rnd.randint(1, left[r])
+                pieces[r] = n
+                left[r] -= n
+                if left[r] == 0:
+                    del left[r]
+            if r in known:
+                cached.append(r)
+            else:
+                known.add(r)
+                sp = {"temperature": 0.0}
+                if asks[r] is not None:
+                    sp["logprobs"] = asks[r]
+                new.append(_NewRequestData(r, prompts[r], sampling_params=sp))
+        rnd.shuffle(cached)
+        if not (new or cached or finished):
+            continue
+        so = _sched(new=new, cached=cached, finished=[r for r in finished if r in known])
+        so.num_scheduled_tokens.update(pieces)
+        out = w.execute_model(so)
+        lp = out.logprobs
+        for i, (r, toks) in enumerate(zip(out.req_ids, out.sampled_token_ids)):
+            assert (toks == []) == (r in left), (r, toks)       # only finished prefills emit
+            for j, t in enumerate(toks):
+                if lp is not None:
+                    n = lp.cu_num_generated_tokens[i] + j
+                    assert lp.logprob_token_ids[n][0] == t and lp.sampled_token_ranks[n] == 1
+            got[r].extend(toks)
+        assert w.engine.active + len(w._prefill_of) == len(active)
+        assert w._parked == set(parked)
+    for r in prompts:
+        n = min(n_new, len(want[r]), exact_until.get(r, n_new))
+        assert got[r][:n] == want[r][:n], r
+    w.execute_model(_sched(finished=[r for r in known]))
+    assert w.engine.active == 0 and not w._tokens and not w._parked and not w._prefill_of

@@ -12,12 +12,12 @@ from tests.test_gpu_model import MODELS, _bf, _engine, _generate, _product
 pytestmark = pytest.mark.gpu
 
 
-def _worker(tw, dw, k, use_graph, max_num_seqs=3, temperature=0.0):
+def _worker(tw, dw, k, use_graph, max_num_seqs=3, temperature=0.0, **kw):
     from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
     w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=dw, num_speculative_tokens=k,
                                           max_num_seqs=max_num_seqs, max_model_len=200,
                                           split_tokens=128, use_graph=use_graph,
-                                          temperature=temperature))
+                                          temperature=temperature, **kw))
     w.init_device()
     w.load_model()
     assert w.determine_num_available_blocks()[0] > 0
@@ -512,12 +512,13 @@ def test_v1_preempted_requests_are_rebuilt_when_they_return():
     """A V1 scheduler preempts a request by not scheduling it and later names it again among the
     cached requests: the worker frees its slot, keeps its tokens, and prefills prompt + emitted
     tokens anew when it returns (whole, or in the pieces the scheduler grants).  Greedy streams are
-    the autoregressive ones, interruptions or not."""
+    the autoregressive ones, interruptions or not (bit for bit on the wide kernel family, where
+    decode rows and rebuilt rows come from the same kernels)."""
     from tests.test_host_logic import _NewRequestData, _sched
     tw, dw = _llama_pair()
     prompts = {"a": [5, 9, 200, 31, 7], "b": list(range(40, 73)), "c": [3, 3, 3]}
-    want = {r: _generate(_engine(tw, None, 0), [p], 40)[0] for r, p in prompts.items()}
-    w = _worker(tw, dw, 3, True)
+    want = {r: _generate(_engine(tw, None, 0, rows="wide"), [p], 40)[0] for r, p in prompts.items()}
+    w = _worker(tw, dw, 3, True, rows="wide")
     got = {r: [] for r in prompts}
     N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0})
 

@@ -495,11 +495,15 @@ class SpecEngine:
         end = done + n_tokens
         with _rt.stream_ctx(self.stream):
             if end == n:
-                self._vacate_active_slot(keep=handle)
+                # the prompt's pages move into the next active slot; a prompt still being
+                # prefilled there takes this one's slot in exchange
                 if e["slot"] != self.active:
                     for kv in (self.t_kv, self.d_kv):
                         if kv is not None:
                             kv.swap_slots(e["slot"], self.active)
+                    for other in self._prefilling.values():
+                        if other["slot"] == self.active:
+                            other["slot"] = e["slot"]
                     e["slot"] = self.active
                 del self._prefilling[handle]
                 temperature, top_k, top_p, min_p = e["sampling"]
@@ -517,11 +521,11 @@ class SpecEngine:
                 if kv is not None:
                     kv.release(e["slot"])
 
-    def _vacate_active_slot(self, keep: Optional[int] = None) -> None:
-        """Slot `active` is about to be filled: a prompt still being prefilled there (other than
-        `keep`) moves to a free slot further up."""
+    def _vacate_active_slot(self) -> None:
+        """Slot `active` is about to be filled by a whole prompt: a prompt still being prefilled
+        there moves to a free slot further up (there is one: admission checked the batch size)."""
         for h, e in self._prefilling.items():
-            if e["slot"] == self.active and h != keep:
+            if e["slot"] == self.active:
                 used = {x["slot"] for x in self._prefilling.values()}
                 free = [s for s in range(self.active + 1, self.cfg.max_batch) if s not in used]
                 if not free:
