@@ -276,4 +276,4 @@ def test_random_v1_schedules_on_the_cpu_build(seed, monkeypatch):
     stream is the one the request gets alone."""
     import tests.test_gpu_fuzz as fuzz
     monkeypatch.setattr(fuzz, "_weights", lambda oc, s: _product(oc, _bf(random_state(oc, seed=s))))
-    fuzz.test_random_v1_schedules_with_pieces_and_preemption(seed, False, "wide")
+    fuzz.test_random_v1_schedules_with_pieces_and_preemption(seed, False, "wide", 0.8 if seed == 3 else 0.0)

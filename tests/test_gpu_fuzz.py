@@ -179,9 +179,10 @@ def test_scheduled_streams_match_the_oracle_golden(rows):
     assert n_match >= 0.6 * n_tokens, (n_match, n_tokens)
 
 
-@pytest.mark.parametrize("seed,use_graph,rows", [(0, True, "wide"), (1, True, "wide"), (2, False, "wide"),
-                                                 (3, True, "wide"), (3, True, "narrow"), (4, False, "narrow")])
-def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
+@pytest.mark.parametrize("seed,use_graph,rows,temperature", [
+    (0, True, "wide", 0.0), (1, True, "wide", 0.0), (2, False, "wide", 0.0), (3, True, "wide", 0.0),
+    (3, True, "narrow", 0.0), (4, False, "narrow", 0.0), (5, True, "narrow", 0.8), (6, False, "wide", 0.8)])
+def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows, temperature):
     """A random V1 scheduler over the worker: prompts arrive whole or in pieces of random sizes,
     running requests are preempted (left out of steps) and return whole or in pieces, requests
     finish at random, also while they are parked or half prefilled; some ask for
@@ -190,7 +191,9 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
     family (and the CPU build) that holds across preemptions bit for bit; an engine that decodes
     on the <= 16-row family rebuilds a returning request's emitted tokens with the prefill
     (wide) kernels, whose sums run in another order, so there the comparison stops at a
-    request's first return."""
+    request's first return.  temperature > 0: every request samples from its own seeded stream;
+    the stream it gets alone (from a speculative engine of its own) is the stream it gets in the
+    schedule, which then has no preemption (a returning request draws afresh)."""
     from tests.test_host_logic import _NewRequestData, _sched
     from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
     from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeConfig, SpecDecodeWorker
@@ -198,18 +201,22 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
     tw, dw = _weights(TARGET, 50), _weights(DRAFT, 51)
     n_req, n_new, slots = 10, 24, 3
     prompts = {f"q{i}": [rnd.randrange(TARGET.vocab) for _ in range(rnd.randint(1, 60))] for i in range(n_req)}
-    solo = SpecEngine(tw, None, EngineConfig(k=0, max_batch=1, max_seq_len=140, split_tokens=128, rows=rows))
+    sampling = temperature > 0.0
+    solo = SpecEngine(tw, dw if sampling else None,
+                      EngineConfig(k=3 if sampling else 0, max_batch=1, max_seq_len=140, split_tokens=128,
+                                   rows=rows, temperature=temperature))
     want = {}
     exact_until = {}     # narrow family: tokens a request had when it first returned
-    for r, p in prompts.items():
+    for i, (r, p) in enumerate(prompts.items()):
         solo.reset()
-        out = [solo.add_request(0, p)]
+        out = [solo.add_request(0, p, **({"seed": 1000 + i} if sampling else {}))]
         while len(out) < n_new:
             out.extend(solo.step()[0])
         want[r] = out[:n_new]
     del solo
     w = SpecDecodeWorker(SpecDecodeConfig(target=tw, draft=dw, num_speculative_tokens=3, max_num_seqs=slots,
-                                          max_model_len=140, split_tokens=128, use_graph=use_graph, rows=rows))
+                                          max_model_len=140, split_tokens=128, use_graph=use_graph, rows=rows,
+                                          temperature=temperature))
     w.init_device()
     w.load_model()
     asks = {r: rnd.choice([None, None, 0, 2]) for r in prompts}
@@ -243,7 +250,7 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
         returning = list(parked)         # (a request preempted in this step returns in a later one)
         # preempt
         for r in list(active):
-            if r not in left and rnd.random() < 0.07:
+            if r not in left and not sampling and rnd.random() < 0.07:
                 active.remove(r)
                 parked.append(r)
         while len(active) < slots and (returning or waiting) and rnd.random() < 0.7:
@@ -268,7 +275,9 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
                 cached.append(r)
             else:
                 known.add(r)
-                sp = {"temperature": 0.0}
+                sp = {"temperature": temperature}
+                if sampling:
+                    sp["seed"] = 1000 + int(r[1:])
                 if asks[r] is not None:
                     sp["logprobs"] = asks[r]
                 new.append(_NewRequestData(r, prompts[r], sampling_params=sp))
@@ -284,7 +293,7 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows):
             for j, t in enumerate(toks):
                 if lp is not None:
                     n = lp.cu_num_generated_tokens[i] + j
-                    assert lp.logprob_token_ids[n][0] == t and lp.sampled_token_ranks[n] == 1
+                    assert lp.logprob_token_ids[n][0] == t and (sampling or lp.sampled_token_ranks[n] == 1)
             got[r].extend(toks)
         assert w.engine.active + len(w._prefill_of) == len(active)
         assert w._parked == set(parked)
