@@ -122,6 +122,15 @@ int sd_sample_rows(const float* probs, int64_t ld, const float* uniforms,
 int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_k, const float* top_p,
                         const float* min_p, int rows_per_seq, int R, int V, sd_stream_t stream);
 
+/* Per-request additive logit masks (SamplingParams.logit_bias, allowed_token_ids, bad_words of one
+ * token; upstream: vllm/v1/sample/logits_processor, not in the reference tree): row r of logits
+ * [R, ld] belongs to sequence r / rows_per_seq; where enabled[seq] != 0, bias[seq, 0..V-1] (f32, row
+ * stride ld_bias; -inf bans a token) is added to the row in place.  Applied to the target's
+ * logits before argmax / softmax, so acceptance and every emitted token see the masked
+ * distribution; the draft needs none (a banned proposal is simply rejected).                   */
+int sd_add_logit_bias(float* logits, int64_t ld, const float* bias, int64_t ld_bias,
+                      const int32_t* enabled, int rows_per_seq, int R, int V, sd_stream_t stream);
+
 /* Log-probabilities of chosen tokens, for ModelRunnerOutput.logprobs
  * (/root/reference/src/doc/engine_core.md:326-329: token ids, log-probabilities and ranks per
  * sampled token, max_num_logprobs + 1 columns).  Row r of logits [R, ld] (f32, raw: no

@@ -277,3 +277,26 @@ def test_random_v1_schedules_on_the_cpu_build(seed, monkeypatch):
     import tests.test_gpu_fuzz as fuzz
     monkeypatch.setattr(fuzz, "_weights", lambda oc, s: _product(oc, _bf(random_state(oc, seed=s))))
     fuzz.test_random_v1_schedules_with_pieces_and_preemption(seed, False, "wide", 0.8 if seed == 3 else 0.0)
+
+
+def test_logit_masks_on_the_cpu_build():
+    from vllm_omni_draft_amd import ops
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    x = torch.randn(6, 40)
+    bias = torch.zeros(3, 40)
+    bias[1, ::2] = float("-inf")
+    bias[2, 5] = 2.0
+    on = torch.tensor([0, 1, 1], dtype=torch.int32)
+    want = x.clone()
+    want[2:4] += bias[1]
+    want[4:6] += bias[2]
+    ops.add_logit_bias(x, bias, on, rows_per_seq=2)
+    assert torch.equal(x, want)
+    oc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64, ffn=128,
+                      vocab=64, max_pos=100)
+    w = _product(oc, _bf(random_state(oc, seed=4)))
+    eng = SpecEngine(w, w, EngineConfig(k=2, max_batch=1, max_seq_len=80, split_tokens=128))
+    out = [eng.add_request(0, [1, 2, 3], bias={"allowed_token_ids": list(range(0, 64, 4))})]
+    for _ in range(8):
+        out += eng.step()[0]
+    assert all(t % 4 == 0 for t in out)

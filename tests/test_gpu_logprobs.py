@@ -175,3 +175,108 @@ def test_logprobs_through_the_v1_worker():
     # a finished request stops asking
     so = _sched(cached=["a"], finished=["b", "c"])
     assert w.execute_model(so).logprobs is None and not w._logprobs_of
+
+
+# ---------------------------------------------------------------------------- logit masks
+def _masked_reference(tw, prompt, n_new, mask_row):
+    """The autoregressive stream under a mask, computed step by step on the host from the
+    engine's own logits (k = 0 engine, the mask applied here, greedy)."""
+    eng = _engine(tw, None, 0)
+    out = []
+    eng.add_request(0, prompt)
+    logits = eng.t_logits[0].clone()
+    # an engine without a mask cannot be steered token by token, so the reference re-prefills
+    seq = list(prompt)
+    for _ in range(n_new):
+        tok = int((logits + mask_row.to(logits.device)).argmax())
+        out.append(tok)
+        seq.append(tok)
+        eng.reset()
+        eng.add_request(0, seq)
+        logits = eng.t_logits[0].clone()
+    return out
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_logit_masks_steer_the_target_and_stay_lossless(use_graph):
+    """logit_bias / allowed_token_ids / banned tokens are added to the target's logits before
+    argmax: a speculative engine emits the stream of masked autoregressive decoding (the draft
+    sees no mask: its banned proposals are rejected), requests with and without masks share a
+    batch, a mask follows its sequence to another slot, and the masked stream equals a
+    reference that applies the mask on the host."""
+    tw, dw = _pair()
+    V = MODELS["llama"].vocab
+    pa, pb, pc = [5, 9, 200, 31, 7], list(range(40, 60)), [3, 1, 4, 1, 5]
+    allowed = list(range(0, V, 3))
+    masks = [{"allowed_token_ids": allowed, "logit_bias": {6: 4.0, 9: -3.0}}, None,
+             {"bad_token_ids": [0, 1, 2, 3, 4, 5, 6, 7], "logit_bias": {100: 2.5}}]
+    row_a = torch.full((V,), float("-inf"))
+    row_a[allowed] = 0.0
+    row_a[6] += 4.0
+    row_a[9] += -3.0
+    want_a = _masked_reference(tw, pa, 14, row_a)
+    assert all(t % 3 == 0 for t in want_a)
+    kw = dict(use_graph=use_graph, max_batch=3)
+    # autoregressive engine with the masks == the host reference; the unmasked request is untouched
+    ar = _engine(tw, None, 0, **kw)
+    outs = [[t] for t in ar.add_requests([pa, pb, pc], biases=masks)]
+    while min(len(o) for o in outs) < 30:
+        for o, new in zip(outs, ar.step()):
+            o.extend(new)
+    assert outs[0][:14] == want_a
+    plain = _engine(tw, None, 0)
+    ref_b = [plain.add_request(0, pb)]
+    while len(ref_b) < 30:
+        ref_b += plain.step()[0]
+    assert outs[1][:30] == ref_b[:30]
+    assert not set(outs[2][:30]) & set(range(8))
+    # speculative engine: the same three streams; one at a time, in pieces, and after a move
+    sp = _engine(tw, dw, 3, **kw)
+    got = [[sp.add_request(0, pc, bias=masks[2])]]
+    h = sp.prefill_begin(pa, bias=masks[0])
+    assert sp.prefill_advance(h, 3) is None
+    got[0] += sp.step()[0]
+    got.append([sp.prefill_advance(h, 2)])
+    got.append([sp.add_request(2, pb)])
+    for _ in range(3):
+        for o, new in zip(got, sp.step()):
+            o.extend(new)
+    sp.remove_request(0)                         # pb (no mask) moves from slot 2 to slot 0
+    c_stream, got = got[0], [got[2], got[1]]
+    while min(len(o) for o in got) < 30:
+        for o, new in zip(got, sp.step()):
+            o.extend(new)
+    assert got[0][:30] == outs[1][:30] and got[1][:30] == outs[0][:30]
+    assert c_stream == outs[2][:len(c_stream)]
+    assert sp.metrics()["accepted"] >= 0
+    with pytest.raises(ValueError):
+        sp.add_request(2, pc, bias={"allowed_token_ids": [V + 5]})
+    with pytest.raises(ValueError):
+        sp.add_request(2, pc, bias={"allowed_token_ids": [3], "bad_token_ids": [3]})
+
+
+def test_logit_masks_under_sampling_and_through_the_worker():
+    """A sampling request with a whitelist only ever emits whitelisted tokens (accepted proposals,
+    recovered and bonus tokens alike); through the V1 worker the masks arrive as sampling_params."""
+    from tests.test_gpu_worker import _worker
+    from tests.test_host_logic import _NewRequestData, _sched
+    tw, dw = _pair()
+    V = MODELS["llama"].vocab
+    allowed = list(range(1, V, 2))
+    eng = _engine(tw, dw, 3, max_batch=2, temperature=1.0, seed=4)
+    outs = [[t] for t in eng.add_requests([[5, 9, 200], [7, 7, 7]], biases=[{"allowed_token_ids": allowed}, None])]
+    for _ in range(40):
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    assert all(t % 2 == 1 for t in outs[0]) and any(t % 2 == 0 for t in outs[1])
+    w = _worker(tw, dw, 3, True)
+    sp = {"temperature": 0.0, "allowed_token_ids": allowed, "logit_bias": {"11": 3.0},
+          "bad_words_token_ids": [[13], [15]]}
+    out = w.execute_model(_sched(new=[_NewRequestData("a", [5, 9, 200], sampling_params=sp),
+                                      _NewRequestData("b", [5, 9, 200], sampling_params={"temperature": 0.0})]))
+    toks = {r: list(t) for r, t in zip(out.req_ids, out.sampled_token_ids)}
+    for _ in range(10):
+        out = w.execute_model(_sched(cached=["a", "b"]))
+        for r, t in zip(out.req_ids, out.sampled_token_ids):
+            toks[r].extend(t)
+    assert all(t % 2 == 1 and t not in (13, 15) for t in toks["a"]) and toks["a"] != toks["b"]

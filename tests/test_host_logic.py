@@ -445,10 +445,13 @@ def test_worker_accepts_the_v1_scheduler_output():
     so.kv_connector_metadata = object()
     with pytest.raises(ValueError, match="connector"):
         w.execute_model(so)
-    for bad in ({"prompt_logprobs": 3}, {"repetition_penalty": 1.2}, {"logit_bias": {5: 1.0}},
-                {"allowed_token_ids": [1, 2]}, {"presence_penalty": 0.5}):
+    for bad in ({"prompt_logprobs": 3}, {"repetition_penalty": 1.2}, {"bad_words": ["no"]},
+                {"bad_words_token_ids": [[5, 6]]}, {"presence_penalty": 0.5}):
         with pytest.raises(ValueError, match="not supported"):
             w.execute_model(_sched(new=[_NewRequestData("z", [1, 2], sampling_params=bad)], cached=["b", "c"]))
+    for mask in ({"logit_bias": {5: 1.0}}, {"allowed_token_ids": [1, 2]}, {"bad_words_token_ids": [[7]]}):
+        with pytest.raises(ValueError, match="applies no logit masks"):     # (this stub engine)
+            w.execute_model(_sched(new=[_NewRequestData("z", [1, 2], sampling_params=mask)], cached=["b", "c"]))
     # (log-probabilities of emitted tokens need an engine that computes them; this stub does not)
     for n, msg in ((3, "computes no log-probabilities"), (99, "outside"), (-1, "outside")):
         with pytest.raises(ValueError, match=msg):

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sd_argmax_rows": (i32, [vp, i64, vp, i32, i32, vp]),
     "sd_softmax_rows": (i32, [vp, i64, C.c_float, vp, i64, i32, i32, vp]),
     "sd_filter_probs_seq": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
+    "sd_add_logit_bias": (i32, [vp, i64, vp, i64, vp, i32, i32, i32, vp]),
     "sd_token_logprobs": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, vp, vp]),
     "sd_softmax_rows_seq": (i32, [vp, i64, vp, i32, vp, i64, i32, i32, vp, vp]),
     "sd_sample_rows": (i32, [vp, i64, vp, vp, i32, i32, vp]),

@@ -382,7 +382,7 @@ extern "C" int sd_graph_end(sd_stream_t stream, sd_graph** out) {
   hipGraphExec_t ex = nullptr;
   e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
   if (e != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     sd_set_error("sd_graph_end: instantiate failed: %s", hipGetErrorString(e));
     return SD_ERR_HIP;
   }
@@ -402,8 +402,8 @@ extern "C" int sd_graph_launch(sd_graph* g, sd_stream_t stream) {
 
 extern "C" void sd_graph_destroy(sd_graph* g) {
   if (!g) return;
-  hipGraphExecDestroy(g->exec);
-  hipGraphDestroy(g->graph);
+  (void)hipGraphExecDestroy(g->exec);   // nothing to report to: the handle is gone either way
+  (void)hipGraphDestroy(g->graph);
   delete g;
 }
 

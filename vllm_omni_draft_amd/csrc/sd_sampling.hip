@@ -490,6 +490,24 @@ __global__ __launch_bounds__(kSampleThreads) void softmax_rows_kernel(
   for (int i = tid; i < V; i += blockDim.x) out[i] = expf(row[i] * inv_t - mx) * inv;
 }
 
+__global__ __launch_bounds__(256) void add_logit_bias_kernel(
+    float* __restrict__ logits, int64_t ld, const float* __restrict__ bias, int64_t ld_bias,
+    const int32_t* __restrict__ enabled, int rows_per_seq, int V) {
+  const int r = blockIdx.y, seq = r / rows_per_seq;
+  if (!enabled[seq]) return;   // block-uniform
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+  float* row = logits + (size_t)r * ld;
+  const float* add = bias + (size_t)seq * ld_bias;
+  if (i + 3 < V) {
+    float4 v = *reinterpret_cast<float4*>(row + i);
+    const float4 a = *reinterpret_cast<const float4*>(add + i);
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    *reinterpret_cast<float4*>(row + i) = v;
+  } else {
+    for (int j = i; j < V; ++j) row[j] += add[j];
+  }
+}
+
 // Log-probability and rank of one chosen token per row, and the row's n_top largest entries in
 // (value descending, index ascending) order: each is the maximum of what comes after the previous
 // one in that order, so n_top passes over a row that sits in L2 and no sort.
@@ -1553,6 +1571,20 @@ extern "C" int sd_filter_probs_seq(float* probs, int64_t ld, const int32_t* top_
                      (size_t)n_lds * kSampleThreads * sizeof(float), (hipStream_t)stream, probs, ld, f, V,
                      n_lds);
   SD_CHECK_LAUNCH("sd_filter_probs_seq");
+  return SD_OK;
+}
+
+extern "C" int sd_add_logit_bias(float* logits, int64_t ld, const float* bias, int64_t ld_bias,
+                                 const int32_t* enabled, int rows_per_seq, int R, int V,
+                                 sd_stream_t stream) {
+  SD_REQUIRE(logits && bias && enabled && R >= 0 && V >= 1 && ld >= V && ld_bias >= V && rows_per_seq >= 1,
+             SD_ERR_INVALID, "sd_add_logit_bias: bad arguments (R=%d V=%d)", R, V);
+  SD_REQUIRE(sd_aligned16(logits) && sd_aligned16(bias) && ld % 4 == 0 && ld_bias % 4 == 0,
+             SD_ERR_UNSUPPORTED, "sd_add_logit_bias: rows must be 16-byte aligned");
+  if (R == 0) return SD_OK;
+  hipLaunchKernelGGL(add_logit_bias_kernel, dim3((V + 1023) / 1024, R), dim3(256), 0, (hipStream_t)stream,
+                     logits, ld, bias, ld_bias, enabled, rows_per_seq, V);
+  SD_CHECK_LAUNCH("sd_add_logit_bias");
   return SD_OK;
 }
 

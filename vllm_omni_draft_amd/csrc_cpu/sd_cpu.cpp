@@ -502,6 +502,21 @@ extern "C" int sd_sample_rows(const float* probs, int64_t ld, const float* u, in
   return SD_OK;
 }
 
+extern "C" int sd_add_logit_bias(float* logits, int64_t ld, const float* bias, int64_t ld_bias,
+                                 const int32_t* enabled, int rows_per_seq, int R, int V, sd_stream_t) {
+  REQUIRE(logits && bias && enabled && R >= 0 && V >= 1 && ld >= V && ld_bias >= V && rows_per_seq >= 1,
+          SD_ERR_INVALID, "sd_add_logit_bias: bad arguments");
+#pragma omp parallel for
+  for (int r = 0; r < R; ++r) {
+    const int seq = r / rows_per_seq;
+    if (!enabled[seq]) continue;
+    float* row = logits + (size_t)r * ld;
+    const float* add = bias + (size_t)seq * ld_bias;
+    for (int i = 0; i < V; ++i) row[i] += add[i];
+  }
+  return SD_OK;
+}
+
 extern "C" int sd_token_logprobs(const float* logits, int64_t ld, const int32_t* tokens, int R, int V,
                                  int n_top, int32_t* out_ids, float* out_lp, int32_t* out_ranks,
                                  sd_stream_t) {

@@ -329,6 +329,12 @@ class SpecEngine:
                 ((kk + ka) * B + B * (k + 1), 1, 0, 1)])
             self.bonus_ids = torch.zeros(B, dtype=torch.int64, device=dev)
             self.samp_scratch = ops.sampling_scratch(max(MAX_ROWS, B * q_max), dev)
+        # Per-request logit masks (logit_bias, allowed_token_ids, banned tokens): one f32 row per
+        # batch slot, allocated when the first such request arrives; the device flags tell the
+        # kernel which sequences carry one (the rest are skipped)
+        self.bias: Optional[torch.Tensor] = None
+        self.bias_on = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._bias_host: List[bool] = [False] * B
         # Log-probabilities of the emitted tokens (ModelRunnerOutput.logprobs): off (None) unless
         # the caller sets logprobs_top = the number of most likely tokens to report beside each
         # emitted one (0: the emitted token's own log-probability and rank only).  While it is
@@ -370,6 +376,8 @@ class SpecEngine:
         self.counters.zero_()
         self.active = 0
         self._prefilling.clear()
+        self.bias_on.zero_()
+        self._bias_host = [False] * self.cfg.max_batch
 
     def set_synthetic_acceptance(self, truth: Optional[torch.Tensor], accept_prob: float = 0.0,
                                  seed: int = 0, pattern: Optional[Sequence[int]] = None,
@@ -400,7 +408,8 @@ class SpecEngine:
                     rope_positions: Optional[torch.Tensor] = None,
                     truth_row: Optional[Sequence[int]] = None,
                     seed: Optional[int] = None, temperature: Optional[float] = None,
-                    top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0) -> int:
+                    top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0,
+                    bias: Optional[dict] = None) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
         first token from the target and returns it (this synchronises).
         Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
@@ -413,7 +422,10 @@ class SpecEngine:
         whatever else is in the batch (None: a stream derived from EngineConfig.seed and the
         order of admission).  temperature (sampling engines): the request's own temperature,
         0 for a greedy request among sampling ones (None: EngineConfig.temperature); top_k /
-        top_p / min_p filter the target distribution the request samples from (0 / 1.0 / 0.0: off)."""
+        top_p / min_p filter the target distribution the request samples from (0 / 1.0 / 0.0: off).
+        bias: the request's logit mask, {"logit_bias": {token: value}, "allowed_token_ids": [...],
+        "bad_token_ids": [...]} (any subset), added to the target's logits before every argmax /
+        softmax of the request (see _set_bias)."""
         with _rt.stream_ctx(self.stream):
             if truth_row is not None:
                 if self.truth is None:
@@ -421,7 +433,61 @@ class SpecEngine:
                 row = torch.tensor(list(truth_row)[:self.truth.shape[1]], dtype=torch.int32)
                 self.truth[slot, :row.numel()].copy_(row)
             self._set_temperature(slot, temperature, top_k, top_p, min_p)
+            self._set_bias(slot, bias)
             return self._add_request(slot, prompt, input_embeds, rope_positions, seed)
+
+    def _bias_row(self, spec: Optional[dict]) -> Optional[torch.Tensor]:
+        """The f32 row [V] of a request's logit mask, or None if it has none.  allowed_token_ids
+        bans everything else (-inf), bad_token_ids bans those, logit_bias adds its values."""
+        if not spec or not any(spec.get(k) for k in ("logit_bias", "allowed_token_ids", "bad_token_ids")):
+            return None
+        unknown = set(spec) - {"logit_bias", "allowed_token_ids", "bad_token_ids"}
+        if unknown:
+            raise ValueError(f"unknown logit mask entries {sorted(unknown)}")
+        allowed = [int(t) for t in spec.get("allowed_token_ids") or []]
+        banned = [int(t) for t in spec.get("bad_token_ids") or []]
+        add = {int(t): float(v) for t, v in (spec.get("logit_bias") or {}).items()}
+        for t in allowed + banned + list(add):
+            if not 0 <= t < self.V:
+                raise ValueError(f"token {t} of a logit mask is outside the vocabulary")
+        row = torch.zeros(self.V, dtype=torch.float32)
+        if allowed:
+            row.fill_(float("-inf"))
+            row[allowed] = 0.0
+        for t, v in add.items():
+            row[t] += v
+        if banned:
+            row[banned] = float("-inf")
+        if not bool(torch.isfinite(row).any()):
+            raise ValueError("the logit mask bans every token")
+        return row
+
+    def _set_bias(self, slot: int, spec: Optional[dict]) -> None:
+        row = self._bias_row(spec)
+        if not 0 <= slot < self.cfg.max_batch:      # validation only
+            return
+        if row is None:
+            if self._bias_host[slot]:
+                self.bias_on[slot] = 0
+                self._bias_host[slot] = False
+            return
+        if self.bias is None:
+            self.bias = torch.zeros(self.cfg.max_batch, self.V, dtype=torch.float32, device=self.device)
+        self.bias[slot].copy_(row)
+        self.bias_on[slot] = 1
+        self._bias_host[slot] = True
+
+    def _apply_bias(self, n_rows: int, rows_per_seq: int, slot0: int = 0) -> None:
+        """Adds the sequences' logit masks to rows 0..n_rows-1 of the target's logits of the pass
+        just enqueued (row r -> slot slot0 + r // rows_per_seq), whole rows or this rank's
+        vocabulary slice."""
+        if self.bias is None:
+            return
+        bias = self.bias[slot0:]
+        if self.vp:
+            Vl = self.target.cfg.lm_vocab
+            bias = bias[:, self.tp.rank * Vl:(self.tp.rank + 1) * Vl]
+        ops.add_logit_bias(self.t_out[:n_rows], bias, self.bias_on[slot0:], rows_per_seq)
 
     def _set_temperature(self, slot: int, temperature: Optional[float], top_k: int = 0,
                          top_p: float = 1.0, min_p: float = 0.0) -> None:
@@ -456,7 +522,7 @@ class SpecEngine:
     # ---- prompts prefilled in pieces (a scheduler with chunked prefill)
     def prefill_begin(self, prompt: Sequence[int], seed: Optional[int] = None,
                       temperature: Optional[float] = None, top_k: int = 0, top_p: float = 1.0,
-                      min_p: float = 0.0) -> int:
+                      min_p: float = 0.0, bias: Optional[dict] = None) -> int:
         """Reserves a batch slot for a text prompt that will be prefilled piece by piece and
         returns its handle.  The sequence joins the batch when prefill_advance has consumed the
         whole prompt; until then steps of the active sequences go on as usual."""
@@ -466,11 +532,12 @@ class SpecEngine:
         if self.active + len(self._prefilling) + 1 > self.cfg.max_batch:
             raise ValueError("no free batch slot for another prompt")
         self._set_temperature(-1, temperature, top_k, top_p, min_p)   # validates only
+        self._bias_row(bias)
         used = {e["slot"] for e in self._prefilling.values()}
         slot = max(s for s in range(self.active, self.cfg.max_batch) if s not in used)
         h, self._next_handle = self._next_handle, self._next_handle + 1
         self._prefilling[h] = dict(prompt=[int(t) for t in prompt], done=0, slot=slot, seed=seed,
-                                   sampling=(temperature, top_k, top_p, min_p))
+                                   sampling=(temperature, top_k, top_p, min_p), bias=bias)
         with _rt.stream_ctx(self.stream):
             self.t_kv.ensure_capacity(slot, n + self._slack)
             if self.d_kv is not None:
@@ -508,6 +575,7 @@ class SpecEngine:
                 del self._prefilling[handle]
                 temperature, top_k, top_p, min_p = e["sampling"]
                 self._set_temperature(self.active, temperature, top_k, top_p, min_p)
+                self._set_bias(self.active, e["bias"])
                 return self._add_request(self.active, prompt, seed=e["seed"], start=done)
             self._prefill_range(e["slot"], prompt, done, end, final=False)
             e["done"] = end
@@ -596,6 +664,7 @@ class SpecEngine:
         self._prefill_range(slot, prompt, start, n, final=True, rope_positions=rope_positions,
                             input_embeds=input_embeds)
         # first generated token from the last prompt row (a 1-token pass: row 0)
+        self._apply_bias(1, 1, slot0=slot)
         if self.sampling:
             self._target_full_rows(1)
             u = torch.tensor([self._seed_slot(slot, seed)], dtype=torch.float32).to(self.device)
@@ -624,7 +693,8 @@ class SpecEngine:
                      truth_rows: Optional[Sequence[Sequence[int]]] = None,
                      seeds: Optional[Sequence[Optional[int]]] = None,
                      temperatures: Optional[Sequence[Optional[float]]] = None,
-                     filters: Optional[Sequence[Optional[dict]]] = None) -> List[int]:
+                     filters: Optional[Sequence[Optional[dict]]] = None,
+                     biases: Optional[Sequence[Optional[dict]]] = None) -> List[int]:
         """Prefills several text prompts in the same passes and returns their first tokens (one
         synchronisation for all of them).  The prompts take the next free slots in order.
         Every pass carries a chunk of each prompt (prefill_rows // len(prompts) tokens per
@@ -645,9 +715,12 @@ class SpecEngine:
                 raise ValueError("one temperature (or None) per prompt")
             if filters is not None and len(filters) != len(prompts):
                 raise ValueError("one filter dict {top_k, top_p, min_p} (or None) per prompt")
+            if biases is not None and len(biases) != len(prompts):
+                raise ValueError("one logit mask (or None) per prompt")
             for i in range(len(prompts)):
                 self._set_temperature(self.active + i, None if temperatures is None else temperatures[i],
                                       **((filters[i] or {}) if filters is not None else {}))
+                self._set_bias(self.active + i, None if biases is None else biases[i])
             return self._add_requests([list(p) for p in prompts], seeds)
 
     def _add_requests(self, prompts: List[List[int]], seeds=None) -> List[int]:
@@ -714,6 +787,7 @@ class SpecEngine:
             # every prompt's last token at its own position
             model.forward(view, last, 1, 0, lens_dev, -1, Bp, 1,
                           self.t_out[:Bp] if model is self.target else None, self._ctx, wide=wide)
+        self._apply_bias(Bp, 1, slot0=slot0)
         if self.sampling:
             self._target_full_rows(Bp)
             u = torch.tensor([self._seed_slot(slot0 + i, None if seeds is None else seeds[i])
@@ -843,6 +917,7 @@ class SpecEngine:
                          self.seq_lens[:B], -1, self.tree_rope)
         self._forward(self.target, self.t_kv, self.tree_tok, q, 0, self.seq_lens, -1, B, q,
                       self.t_out, tree=(self.tree_mask, self.tree_rope))
+        self._apply_bias(B * q, q)
         if self.sampling:
             # the target's distribution after every tree row (per-sequence temperature and
             # filters), then the walk with point-mass proposals: the candidates have no draft
@@ -905,6 +980,7 @@ class SpecEngine:
         B = self.active
         self._forward(self.target, self.t_kv, self.tok_buf, 2, 1, self.seq_lens, -1, B, 1,
                       self.t_out)
+        self._apply_bias(B, 1)
         if self.sampling:
             self._target_full_rows(B)
             ops.softmax_rows(self.t_logits[:B], self.temps[:B], out=self.t_probs.view(-1, self.V),
@@ -933,6 +1009,7 @@ class SpecEngine:
             self._forward(self.draft, self.d_kv, self.tok_buf, k + 2, 0, self.seq_lens, -2, B, 2, None)
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, 1,
                       self.t_out)
+        self._apply_bias(B, 1)
         if self.sampling:
             self._target_full_rows(B)
             ops.softmax_rows(self.t_logits[:B], self.temps[:B],
@@ -1078,6 +1155,7 @@ class SpecEngine:
         B, k = self.active, self.k
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, k + 1,
                       self.t_out)
+        self._apply_bias(B * (k + 1), k + 1)
         rows = self.t_logits[:B * (k + 1)]
         if fused:
             self._target_partials(B * (k + 1))
@@ -1134,7 +1212,9 @@ class SpecEngine:
                     kv.move_slot(last, slot)
             if slot != last:
                 moved = [self.seq_lens, self.tok_buf, self.gen_tokens, self.gen_counts, self.rope_delta,
-                         self.force_ctr]
+                         self.force_ctr, self.bias_on]
+                if self._bias_host[last]:
+                    moved.append(self.bias)
                 if self.sampling:
                     moved += [self.u_seeds, self.u_counters, self.temps, self.top_k, self.top_p, self.min_p]
                     self.host_seeds[slot] = self.host_seeds[last]
@@ -1143,9 +1223,13 @@ class SpecEngine:
                 for t in moved:
                     t[slot].copy_(t[last])
                 self.host_lens[slot], self.host_gen[slot] = self.host_lens[last], self.host_gen[last]
+                self._bias_host[slot] = self._bias_host[last]
                 if self.ngram:
                     self.history[slot] = self.history[last]
             self.host_lens[last] = self.host_gen[last] = 0
+            if self._bias_host[last]:
+                self.bias_on[last] = 0
+                self._bias_host[last] = False
             self.active = last
             _rt.synchronize(self.device)
 
@@ -1252,7 +1336,8 @@ class SpecEngine:
         stream = ops._stream()
         lib = _lib.load()
         if self.cfg.use_graph and _rt.on_gpu():   # (the CPU build has no stream capture)
-            key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity)
+            key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity,
+                   self.bias is not None)
             # (a tree step has one shape too: every sequence's tree is padded to tree_nodes rows)
             g = self._graphs.get(key)
             if g is None:

@@ -184,6 +184,24 @@ def softmax_rows(logits: torch.Tensor, temperature=1.0, out=None, *, row_offset=
     return out
 
 
+def add_logit_bias(logits: torch.Tensor, bias: torch.Tensor, enabled: torch.Tensor,
+                   rows_per_seq: int = 1) -> None:
+    """logits[r] += bias[r // rows_per_seq] in place for the sequences whose enabled flag is set
+    (float32 rows, int32 flags; -inf bans a token; see sd_add_logit_bias).  bias may be a column
+    slice of a wider tensor (a rank's share of the vocabulary)."""
+    _need(logits, torch.float32, "logits")
+    _need(enabled, torch.int32, "enabled")
+    if bias.dtype != torch.float32 or bias.dim() != 2 or bias.stride(1) != 1:
+        raise _lib.SdError("add_logit_bias: bias must be float32 rows")
+    R, V = logits.shape
+    n_seq = -(-R // rows_per_seq)
+    if bias.shape[1] != V or bias.shape[0] < n_seq or enabled.numel() < n_seq:
+        raise _lib.SdError("add_logit_bias: bias / flags do not cover the rows' sequences")
+    _lib.check(_lib.load().sd_add_logit_bias(_p(logits), logits.stride(0), bias.data_ptr(), bias.stride(0),
+                                             _p(enabled), rows_per_seq, R, V, _stream()),
+               "sd_add_logit_bias")
+
+
 LOGPROBS_TOP_MAX = 32   # SD_LOGPROBS_TOP_MAX
 
 

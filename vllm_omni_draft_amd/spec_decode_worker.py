@@ -56,6 +56,12 @@ class SamplingParams:
     top_p: float = 1.0
     min_p: float = 0.0
     ignore_eos: bool = True
+    # Logit masks, applied to the target's logits before every argmax / softmax of the request
+    # (sd_add_logit_bias): additive values per token, a whitelist (everything else is banned),
+    # banned single tokens (upstream's bad_words of one token each).
+    logit_bias: Optional[Dict[int, float]] = None
+    allowed_token_ids: Optional[List[int]] = None
+    bad_token_ids: Optional[List[int]] = None
     # None: no log-probabilities.  n >= 0: ModelRunnerOutput.logprobs carries, for every token
     # the request emits, its log-probability under the target's raw logits (no temperature, no
     # filters: upstream's default "raw_logprobs"), its rank, and the n most likely tokens.
@@ -141,6 +147,13 @@ class ModelRunnerOutput:
     spec_decode_metrics: Optional[SpecDecodeWorkerMetrics] = None
 
 
+def _bias_of(sp: "SamplingParams") -> Optional[dict]:
+    """The engine's logit-mask spec of a request, or None."""
+    spec = {k: v for k, v in (("logit_bias", sp.logit_bias), ("allowed_token_ids", sp.allowed_token_ids),
+                              ("bad_token_ids", sp.bad_token_ids)) if v}
+    return spec or None
+
+
 def _get(obj, name, default=None):
     """Field `name` of a dataclass-like object or of a dict."""
     if isinstance(obj, dict):
@@ -185,12 +198,18 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
         if _get(r, "num_computed_tokens", 0):
             raise ValueError(f"request {rid}: prefix-cached prompt tokens are not supported")
         sp = _get(r, "sampling_params", None)
-        for name, off in (("prompt_logprobs", None), ("logit_bias", None),
-                          ("bad_words", None), ("allowed_token_ids", None), ("repetition_penalty", 1.0),
+        for name, off in (("prompt_logprobs", None), ("repetition_penalty", 1.0),
                           ("presence_penalty", 0.0), ("frequency_penalty", 0.0)):
             val = _get(sp, name, off) if sp is not None else off
             if val is not None and val != off and val != [] and val != {}:
                 raise ValueError(f"request {rid}: sampling_params.{name}={val!r} is not supported")
+        # bad words: only as token ids, one token each (a longer one would need the history)
+        bad_ids = _get(sp, "bad_words_token_ids", None) or _get(sp, "_bad_words_token_ids", None) or []
+        if _get(sp, "bad_words", None) and not bad_ids:
+            raise ValueError(f"request {rid}: sampling_params.bad_words as text is not supported "
+                             "(pass bad_words_token_ids)")
+        if any(len(seq) != 1 for seq in bad_ids):
+            raise ValueError(f"request {rid}: bad words of several tokens are not supported")
         if _get(r, "pooling_params", None) is not None:
             raise ValueError(f"request {rid}: pooling requests are not supported")
         if _get(r, "lora_request", None) is not None:
@@ -201,6 +220,10 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
                                 top_k=_get(sp, "top_k", 0) or 0, top_p=_get(sp, "top_p", 1.0) or 1.0,
                                 min_p=_get(sp, "min_p", 0.0) or 0.0,
                                 ignore_eos=bool(_get(sp, "ignore_eos", True)),
+                                logit_bias={int(t): float(v) for t, v in
+                                            (_get(sp, "logit_bias", None) or {}).items()} or None,
+                                allowed_token_ids=list(_get(sp, "allowed_token_ids", None) or []) or None,
+                                bad_token_ids=[int(seq[0]) for seq in bad_ids] or None,
                                 logprobs=_get(sp, "logprobs", None)) if sp is not None \
             else SamplingParams()
         mm = None
@@ -744,6 +767,10 @@ class SpecDecodeWorker:
                                      f"to serve sampling and greedy requests together)")
             if sp.seed is not None and not isinstance(sp.seed, int):
                 raise ValueError(f"request {g.request_id}: seed must be an integer")
+            if _bias_of(sp) is not None:
+                if not hasattr(eng, "_bias_row"):
+                    raise ValueError("this engine applies no logit masks")
+                eng._bias_row(_bias_of(sp))      # raises on tokens outside the vocabulary
             if sp.logprobs is not None:
                 if not isinstance(sp.logprobs, int) or not 0 <= sp.logprobs <= ops.LOGPROBS_TOP_MAX:
                     raise ValueError(f"request {g.request_id}: logprobs {sp.logprobs!r} outside "
@@ -827,12 +854,16 @@ class SpecDecodeWorker:
                           temperatures=[g.sampling_params.temperature for g in group],
                           filters=[dict(top_k=g.sampling_params.top_k, top_p=g.sampling_params.top_p,
                                         min_p=g.sampling_params.min_p) for g in group]) if seeded else {}
+                if any(_bias_of(g.sampling_params) for g in group):
+                    kw["biases"] = [_bias_of(g.sampling_params) for g in group]
                 firsts = eng.add_requests([g.prompt_token_ids for g in group], **kw)
             else:
                 group = prompts[i:i + 1]
                 sp0 = group[0].sampling_params
                 kw = dict(seed=sp0.seed, temperature=sp0.temperature, top_k=sp0.top_k, top_p=sp0.top_p,
                           min_p=sp0.min_p) if seeded else {}
+                if _bias_of(sp0):
+                    kw["bias"] = _bias_of(sp0)
                 firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
                                           **mm_inputs[group[0].request_id], **kw)]
             for n, (g, first) in enumerate(zip(group, firsts)):
@@ -849,6 +880,8 @@ class SpecDecodeWorker:
             sp = g.sampling_params
             kw = dict(seed=sp.seed, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
                       min_p=sp.min_p) if seeded else {}
+            if _bias_of(sp):
+                kw["bias"] = _bias_of(sp)
             self._prefill_of[g.request_id] = eng.prefill_begin(g.prompt_token_ids, **kw)
             self._prefill_left[g.request_id] = len(g.prompt_token_ids)
         for g in pieces + continued:
