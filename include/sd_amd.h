@@ -525,6 +525,65 @@ int sd_embed(const int32_t* ids, int64_t id_stride_seq, int64_t id_offset,
              int q_len, int H, int vocab, sd_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Two dependent linear layers of a decoder layer in one launch, for passes of at
+ * most SD_CHAIN_MAX_ROWS token rows (a draft model's decode passes, where every
+ * launch boundary costs as much as the bytes a small matrix streams).
+ * (No counterpart in the reference tree; upstream's draft worker runs one
+ * kernel per linear layer.)
+ *
+ *   sd_chain_o_up      h += o_w . attention;  act = silu(gate) * up of RMSNorm(h)
+ *                      == sd_linear_attn_merge (or sd_linear) RESIDUAL, then
+ *                         sd_norm_linear SILU_MUL
+ *   sd_chain_down_qkv  h += down_w . act;  q, K/V-cache append of the NEXT layer's
+ *                      RMSNorm(h) . qkv_w with rotary embedding
+ *                      == sd_linear RESIDUAL, then sd_norm_qkv_rope
+ *
+ * Rows have exactly the bits of those calls (same summation order and
+ * roundings).  Inside a launch the first layer's outputs travel between
+ * workgroups as tagged 8-byte words in `state` while the second matrix is
+ * already streaming.  `state`: sd_chain_state_bytes(hidden) bytes of device
+ * memory, 256-byte aligned, prepared once by sd_chain_state_init and then owned by
+ * the calls (it carries the launch counter the tags come from); passes that may
+ * overlap in time (other streams) need a state each.  Shapes: Hq*D, hidden and
+ * ffn multiples of 2048, hidden <= 8192, RMSNorm, gated SiLU MLP, ordinary rotary
+ * positions; w_scale pointers as in sd_linear (both matrices of a call bf16 or
+ * both fp8); biases may be NULL.  Every wait inside a launch is bounded (0.2 s):
+ * a launch whose workgroups cannot all run at once (the grid is one workgroup
+ * per CU at most) raises the failure word read by sd_chain_errors and returns
+ * unspecified rows instead of hanging.                                        */
+#define SD_CHAIN_MAX_ROWS 4
+size_t sd_chain_state_bytes(int hidden);
+/* Zeroes the state and sets the launch counter; synchronises `stream`.       */
+int sd_chain_state_init(void* state, size_t bytes, int hidden, sd_stream_t stream);
+/* *failed != 0: some launch on this state gave up waiting (synchronous read). */
+int sd_chain_errors(const void* state, int* failed);
+/* 1 if both fused calls take these shapes (rows = B*q_len, q_dim = Hq*D).    */
+int sd_chain_supported(int rows, int hidden, int q_dim, int ffn);
+/* attn != NULL: attention output rows [B*q_len, Hq*D] (row stride ld_attn);
+ * attn == NULL: the per-split partials sd_paged_attention (out == NULL) left in
+ * attn_workspace are merged while staging (arguments as sd_linear_attn_merge).
+ * h [B*q_len, hidden] is read (residual) and overwritten; act [B*q_len, ffn].  */
+int sd_chain_o_up(void* state, const void* o_w, const float* o_s, const void* o_b,
+                  const void* attn, int64_t ld_attn, const void* attn_workspace,
+                  size_t attn_workspace_bytes, const int32_t* seq_lens,
+                  int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
+                  int max_ctx, int split_tokens, void* h, int hidden,
+                  const void* norm_w, float eps, const void* up_w,
+                  const float* up_s, const void* up_b, void* act, int64_t ld_act,
+                  int ffn, sd_stream_t stream);
+/* norm_w / qkv_w / qkv_b / the cache pointers belong to the layer AFTER the one
+ * whose down projection this is; other arguments as sd_norm_qkv_rope.         */
+int sd_chain_down_qkv(void* state, const void* down_w, const float* down_s,
+                      const void* down_b, const void* act, int64_t ld_act, int ffn,
+                      void* h, int hidden, const void* norm_w, float eps,
+                      const void* qkv_w, const float* qkv_s, const void* qkv_b,
+                      void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
+                      void* k_cache, void* v_cache, const int32_t* block_tables,
+                      int max_blocks_per_seq, const int32_t* seq_lens,
+                      int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
+                      sd_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Decoder model: a host-side descriptor over caller-owned device weights.
  * ---------------------------------------------------------------------- */
 
@@ -636,6 +695,12 @@ typedef struct {
    * (Hq/Hkv) <= 64, and rope_pos = the rows' rotary positions ([B*q_len] i32; a model
    * without sections reads one component only).                              */
   const uint64_t* tree_mask;
+  /* NULL, or a prepared sd_chain state (sd_chain_state_init, this model's hidden
+   * size): passes whose shapes sd_chain_supported accepts (narrow family, RMSNorm
+   * model, no tensor parallelism, no tree, no multimodal positions) then run
+   * every layer as attention + sd_chain_o_up + sd_chain_down_qkv, three launches
+   * instead of five, with the same bits.                                      */
+  void* chain_state;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

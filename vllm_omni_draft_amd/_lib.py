@@ -54,7 +54,8 @@ class ForwardArgs(C.Structure):
     _fields_ = [("B", i32), ("q_len", i32), ("token_ids", vp), ("tok_stride", i64),
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
                 ("split_tokens", i32), ("logits", vp), ("wide", i32),
-                ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp)]
+                ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp),
+                ("chain_state", vp)]
 
 
 class UniformRegion(C.Structure):
@@ -149,6 +150,14 @@ SIGNATURES = {
     "sd_propose_from_partials": (i32, [vp, vp, i32, i32, vp, i32, i32, i32, vp]),
     "sd_verify_from_partials": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp, i32, i32,
                                       vp]),
+    "sd_chain_state_bytes": (C.c_size_t, [i32]),
+    "sd_chain_state_init": (i32, [vp, C.c_size_t, i32, vp]),
+    "sd_chain_errors": (i32, [vp, C.POINTER(i32)]),
+    "sd_chain_supported": (i32, [i32, i32, i32, i32]),
+    "sd_chain_o_up": (i32, [vp, vp, vp, vp, vp, i64, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32,
+                            i32, i32, vp, i32, vp, C.c_float, vp, vp, vp, vp, i64, i32, vp]),
+    "sd_chain_down_qkv": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, i32, vp, C.c_float, vp, vp, vp, vp,
+                                i64, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "sd_graph_begin": (i32, [vp]),
     "sd_graph_end": (i32, [vp, C.POINTER(vp)]),
     "sd_graph_launch": (i32, [vp, vp]),

@@ -233,6 +233,11 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       tree || (mrope && (a->rope_pos || a->rope_delta)) ? &rope_pos : nullptr;
   SD_REQUIRE(mrope || tree || (!a->rope_pos && !a->rope_delta), SD_ERR_INVALID,
              "sd_model_forward: rotary positions given to a model without rotary sections");
+  // Layers as attention + two fused launches (sd_chain_*), when the caller brought a state and
+  // the pass has the shape for it; same bits as the five launches below.
+  const bool chain = a->chain_state && !wide && llama && !d.allreduce && !tree && !rpp &&
+                     sd_fused_norm_fits(rows, H, false) &&
+                     sd_chain_supported(rows, H, Hq * D, F) != 0;
   for (int li = 0; li < d.n_layers; ++li) {
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
@@ -280,7 +285,9 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       continue;
     }
     const bool fuse = sd_fused_norm_fits(rows, H, !llama);
-    if (fuse) {
+    if (chain && li > 0) {
+      // q and the cache entries of this layer came out of the previous layer's fused launch
+    } else if (fuse) {
       SD_TRY(sd_norm_qkv_rope(l.qkv_w, l.qkv_s, h, H, l.attn_norm_w, l.attn_norm_b, d.norm_eps, !llama,
                               l.qkv_b, qkv, (int64_t)Hq * D, llama ? d.rope_cs : nullptr, d.max_pos,
                               kc, vc, kv->block_tables, kv->max_blocks_per_seq, a->seq_lens,
@@ -313,6 +320,26 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     }
     // Row-parallel projections under tensor parallelism: rank 0 adds the residual and the
     // bias, the others store their partial product, and the sum over ranks lands in h.
+    if (chain) {
+      SD_TRY(sd_chain_o_up(a->chain_state, l.o_w, l.o_s, l.o_b, merge_in_proj ? nullptr : attn,
+                           (int64_t)Hq * D, attn_ws, w.attn_ws_bytes, a->seq_lens, a->pos_offset,
+                           a->B, a->q_len, Hq, Hkv, D, a->max_ctx, a->split_tokens, h, H,
+                           l.mlp_norm_w, d.norm_eps, l.up_w, l.up_s, l.up_b, act, F, F, stream));
+      if (li + 1 < d.n_layers) {
+        const sd_layer_weights& nx = m->layers[li + 1];
+        SD_TRY(sd_chain_down_qkv(a->chain_state, l.down_w, l.down_s, l.down_b, act, F, F, h, H,
+                                 nx.attn_norm_w, d.norm_eps, nx.qkv_w, nx.qkv_s, nx.qkv_b, qkv,
+                                 (int64_t)Hq * D, d.rope_cs, d.max_pos,
+                                 (char*)kc + kv->layer_stride_bytes,
+                                 (char*)vc + kv->layer_stride_bytes, kv->block_tables,
+                                 kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
+                                 Hq, Hkv, D, stream));
+      } else {
+        SD_TRY(sd_linear(l.down_w, l.down_s, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL,
+                         stream));
+      }
+      continue;
+    }
     const bool lead = !d.allreduce || d.tp_rank == 0;
     const int proj_epi = lead ? SD_EPI_RESIDUAL : SD_EPI_STORE;
     if (merge_in_proj) {

@@ -1013,6 +1013,27 @@ extern "C" int sd_linear_attn_merge(const void*, const float*, const void*, size
   UNSUPPORTED("sd_linear_attn_merge");
 }
 
+// The fused two-layer launches exist to hide GPU launch boundaries; the CPU build has none
+// to hide: sd_model_forward ignores chain_state and the entry points are not provided.
+extern "C" size_t sd_chain_state_bytes(int hidden) {
+  return hidden < 1 ? 0 : 256 + (size_t)SD_CHAIN_MAX_ROWS * hidden * 8;
+}
+extern "C" int sd_chain_state_init(void*, size_t, int, sd_stream_t) { UNSUPPORTED("sd_chain_state_init"); }
+extern "C" int sd_chain_errors(const void*, int*) { UNSUPPORTED("sd_chain_errors"); }
+extern "C" int sd_chain_supported(int, int, int, int) { return 0; }
+extern "C" int sd_chain_o_up(void*, const void*, const float*, const void*, const void*, int64_t,
+                             const void*, size_t, const int32_t*, int, int, int, int, int, int, int, int,
+                             void*, int, const void*, float, const void*, const float*, const void*,
+                             void*, int64_t, int, sd_stream_t) {
+  UNSUPPORTED("sd_chain_o_up");
+}
+extern "C" int sd_chain_down_qkv(void*, const void*, const float*, const void*, const void*, int64_t, int,
+                                 void*, int, const void*, float, const void*, const float*, const void*,
+                                 void*, int64_t, const float*, int, void*, void*, const int32_t*, int,
+                                 const int32_t*, int, int, int, int, int, int, sd_stream_t) {
+  UNSUPPORTED("sd_chain_down_qkv");
+}
+
 extern "C" int sd_norm_qkv_rope(const void* W, const float* ws, const void* x, int64_t ldx,
                                 const void* norm_w, const void* norm_b, float eps, int layer_norm,
                                 const void* bias, void* q_out, int64_t ldq, const float* rope_cs,

@@ -86,6 +86,10 @@ class EngineConfig:
     # proposals (sd_tree_accept_sample).  1 = a single chain of k proposals.
     tree_candidates: int = 1
     tree_nodes: int = 0
+    # Draft passes of <= 4 rows with two linear layers per launch (DecoderModel fused_pairs):
+    # same proposals bit for bit, three launches per layer instead of five.  Off by default:
+    # measured slower than the five launches on MI355X.
+    draft_fused_pairs: bool = False
 
 
 def acceptance_pattern(accept_prob: float, k: int, length: int = 16, rotate: int = 0) -> List[int]:
@@ -181,7 +185,8 @@ class SpecEngine:
         else:
             draft_wide = self.wide if cfg.draft_rows == "same" else cfg.draft_rows == "wide"
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
-                                   wide=draft_wide, tp_group=tp_group if draft_tp else None)
+                                   wide=draft_wide, tp_group=tp_group if draft_tp else None,
+                                   fused_pairs=cfg.draft_fused_pairs)
                       if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self._lanes: List[torch.cuda.Stream] = []

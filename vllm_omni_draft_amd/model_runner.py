@@ -28,7 +28,8 @@ def _ptr(t):
 
 class DecoderModel:
     def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
-                 tp_group=None, wide: bool = False, wide_prefill: bool = True):
+                 tp_group=None, wide: bool = False, wide_prefill: bool = True,
+                 fused_pairs: bool = False):
         """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
@@ -77,6 +78,16 @@ class DecoderModel:
         nbytes = lib.sd_model_workspace_bytes(self._handle, max(self.max_rows, self.prefill_rows),
                                               max_ctx, split_tokens)
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=weights.embed.device)
+        # fused_pairs: passes of <= 4 rows run each layer as attention + sd_chain_o_up +
+        # sd_chain_down_qkv (three launches for five, same bits).  Opt-in: on MI355X the five
+        # launches are faster (an in-launch exchange costs what a launch boundary costs).
+        self.chain_state = None
+        if fused_pairs:
+            if tp_group is not None or cfg.arch != "llama" or cfg.mrope_section or not ops.on_gpu() \
+                    or not ops.chain_supported(1, cfg.hidden, cfg.n_heads * cfg.head_dim, cfg.ffn):
+                raise _lib.SdError("fused_pairs needs an unsharded rotary model on the GPU build whose "
+                                   "hidden, Hq*D and ffn widths are multiples of 2048")
+            self.chain_state = ops.chain_state(cfg.hidden, device=weights.embed.device)
 
     def __del__(self):
         h = getattr(self, "_handle", None)
@@ -144,7 +155,8 @@ class DecoderModel:
                                 max_ctx=max_ctx or self.max_ctx, split_tokens=self.split_tokens,
                                 logits=_ptr(logits), wide=int(self.wide if wide is None else wide),
                                 input_embeds=_ptr(input_embeds), rope_pos=_ptr(rope_pos),
-                                rope_delta=_ptr(rope_delta), tree_mask=_ptr(tree_mask))
+                                rope_delta=_ptr(rope_delta), tree_mask=_ptr(tree_mask),
+                                chain_state=_ptr(self.chain_state) if workspace is None else None)
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
                                           ops._stream())

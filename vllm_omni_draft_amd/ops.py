@@ -3,6 +3,7 @@ HIP stream, raise on any non-zero status.  No computation happens in Python
 and nothing here falls back to PyTorch ops."""
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -821,4 +822,64 @@ def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache,
         Hq * D, _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache),
         _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
         _rope_positions(rope_pos, rope_delta, mrope_section, M), _stream()), "sd_norm_qkv_rope")
+    return q
+
+
+# ---------------------------------------------------------------- fused two-layer launches
+def chain_state(hidden: int, device="cuda") -> torch.Tensor:
+    """The device state of the fused launches below (sd_chain_state_init): tagged-word exchange
+    buffer + launch counter.  One per model and per stream that may run passes concurrently."""
+    lib = _lib.load()
+    n = int(lib.sd_chain_state_bytes(hidden))
+    st = torch.zeros(n + 256, dtype=torch.uint8, device=device)
+    off = (-st.data_ptr()) % 256
+    st = st[off:off + n]
+    _lib.check(lib.sd_chain_state_init(_p(st), n, hidden, _stream()), "sd_chain_state_init")
+    return st
+
+
+def chain_supported(rows: int, hidden: int, q_dim: int, ffn: int) -> bool:
+    return bool(_lib.load().sd_chain_supported(rows, hidden, q_dim, ffn))
+
+
+def chain_errors(state: torch.Tensor) -> int:
+    failed = C.c_int(0)
+    _lib.check(_lib.load().sd_chain_errors(_p(state), C.byref(failed)), "sd_chain_errors")
+    return failed.value
+
+
+def chain_o_up(state, o_w: TiledWeight, h, norm_w, eps, up_w: TiledWeight, B, q_len, Hq, Hkv, D, *,
+               attn=None, workspace=None, seq_lens=None, pos_offset=0, max_ctx=1, split_tokens=256,
+               o_bias=None, up_bias=None, act=None) -> torch.Tensor:
+    """h += o_w @ attention (rows `attn`, or merged from the partials in `workspace`);
+    returns act = silu(gate) * up of RMSNorm(h).  h is updated in place."""
+    _need(h, torch.bfloat16, "h")
+    M, H = h.shape
+    F = up_w.N
+    if act is None:
+        act = torch.empty(M, F, dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.load().sd_chain_o_up(
+        _p(state), _p(o_w.data), _p(o_w.scale), _p(o_bias), _p(attn),
+        0 if attn is None else attn.stride(0), _p(workspace),
+        0 if workspace is None else workspace.numel(), _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D,
+        max_ctx, split_tokens, _p(h), H, _p(norm_w), float(eps), _p(up_w.data), _p(up_w.scale),
+        _p(up_bias), _p(act), act.stride(0), F, _stream()), "sd_chain_o_up")
+    return act
+
+
+def chain_down_qkv(state, down_w: TiledWeight, act, h, norm_w, eps, qkv_w: TiledWeight, rope_cs,
+                   k_cache, v_cache, block_tables, seq_lens, pos_offset, B, q_len, Hq, Hkv, D, *,
+                   down_bias=None, qkv_bias=None) -> torch.Tensor:
+    """h += down_w @ act; returns the rotated q of RMSNorm(h) @ qkv_w (K/V appended to the
+    cache).  h is updated in place."""
+    _need(h, torch.bfloat16, "h")
+    _need(act, torch.bfloat16, "act")
+    M, H = h.shape
+    q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.load().sd_chain_down_qkv(
+        _p(state), _p(down_w.data), _p(down_w.scale), _p(down_bias), _p(act), act.stride(0),
+        act.shape[1], _p(h), H, _p(norm_w), float(eps), _p(qkv_w.data), _p(qkv_w.scale),
+        _p(qkv_bias), _p(q), Hq * D, _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0],
+        _p(k_cache), _p(v_cache), _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset,
+        B, q_len, Hq, Hkv, D, _stream()), "sd_chain_down_qkv")
     return q
