@@ -51,7 +51,10 @@ def main():
     cfg = config.preset(name)
     w = weights.random_init(cfg, seed=2, device=dev)
     model = DecoderModel(w, max_ctx, int(os.environ.get("SD_SPLIT", "256")),
-                         wide=os.environ.get("SD_WIDE", "0") == "1")
+                         wide=os.environ.get("SD_WIDE", "0") == "1",
+                         fused_pairs=os.environ.get("SD_FUSED", "0") == "1")
+    if model.chain_state is not None:
+        print("two linear layers per launch (sd_chain_*)", flush=True)
     if os.environ.get("SD_WIDE", "0") == "1":
         print("wide kernel family", flush=True)
     B = int(os.environ.get("SD_B", "1"))          # sequences per pass, q_len rows each
