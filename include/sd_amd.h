@@ -550,7 +550,11 @@ int sd_embed(const int32_t* ids, int64_t id_stride_seq, int64_t id_offset,
  * both fp8); biases may be NULL.  Every wait inside a launch is bounded (0.2 s):
  * a launch whose workgroups cannot all run at once (the grid is one workgroup
  * per CU at most) raises the failure word read by sd_chain_errors and returns
- * unspecified rows instead of hanging.                                        */
+ * unspecified rows instead of hanging.  The launch counter is 32 bits wide:
+ * prepare the state again before 2^32 launches (days of decoding).  On
+ * MI355X these launches measured slower than the ones they replace (an
+ * in-launch exchange costs what a launch boundary costs): a building block
+ * for a resident draft pass, not the default path.                           */
 #define SD_CHAIN_MAX_ROWS 4
 size_t sd_chain_state_bytes(int hidden);
 /* Zeroes the state and sets the launch counter; synchronises `stream`.       */
