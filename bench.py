@@ -190,6 +190,56 @@ def kernel_roofline(eng, tw, rows, reps=3):
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
+def draft_pass_roofline(dw, device, ctx, split_tokens):
+    """One decode pass of the draft model (one row, `ctx` cached tokens, LM head included) in a
+    replayed graph of four passes on a cache of its own: the bytes a pass must stream (every
+    weight matrix once, the context's K/V once) over its duration.  The k passes of a step run
+    one after the other, so this is the rate the draft side of the step runs at."""
+    import ctypes as C
+    from vllm_omni_draft_amd import _lib
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    cfg = dw.cfg
+    max_ctx = ctx + 64
+    model = DecoderModel(dw, max_ctx, split_tokens)
+    kv = PagedKVCache(cfg, PagedKVCache.pages_for(cfg, 1, max_ctx), 1, max_ctx, device)
+    kv.ensure_capacity(0, max_ctx)
+    kv.k.normal_(0, 0.5)
+    kv.v.normal_(0, 0.5)
+    seq_lens = torch.tensor([ctx], dtype=torch.int32, device=device)
+    toks = torch.arange(5, 13, dtype=torch.int32, device=device)
+    logits = torch.empty(1, cfg.head_rows, dtype=torch.float32, device=device)
+    lib = _lib.load()
+    stream = torch.cuda.Stream()
+    reps = 4
+    enqueue = lambda: [model.forward(kv, toks, 0, 0, seq_lens, 0, 1, 1, logits, max_ctx) for _ in range(reps)]
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        enqueue()
+        torch.cuda.synchronize()
+        g = C.c_void_p()
+        _lib.check(lib.sd_graph_begin(stream.cuda_stream), "sd_graph_begin")
+        enqueue()
+        _lib.check(lib.sd_graph_end(stream.cuda_stream, C.byref(g)), "sd_graph_end")
+        ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lib.sd_graph_launch(g, stream.cuda_stream)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / reps)
+        lib.sd_graph_destroy(g)
+    us = sorted(ts)[len(ts) // 2]
+    nbytes = streamed_weight_bytes(dw) + 2 * cfg.n_layers * cfg.n_kv_heads * cfg.head_dim * ctx * 2
+    gbs = nbytes / us * 1e-3
+    return {"what": f"one decode pass of the draft ({cfg.n_layers} layers + LM head), 1 row, {ctx} cached "
+                    f"tokens, in a replayed graph", "bound": "hbm", "bytes_per_pass": int(nbytes),
+            "us_per_pass": round(us, 1), "launches_per_pass": 5 * cfg.n_layers + 2,
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def attention_roofline(device, k):
     """The verify attention kernel alone at a KV-bound size: 32 sequences x 4096
     cached tokens, Llama-3-8B head shape, k+1 query tokens each."""
@@ -423,6 +473,7 @@ def main():
                     *((streamed_weight_bytes(tw), streamed_weight_bytes(dw)) if fp8 else ()))
     roof = kernel_roofline(eng, tw, k + 1)
     attn = attention_roofline(device, k)
+    draft_pass = draft_pass_roofline(dw, device, int(ctx_mid), args.draft_split_tokens or args.split_tokens)
     sweep = []
     other_mode = None
     fp8_draft = None
@@ -520,6 +571,7 @@ def main():
                           "unit": "GB/s", "frac": round(sb / (ms_per_step * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)},
         "roofline": roof,
         "verify_attention_roofline": attn,
+        "draft_pass_roofline": draft_pass,
         "accept_sweep": sweep,
         "cpu_baseline": cpu,
     }
