@@ -32,6 +32,24 @@ lib.sd_debug_read_chain_stamps.argtypes = [C.c_void_p]
 buf = (C.c_uint64 * 32)()
 
 
+lib.sd_debug_read_chain_wg_stamps.argtypes = [C.c_void_p]
+wbuf = (C.c_uint64 * (512 * 4))()
+
+
+def show_wgs(name, n_wg=256):
+    """Distribution over the workgroups: when each published phase 0, had gathered phase 1's
+    input and ended, relative to the earliest start."""
+    assert lib.sd_debug_read_chain_wg_stamps(wbuf) == 0
+    t = [[wbuf[w * 4 + i] for i in range(4)] for w in range(n_wg)]
+    t0 = min(r[0] for r in t)
+    cols = ["start", "published", "gathered", "end"]
+    parts = []
+    for i, c in enumerate(cols):
+        v = sorted((r[i] - t0) / 100.0 for r in t)
+        parts.append(f"{c} {v[0]:.2f}/{v[len(v) // 2]:.2f}/{v[-1]:.2f}")
+    print(f"{name} all workgroups (min/median/max us): " + "  ".join(parts))
+
+
 def show(name):
     torch.cuda.synchronize()
     assert lib.sd_debug_read_chain_stamps(buf) == 0
@@ -48,8 +66,10 @@ for rep in range(3):
         act = ops.chain_o_up(state, l["o"], h, g, 1e-5, l["up"], 1, M, Hq, Hkv, D, attn=attn)
         if rep == 2:
             show("o_up    ")
+            show_wgs("o_up    ")
         q = ops.chain_down_qkv(state, l["down"], act, h, g, 1e-5, l["qkv"], cs, kc, vc, bt, seq_lens, 0, 1,
                                M, Hq, Hkv, D)
         if rep == 2:
             show("down_qkv")
+            show_wgs("down_qkv")
 print("chain errors:", ops.chain_errors(state))

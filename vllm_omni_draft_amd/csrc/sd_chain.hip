@@ -40,6 +40,10 @@ constexpr int kMaxUnits = 8;       // units of one phase a workgroup may own
 constexpr size_t kEpiBytes = ((size_t)2 * kMaxRows * kMaxUnits * 16 + 4 * kMaxUnits * 16) * 4 +
                              kMaxRows * 2 * 4;
 constexpr unsigned long long kPollTicks = 20000000ull;  // 0.2 s of the 100 MHz wall clock
+#ifndef SD_CHAIN_IN_FLIGHT
+#define SD_CHAIN_IN_FLIGHT 4
+#endif
+constexpr int kInFlight = SD_CHAIN_IN_FLIGHT;  // wave loads a streaming wave keeps outstanding
 
 enum { KIND_O_UP = 0, KIND_DOWN_QKV = 1 };
 
@@ -92,8 +96,13 @@ __device__ unsigned long long sd_chain_stamps[32];
 // slot i by the first streaming wave, slot 16 + i by the first row wave, of workgroup 0
 #define CSTAMP(i) \
   if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) sd_chain_stamps[(i) + (threadIdx.x >= 512 ? 16 : 0)] = wall_clock64()
+// every workgroup: [0] start, [1] phase 0 published, [2] phase 1 input gathered, [3] end
+__device__ unsigned long long sd_chain_wg_stamps[512][4];
+#define WSTAMP(i) \
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 512) sd_chain_wg_stamps[blockIdx.x][i] = wall_clock64()
 #else
 #define CSTAMP(i)
+#define WSTAMP(i)
 #endif
 
 __device__ __forceinline__ unsigned long long pack_word(bf16_t v, unsigned tag) {
@@ -193,7 +202,6 @@ __global__ __launch_bounds__(kMaxThreads) void chain_kernel(ChainArgs a) {
     const bool copy_x0 = !(KIND == KIND_O_UP && a.merge.part_o);
     const bf16_t* xr = a.x0 + (size_t)m * a.ldx0;
     bf16_t* xl0 = xs0 + (size_t)m * LDX0;
-    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 xv[16], gv[4];
     // unconditional loads from clamped addresses (a branch around a load makes the compiler
     // wait for everything in flight at the join); values are selected after the barrier
@@ -353,6 +361,7 @@ __global__ __launch_bounds__(kMaxThreads) void chain_kernel(ChainArgs a) {
         }
       }
       CSTAMP(3);
+      if (m == 0) { WSTAMP(2); }
       if (!ok && lane == 0)
         __hip_atomic_store(a.state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float rs = rsqrtf(wave_sum(s2) / (float)H + a.eps);
@@ -381,32 +390,47 @@ __global__ __launch_bounds__(kMaxThreads) void chain_kernel(ChainArgs a) {
     unit = wg + ui * G;
     seg = wave + kStreamWaves * s;
   };
-  bf16x8 r0[kWLoads], r1[kWLoads];
-  // Always kWLoads loads, no branch (the wait counts the compiler derives stay exact): an
-  // item past the end re-reads the matrix's first KiB; lanes of a half-tile unit's other
-  // row half read their partner lane's bytes (same cache line) and are zeroed when used.
+  // Three ring slots of one segment each: deep enough to take in the second matrix while the
+  // first phase's outputs cross the chip.  Requests are THROTTLED: a wave keeps at most
+  // kInFlight wave loads (1 KiB each; twice as many for half-tile items, whose loads carry
+  // half the bytes) outstanding.  16..32 KiB in flight per CU already stream at the full HBM
+  // rate (experiments/inflight_latency.hip: 6.2 TB/s at 16 KiB, 5.5 TB/s at 128 KiB), and a
+  // small load of another wave of the CU then returns in 0.6..1 us instead of 8.
+  bf16x8 r0[kWLoads], r1[kWLoads], r2[kWLoads];
+  // lanes of a half-tile unit's other row half read their partner lane's bytes (same cache
+  // line) and are zeroed when used
   auto issue = [&](bf16x8(&r)[kWLoads], int gi) {
-    const bool valid = gi < n_total;
+    if (gi >= n_total) return;
     int p, ui, unit, seg, s;
-    decode(valid ? gi : 0, p, ui, unit, seg, s);
+    decode(gi, p, ui, unit, seg, s);
     const ChainPhase& ph = a.ph[p];
     const int KS = ph.K / 32;
     const int tile = ph.half ? unit >> 1 : unit;
     const bool live = !ph.half || ((lane >> 3) & 1) == (unit & 1);
-    const size_t off = valid ? ((size_t)tile * (KS / kWSteps) + (size_t)seg * kWLoads) * 512 : 0;
+    const size_t off = ((size_t)tile * (KS / kWSteps) + (size_t)seg * kWLoads) * 512;
     const bf16_t* w = ph.W + off + (live ? lane : lane ^ 8) * 8;
+    if (ph.half) {
 #pragma unroll
-    for (int j = 0; j < kWLoads; ++j)
-      r[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w + (size_t)j * 512));
+      for (int j = 0; j < kWLoads; ++j) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kInFlight - 1) : "memory");
+        r[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w + (size_t)j * 512));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kWLoads; ++j) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kInFlight - 1) : "memory");
+        r[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w + (size_t)j * 512));
+      }
+    }
   };
 
   // epilogue role of this thread (waves 0..3): row nl of the tile, token m
   const int nl = 4 * (tid >> 6) + (tid & 3), m = (tid >> 2) & 15;
   const bool epi_row = tid < 256 && m < M;
   CSTAMP(0);
+  if (wave == 0) { WSTAMP(0); }
   __syncthreads();  // the row waves have asked for their activations
   issue(r0, 0);
-  issue(r1, 1);
   __syncthreads();  // phase 0 input staged
   CSTAMP(1);
 
@@ -486,8 +510,9 @@ __global__ __launch_bounds__(kMaxThreads) void chain_kernel(ChainArgs a) {
     }
   };
 
-  // one item: wait for its ring slot, refill the slot two items ahead, chain the MFMAs
-  auto half_step = [&](bf16x8(&r)[kWLoads], int gi) {
+  // one item: its ring slot through the MFMAs, the unit's end if it is the unit's last segment,
+  // then the slot's refill three items ahead
+  auto half_step = [&](bf16x8(&r)[kWLoads], int gi, bool refill) {
     int p, ui, unit, seg, s;
     decode(gi, p, ui, unit, seg, s);
     if (gi == n0 && p == 1) {
@@ -499,7 +524,6 @@ __global__ __launch_bounds__(kMaxThreads) void chain_kernel(ChainArgs a) {
     bf16x8 cur[kWLoads];
 #pragma unroll
     for (int j = 0; j < kWLoads; ++j) cur[j] = live ? r[j] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    issue(r, gi + 2);
     if (s == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
     const bf16_t* xp = (p ? xrow1 : xrow0) + (size_t)seg * kSeg * 32;
 #pragma unroll
@@ -515,17 +539,25 @@ __global__ __launch_bounds__(kMaxThreads) void chain_kernel(ChainArgs a) {
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc, 0, 0, 0);
     }
     if (s == (p ? spw1 : spw0) - 1) unit_end(p, ui, unit);
+    if (refill) issue(r, gi + 3);
   };
 
-  // pairs in the loop, an odd last item behind it: the loop body always issues both slots, so
-  // the wait in front of a slot is "all but the other slot's loads"
-  int gi = 0;
-  for (; gi + 1 < n_total; gi += 2) {
-    half_step(r0, gi);
-    half_step(r1, gi + 1);
+  // The first item is used (and, one segment per unit, published) before the ring fills up.
+  half_step(r0, 0, false);
+  if (wave == 0) { WSTAMP(1); }
+  issue(r1, 1);
+  issue(r2, 2);
+  issue(r0, 3);
+  int gi = 1;
+  for (; gi + 2 < n_total; gi += 3) {
+    half_step(r1, gi, true);
+    half_step(r2, gi + 1, true);
+    half_step(r0, gi + 2, true);
   }
-  if (gi < n_total) half_step(r0, gi);
+  if (gi < n_total) half_step(r1, gi, false);
+  if (gi + 1 < n_total) half_step(r2, gi + 1, false);
   CSTAMP(4);
+  if (wave == 0) { WSTAMP(3); }
   // the next launch's tag (every workgroup read this one's before it published anything, and
   // workgroup 0 got here only after gathering every workgroup's words)
   if (wg == 0 && tid == 0) a.state[0] = tag + 1u;
@@ -711,5 +743,8 @@ extern "C" int sd_chain_down_qkv(void* state, const void* down_w, const float* d
 #ifdef SD_CHAIN_STAMPS
 extern "C" int sd_debug_read_chain_stamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sd_chain_stamps), sizeof(sd_chain_stamps));
+}
+extern "C" int sd_debug_read_chain_wg_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sd_chain_wg_stamps), sizeof(sd_chain_wg_stamps));
 }
 #endif
