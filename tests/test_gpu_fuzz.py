@@ -229,7 +229,7 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows, t
     while len(done) < n_req:
         steps += 1
         assert steps < 3000
-        new, cached, pieces, finished = [], [], {}, []
+        new, cached, pieces, finished, resumed = [], [], {}, [], set()
         # requests that reached their length finish (wherever they are)
         for r in list(active) + list(parked):
             if len(got[r]) >= n_new:
@@ -257,6 +257,7 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows, t
             if returning and (not waiting or rnd.random() < 0.5):
                 r = returning.pop(rnd.randrange(len(returning)))
                 parked.remove(r)
+                resumed.add(r)       # recomputed from position 0 (resumed_from_preemption)
                 left[r] = len(prompts[r]) + len(got[r])
                 if rows != "wide":
                     exact_until.setdefault(r, len(got[r]))
@@ -284,7 +285,8 @@ def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows, t
         rnd.shuffle(cached)
         if not (new or cached or finished):
             continue
-        so = _sched(new=new, cached=cached, finished=[r for r in finished if r in known])
+        so = _sched(new=new, cached=cached, finished=[r for r in finished if r in known],
+                    resumed=resumed)
         so.num_scheduled_tokens.update(pieces)
         out = w.execute_model(so)
         lp = out.logprobs

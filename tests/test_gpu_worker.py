@@ -365,8 +365,8 @@ def test_v1_chunked_prefill_through_the_worker():
     got = {r: [] for r in prompts}
     N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0})
 
-    def run(new=(), cached=(), pieces=None, finished=()):
-        so = _sched(new=list(new), cached=list(cached), finished=finished)
+    def run(new=(), cached=(), pieces=None, finished=(), resumed=()):
+        so = _sched(new=list(new), cached=list(cached), finished=finished, resumed=resumed)
         so.num_scheduled_tokens.update(pieces or {})
         out = w.execute_model(so)
         for r, toks in zip(out.req_ids, out.sampled_token_ids):
@@ -522,8 +522,8 @@ def test_v1_preempted_requests_are_rebuilt_when_they_return():
     got = {r: [] for r in prompts}
     N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0})
 
-    def run(new=(), cached=(), pieces=None, finished=()):
-        so = _sched(new=list(new), cached=list(cached), finished=finished)
+    def run(new=(), cached=(), pieces=None, finished=(), resumed=()):
+        so = _sched(new=list(new), cached=list(cached), finished=finished, resumed=resumed)
         so.num_scheduled_tokens.update(pieces or {})
         out = w.execute_model(so)
         for r, toks in zip(out.req_ids, out.sampled_token_ids):
@@ -537,10 +537,10 @@ def test_v1_preempted_requests_are_rebuilt_when_they_return():
     run(cached=["c"])                                    # and "a"
     assert w.engine.active == 1 and w._parked == {"a", "b"}
     n_b = len(prompts["b"]) + len(got["b"])
-    o = run(cached=["c", "b"], pieces={"b": n_b})        # "b" returns whole
+    o = run(cached=["c", "b"], pieces={"b": n_b}, resumed={"b"})        # "b" returns whole
     assert len(o["b"]) == 1 and w.engine.active == 2
     n_a = len(prompts["a"]) + len(got["a"])
-    o = run(cached=["c", "b", "a"], pieces={"a": n_a - 3})   # "a" returns in two pieces
+    o = run(cached=["c", "b", "a"], pieces={"a": n_a - 3}, resumed={"a"})   # "a" returns in two pieces
     assert o["a"] == []
     o = run(cached=["c", "b", "a"], pieces={"a": 3})
     assert len(o["a"]) == 1 and w.engine.active == 3 and not w._parked

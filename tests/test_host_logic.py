@@ -393,11 +393,17 @@ class _SchedulerOutput:
     kv_connector_metadata: _Opt[_Any] = None
 
 
-def _sched(new=(), cached=(), finished=(), spec=None, old_layout=False):
+def _sched(new=(), cached=(), finished=(), spec=None, old_layout=False, resumed=(), computed=None):
+    """resumed: cached requests the scheduler recomputes after a preemption
+    (resumed_from_preemption); computed: request -> num_computed_tokens (default 0 for a resumed
+    request, 7 for any other: a running request has computed tokens)."""
     n_tok = {r.req_id: len(r.prompt_token_ids) for r in new}
     n_tok.update({r: 1 for r in cached})
-    c = ([type("C", (), {"req_id": r})() for r in cached] if old_layout
-         else _CachedRequestData(list(cached)))
+    flags = [r in resumed for r in cached]
+    ncomp = [(computed or {}).get(r, 0 if r in resumed else 7) for r in cached]
+    c = ([type("C", (), {"req_id": r, "resumed_from_preemption": f, "num_computed_tokens": n})()
+          for r, f, n in zip(cached, flags, ncomp)] if old_layout
+         else _CachedRequestData(list(cached), resumed_from_preemption=flags, num_computed_tokens=ncomp))
     return _SchedulerOutput(list(new), c, n_tok, sum(n_tok.values()),
                             scheduled_spec_decode_tokens=spec or {}, finished_req_ids=set(finished))
 
@@ -464,6 +470,72 @@ def test_worker_accepts_the_v1_scheduler_output():
     req = request_from_scheduler_output(_sched(new=[_NewRequestData("z", [1, 2], sampling_params=ok)]))
     sp = req.seq_group_metadata_list[0].sampling_params
     assert (sp.top_k, sp.top_p, sp.min_p) == (40, 0.9, 0.0)
+
+
+class _PieceEngine(FakeEngine):
+    """FakeEngine with piecewise prefill: the last piece admits the sequence."""
+
+    def prefill_begin(self, prompt):
+        self._pending = getattr(self, "_pending", {})
+        h = len(self._pending) + 1
+        self._pending[h] = [list(prompt), 0]
+        return h
+
+    def prefill_advance(self, h, n):
+        p = self._pending[h]
+        p[1] += n
+        assert p[1] <= len(p[0])
+        if p[1] < len(p[0]):
+            return None
+        del self._pending[h]
+        return self.add_request(self.active, p[0])
+
+    def prefill_abort(self, h):
+        del self._pending[h]
+
+
+@pytest.mark.parametrize("old_layout", [False, True])
+def test_a_skipped_request_returns_whole_and_a_preempted_one_in_pieces(old_layout):
+    """A V1 scheduler may leave a running request out of one step without preempting it (token
+    budget): it comes back with num_scheduled_tokens = 1 + speculative tokens, resumed_from_preemption
+    False and its computed tokens counted.  The worker dropped its slot, so it rebuilds the
+    request WHOLE in that step and emits a token (a piecewise rebuild in pieces of 1 would emit
+    nothing for many steps while the scheduler counts decode steps).  A request the scheduler
+    really recomputes (resumed_from_preemption True, num_computed_tokens 0) is rebuilt in the
+    pieces the scheduler names; prefix-cache hits on resume are refused before anything runs."""
+    from vllm_omni_draft_amd.spec_decode_worker import SpecDecodeWorker
+    eng = _PieceEngine()
+    w = SpecDecodeWorker(vllm_config=None, engine=eng)
+    N = lambda rid, tok: _NewRequestData(rid, [tok, 1, 2, 3], sampling_params=None)
+    S = lambda **kw: _sched(old_layout=old_layout, **kw)
+    w.execute_model(S(new=[N("a", 1), N("b", 2)]))
+    w.execute_model(S(cached=["a", "b"]))
+    w.execute_model(S(cached=["a"]))                       # "b" left out
+    assert "b" in w._parked and eng.owners == [1]
+    n_b = len(w._tokens["b"])
+    so = S(cached=["a", "b"])                              # back, as a decode step: 1 + 3 tokens
+    so.num_scheduled_tokens["b"] = 4
+    out = w.execute_model(so)
+    assert not w._parked and not w._prefill_of and eng.owners == [1, 2]
+    assert eng.prompts[-1] == w._tokens["b"][:n_b]         # rebuilt whole from prompt + emitted
+    assert len(out.sampled_token_ids[1]) == 1              # and it emitted in that step
+    # a real preemption: recomputed from position 0 in the scheduler's pieces
+    w.execute_model(S(cached=["a"]))
+    n_b = len(w._tokens["b"])
+    so = S(cached=["a", "b"], resumed={"b"})
+    so.num_scheduled_tokens["b"] = 3
+    out = w.execute_model(so)
+    assert out.sampled_token_ids[1] == [] and w._prefill_left["b"] == n_b - 3
+    so = S(cached=["a", "b"])
+    so.num_scheduled_tokens["b"] = n_b - 3
+    out = w.execute_model(so)
+    assert len(out.sampled_token_ids[1]) == 1 and not w._prefill_of and eng.owners == [1, 2]
+    # resumed with prefix-cache hits: refused, nothing ran, the request stays parked
+    w.execute_model(S(cached=["a"]))
+    steps = eng.steps
+    with pytest.raises(ValueError, match="prefix-cached"):
+        w.execute_model(S(cached=["a", "b"], resumed={"b"}, computed={"b": 16}))
+    assert eng.steps == steps and "b" in w._parked and eng.owners == [1]
 
 
 def test_a_refused_step_loses_no_tokens():

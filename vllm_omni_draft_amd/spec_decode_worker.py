@@ -84,6 +84,12 @@ class SequenceGroupMetadata:
     # this step).  A prompt that is not finished emits nothing; it is continued by naming the
     # request again (is_prompt False) with the next piece's size.
     num_prompt_tokens: Optional[int] = None
+    # A running request as a V1 scheduler describes it (CachedRequestData): whether it returns
+    # from a preemption (its cache was dropped, the scheduler recomputes it) and how many of its
+    # tokens the scheduler counts as computed.  None: not a V1 step (num_prompt_tokens, if set,
+    # is then the caller's own piece size).
+    resumed_from_preemption: Optional[bool] = None
+    num_computed_tokens: Optional[int] = None
 
 
 @dataclass
@@ -177,16 +183,29 @@ def request_from_scheduler_output(so) -> "ExecuteModelRequest":
         raise ValueError("KV-cache connectors (transfers to or from another worker) are not supported")
     new = list(_get(so, "scheduled_new_reqs", None) or [])
     cached = _get(so, "scheduled_cached_reqs", None)
+    # per running request: resumed_from_preemption and num_computed_tokens (upstream's
+    # CachedRequestData carries them as parallel lists; the older layout as fields per request)
     if cached is None:
         cached_ids: List[str] = []
+        flags: List[bool] = []
+        computed: List[Optional[int]] = []
     elif _get(cached, "req_ids", None) is not None:
         cached_ids = list(_get(cached, "req_ids"))
+        fl = list(_get(cached, "resumed_from_preemption", None) or [])
+        nc = list(_get(cached, "num_computed_tokens", None) or [])
+        flags = [bool(fl[i]) if i < len(fl) else False for i in range(len(cached_ids))]
+        computed = [int(nc[i]) if i < len(nc) else None for i in range(len(cached_ids))]
     else:
         cached_ids = [_get(c, "req_id") for c in cached]
+        flags = [bool(_get(c, "resumed_from_preemption", False)) for c in cached]
+        computed = [_get(c, "num_computed_tokens", None) for c in cached]
     n_tok = _get(so, "num_scheduled_tokens", None) or {}
     # (for a running request the count is 1 + its speculative tokens and means nothing here; for
-    # a prompt still being prefilled it is the next piece, which the worker picks up)
-    metas = [SequenceGroupMetadata(rid, False, num_prompt_tokens=n_tok.get(rid)) for rid in cached_ids]
+    # a prompt still being prefilled, or a request recomputed after a preemption, it is the next
+    # piece, which the worker picks up)
+    metas = [SequenceGroupMetadata(rid, False, num_prompt_tokens=n_tok.get(rid),
+                                   resumed_from_preemption=flags[i], num_computed_tokens=computed[i])
+             for i, rid in enumerate(cached_ids)]
     for r in new:
         rid = _get(r, "req_id")
         prompt = list(_get(r, "prompt_token_ids", None) or [])
@@ -292,45 +311,35 @@ class Top1Proposer(SpeculativeProposer):
             proposal_lens=lens, no_proposals=(B == 0))
 
 
-class NGramProposer(SpeculativeProposer):
+class HostProposer(SpeculativeProposer):
+    """Proposals the engine holds before the step starts, made on the host: it uploaded them in
+    prepare_step; this hands out the views.  Sequences without a proposal (proposal_lens 0) get
+    one token from the target as in plain decoding."""
+
+    def __init__(self, engine: SpecEngine):
+        self.engine = engine
+
+    def get_spec_proposals(self, execute_model_req=None,
+                           seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
+        eng = self.engine
+        B = eng.active
+        with _rt.stream_ctx(eng.stream):
+            eng._enqueue_lookup_proposals()
+        return SpeculativeProposals(
+            proposal_token_ids=eng.draft_ids[:B],
+            proposal_probs=eng.d_probs[:B] if eng.sampling else None,
+            proposal_lens=eng.prop_lens[:B], no_proposals=(B == 0))
+
+
+class NGramProposer(HostProposer):
     """Prompt-lookup proposals: no draft model; the continuation of the most recent earlier
-    occurrence of a sequence's last n tokens (upstream's NGramWorker role).  The engine
-    computes them on the host in prepare_step; sequences without a match propose nothing
-    (proposal_lens 0) and get one token from the target as in plain decoding."""
-
-    def __init__(self, engine: SpecEngine):
-        self.engine = engine
-
-    def get_spec_proposals(self, execute_model_req=None,
-                           seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
-        eng = self.engine
-        B = eng.active
-        with _rt.stream_ctx(eng.stream):
-            eng._enqueue_lookup_proposals()
-        return SpeculativeProposals(
-            proposal_token_ids=eng.draft_ids[:B],
-            proposal_probs=eng.d_probs[:B] if eng.sampling else None,
-            proposal_lens=eng.prop_lens[:B], no_proposals=(B == 0))
+    occurrence of a sequence's last n tokens (upstream's NGramWorker role), found by the engine
+    on the host in prepare_step."""
 
 
-class ExternalProposer(SpeculativeProposer):
+class ExternalProposer(HostProposer):
     """Proposals that arrive with the step (ExecuteModelRequest.external_proposals, or a V1
-    scheduler output's scheduled_spec_decode_tokens): the engine uploaded them in
-    prepare_step; this hands out the views, like NGramProposer."""
-
-    def __init__(self, engine: SpecEngine):
-        self.engine = engine
-
-    def get_spec_proposals(self, execute_model_req=None,
-                           seq_ids_with_bonus_token_in_last_step=frozenset()) -> SpeculativeProposals:
-        eng = self.engine
-        B = eng.active
-        with _rt.stream_ctx(eng.stream):
-            eng._enqueue_lookup_proposals()
-        return SpeculativeProposals(
-            proposal_token_ids=eng.draft_ids[:B],
-            proposal_probs=eng.d_probs[:B] if eng.sampling else None,
-            proposal_lens=eng.prop_lens[:B], no_proposals=(B == 0))
+    scheduler output's scheduled_spec_decode_tokens)."""
 
 
 class MQAScorer(SpeculativeScorer):
@@ -534,6 +543,24 @@ class SpecDecodeConfig:
     draft_vocab_subset: Optional[Sequence[int]] = None
 
 
+@dataclass
+class _StepPlan:
+    """What one execute_model call does with each of its requests (made and validated by
+    SpecDecodeWorker._plan_step before anything runs)."""
+    req: ExecuteModelRequest
+    metas: List[SequenceGroupMetadata]          # the step's requests, returning ones rebuilt as prompts
+    running: List[SequenceGroupMetadata]        # get a speculative step
+    continued: List[SequenceGroupMetadata]      # next piece of a prompt that is being prefilled
+    pieces: List[SequenceGroupMetadata]         # first piece of a prompt
+    prompts: List[SequenceGroupMetadata]        # whole prompts
+    finished: List[str]                         # running requests that end
+    dropped: List[str]                          # half-prefilled requests that end
+    parked_now: List[str]                       # running requests the step left out
+    resumed: Set[str]                           # parked requests named again
+    mm_inputs: Dict[str, dict]
+    asked: List[int] = field(default_factory=list)   # logprobs counts asked for by the step's requests
+
+
 class SpecDecodeWorker:
     """Worker that runs draft-k / verify / accept for every running sequence.
 
@@ -694,36 +721,62 @@ class SpecDecodeWorker:
         or the V0-shaped ExecuteModelRequest of this module.  delay_capture is accepted for
         signature compatibility: step graphs are captured on first use of a batch shape anyway.
 
-        Every request of the step is checked before anything runs: a refused step leaves the
-        running sequences where they were (no token is produced and then dropped)."""
+        Every request of the step is checked before anything runs (_plan_step): a refused step
+        leaves the running sequences where they were (no token is produced and then dropped)."""
         req = scheduler_output
         if not isinstance(req, ExecuteModelRequest):
             if _get(req, "scheduled_new_reqs", None) is None and _get(req, "scheduled_cached_reqs", None) is None:
                 raise TypeError("execute_model takes a SchedulerOutput (scheduled_new_reqs / "
                                 "scheduled_cached_reqs / finished_req_ids) or an ExecuteModelRequest")
             req = request_from_scheduler_output(req)
+        plan = self._plan_step(req)
+        self._retire(plan)
+        out: Dict[str, List[int]] = {}
+        lp: Dict[str, List[tuple]] = {}
+        self._step_running(plan, out, lp)
+        self._admit_prompts(plan, out, lp)
+        self._admit_pieces(plan, out, lp)
+        return self._collect(plan, out, lp)
+
+    def _rebuilt(self, g: SequenceGroupMetadata) -> SequenceGroupMetadata:
+        """The prompt-shaped request that rebuilds a parked sequence named again by the step:
+        prompt + emitted tokens, prefilled whole (it then emits a token in this step) or, when
+        the scheduler recomputes it from position 0 in pieces, in those pieces."""
+        rid = g.request_id
+        first, toks = self._request[rid], self._tokens[rid]
+        piece = g.num_prompt_tokens
+        if g.resumed_from_preemption is None:
+            pass                                 # not a V1 step: the caller's own piece size
+        elif g.resumed_from_preemption:
+            if g.num_computed_tokens:
+                raise ValueError(f"request {rid} resumes with {g.num_computed_tokens} prefix-cached "
+                                 "tokens: not supported (this worker recomputes a resumed request "
+                                 "from its first token)")
+        else:
+            # The scheduler only left the request out of a step (token budget): its count is
+            # 1 + speculative tokens, not a piece of a recomputation.
+            piece = None
+        sp = first.sampling_params
+        if sp.seed is not None:      # a stream of its own for every incarnation
+            sp = SamplingParams(**{**vars(sp), "seed": (sp.seed + 0x9E3779B1 * self._park_count[rid])
+                                   & 0x7FFFFFFFFFFFFFFF})
+        return SequenceGroupMetadata(
+            rid, True, list(toks), sp, multi_modal_data=first.multi_modal_data,
+            num_prompt_tokens=piece if piece is not None and 1 <= piece < len(toks) else None)
+
+    def _plan_step(self, req: ExecuteModelRequest) -> "_StepPlan":
+        """Sorts the step's requests into what happens to them and validates all of it; nothing
+        runs here."""
         eng = self.engine
         metas = req.seq_group_metadata_list
         # A running request that the step does not name (and does not finish) is parked: its
         # slot is freed, its tokens are kept.  When it is named again it is rebuilt from them
-        # (prompt and emitted tokens prefilled anew, whole or in the pieces the step schedules)
         # and goes on where it stopped: a V1 scheduler preempts and resumes requests this way.
         named = {g.request_id for g in metas}
         parked_now = [r for r in self._req_at if r not in named and r not in req.finished_requests_ids]
         resumed = {g.request_id for g in metas if not g.is_prompt and g.request_id in self._parked}
         if resumed:
-            metas = list(metas)
-            for i, g in enumerate(metas):
-                if g.request_id in resumed:
-                    first, toks = self._request[g.request_id], self._tokens[g.request_id]
-                    piece = g.num_prompt_tokens
-                    sp = first.sampling_params
-                    if sp.seed is not None:      # a stream of its own for every incarnation
-                        sp = SamplingParams(**{**vars(sp), "seed": (sp.seed + 0x9E3779B1 * self._park_count[g.request_id])
-                                               & 0x7FFFFFFFFFFFFFFF})
-                    metas[i] = SequenceGroupMetadata(
-                        g.request_id, True, list(toks), sp, multi_modal_data=first.multi_modal_data,
-                        num_prompt_tokens=piece if piece is not None and 1 <= piece < len(toks) else None)
+            metas = [self._rebuilt(g) if g.request_id in resumed else g for g in metas]
         # prompts that arrive in pieces (chunked prefill): first pieces and continuations
         continued = [g for g in metas if not g.is_prompt and g.request_id in self._prefill_of]
         running = [g for g in metas if not g.is_prompt and g.request_id not in self._prefill_of]
@@ -733,7 +786,6 @@ class SpecDecodeWorker:
         finished = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._slot_of]
         dropped = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._prefill_of]
 
-        # ---- validation (nothing has run yet)
         have = getattr(getattr(eng, "cfg", None), "temperature", None)
         max_len = getattr(getattr(eng, "cfg", None), "max_seq_len", None)
         seen = set()
@@ -802,52 +854,62 @@ class SpecDecodeWorker:
         n_prefilling = len(self._prefill_of) - len(dropped)
         if n_after + n_prefilling + len(prompts) + len(pieces) > eng.cfg.max_batch:
             raise RuntimeError("no free sequence slot (max_num_seqs reached)")
-        ext = req.external_proposals
-        if ext is not None and not getattr(eng, "external", False):
+        if req.external_proposals is not None and not getattr(eng, "external", False):
             raise ValueError("the step carries proposals (external_proposals / "
                              "scheduled_spec_decode_tokens) but this worker makes its own")
         # multimodal inputs (vision tower included) are prepared before the step as well
         mm_inputs = {g.request_id: self._multimodal_inputs(g) for g in prompts}
+        return _StepPlan(req, metas, running, continued, pieces, prompts, finished, dropped,
+                         parked_now, resumed, mm_inputs)
 
-        # ---- the step
-        for rid in dict.fromkeys(req.finished_requests_ids):
+    def _retire(self, plan: "_StepPlan") -> None:
+        """Requests that leave: finished ones (running, parked or half prefilled) and the
+        running ones the step left out."""
+        eng = self.engine
+        for rid in dict.fromkeys(plan.req.finished_requests_ids):
             if rid in self._parked:          # finished while parked: nothing left but its log
                 self._forget(rid)
-        for rid in finished:
+        for rid in plan.finished:
             self._finish(rid)
-        for rid in parked_now:
+        for rid in plan.parked_now:
             self._park(rid)
-        self._parked -= resumed
-        for rid in dropped:
+        self._parked -= plan.resumed
+        for rid in plan.dropped:
             eng.prefill_abort(self._prefill_of.pop(rid))
             self._prefill_left.pop(rid, None)
             self._forget(rid)
-        out: Dict[str, List[int]] = {}
         # log-probabilities: computed for the whole step as soon as one of its requests asks
-        for g in prompts + pieces:
+        for g in plan.prompts + plan.pieces:
             if g.sampling_params.logprobs is not None:
                 self._logprobs_of[g.request_id] = int(g.sampling_params.logprobs)
-        asked = [self._logprobs_of[g.request_id] for g in metas if g.request_id in self._logprobs_of]
-        lp: Dict[str, List[tuple]] = {}
+        plan.asked = [self._logprobs_of[g.request_id] for g in plan.metas if g.request_id in self._logprobs_of]
         if hasattr(eng, "logprobs_top"):
-            eng.logprobs_top = max(asked) if asked else None
-        if running:
-            if ext is not None:
-                eng.set_external_proposals([ext.get(r, []) for r in self._req_at])
-            emitted = self._run_speculative_decoding_step(req)
-            for slot, toks in enumerate(emitted):
-                out[self._req_at[slot]] = toks
-                if asked:
-                    lp[self._req_at[slot]] = eng.last_logprobs[slot]
-        # text prompts that arrive together are prefilled in the same passes (one
-        # synchronisation for the group); a prompt with images goes alone
+            eng.logprobs_top = max(plan.asked) if plan.asked else None
+
+    def _step_running(self, plan: "_StepPlan", out, lp) -> None:
+        eng = self.engine
+        if not plan.running:
+            return
+        ext = plan.req.external_proposals
+        if ext is not None:
+            eng.set_external_proposals([ext.get(r, []) for r in self._req_at])
+        emitted = self._run_speculative_decoding_step(plan.req)
+        for slot, toks in enumerate(emitted):
+            out[self._req_at[slot]] = toks
+            if plan.asked:
+                lp[self._req_at[slot]] = eng.last_logprobs[slot]
+
+    def _admit_prompts(self, plan: "_StepPlan", out, lp) -> None:
+        """Whole prompts: text prompts that arrive together are prefilled in the same passes
+        (one synchronisation for the group); a prompt with images goes alone."""
+        eng, prompts, mm_inputs = self.engine, plan.prompts, plan.mm_inputs
+        seeded = bool(getattr(eng, "sampling", False))    # greedy engines have no use for seeds
         i = 0
         while i < len(prompts):
             j = i
             while (j < len(prompts) and not mm_inputs[prompts[j].request_id]
                    and hasattr(eng, "add_requests")):
                 j += 1
-            seeded = bool(getattr(eng, "sampling", False))    # greedy engines have no use for seeds
             if j - i >= 2:
                 group = prompts[i:j]
                 kw = dict(seeds=[g.sampling_params.seed for g in group],
@@ -870,13 +932,16 @@ class SpecDecodeWorker:
                 self._slot_of[g.request_id] = len(self._req_at)
                 self._req_at.append(g.request_id)
                 out[g.request_id] = [first]
-                if asked:
+                if plan.asked:
                     lp[g.request_id] = eng.last_logprobs[n]
             i += len(group)
-        # prompts in pieces: a piece emits nothing; the last one admits the sequence and emits
-        # its first token
+
+    def _admit_pieces(self, plan: "_StepPlan", out, lp) -> None:
+        """Prompts in pieces: a piece emits nothing; the last one admits the sequence and emits
+        its first token."""
+        eng = self.engine
         seeded = bool(getattr(eng, "sampling", False))
-        for g in pieces:
+        for g in plan.pieces:
             sp = g.sampling_params
             kw = dict(seed=sp.seed, temperature=sp.temperature, top_k=sp.top_k, top_p=sp.top_p,
                       min_p=sp.min_p) if seeded else {}
@@ -884,7 +949,7 @@ class SpecDecodeWorker:
                 kw["bias"] = _bias_of(sp)
             self._prefill_of[g.request_id] = eng.prefill_begin(g.prompt_token_ids, **kw)
             self._prefill_left[g.request_id] = len(g.prompt_token_ids)
-        for g in pieces + continued:
+        for g in plan.pieces + plan.continued:
             first = eng.prefill_advance(self._prefill_of[g.request_id], g.num_prompt_tokens)
             self._prefill_left[g.request_id] -= g.num_prompt_tokens
             out[g.request_id] = []
@@ -893,10 +958,13 @@ class SpecDecodeWorker:
                 self._slot_of[g.request_id] = len(self._req_at)
                 self._req_at.append(g.request_id)
                 out[g.request_id] = [first]
-                if asked:
+                if plan.asked:
                     lp[g.request_id] = eng.last_logprobs[0]
-        ids = [g.request_id for g in metas]
-        for g in prompts + pieces:
+
+    def _collect(self, plan: "_StepPlan", out, lp) -> ModelRunnerOutput:
+        """The step's ModelRunnerOutput; every request's token log grows by what it emitted."""
+        ids = [g.request_id for g in plan.metas]
+        for g in plan.prompts + plan.pieces:
             if g.request_id not in self._tokens:
                 self._request[g.request_id] = g
                 self._tokens[g.request_id] = list(g.prompt_token_ids)
@@ -904,7 +972,7 @@ class SpecDecodeWorker:
             if r in self._tokens:
                 self._tokens[r].extend(out[r])
         logprobs = None
-        if asked:
+        if plan.asked:
             rows = [e for r in ids for e in lp.get(r, [])]
             cu = [0]
             for r in ids:
