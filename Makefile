@@ -19,7 +19,7 @@ CXX ?= g++
 all: $(LIB) $(CPU_LIB)
 
 $(CPU_LIB): vllm_omni_draft_amd/csrc_cpu/sd_cpu.cpp include/sd_amd.h
-	$(CXX) -O3 -std=c++17 -fPIC -shared -fopenmp -mavx2 -mfma -Wall -o $@ $<
+	$(CXX) -O3 -std=c++17 -fPIC -shared -fopenmp -mavx2 -mfma -ffp-contract=off -Wall -o $@ $<
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
 	$(HIPCC) $(FLAGS) -c $< -o $@

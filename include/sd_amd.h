@@ -348,7 +348,10 @@ int sd_tree_accept_greedy(const int64_t* target_ids, const int32_t* tree_tok,
  * At the current node, with r = its row: the children are tried in row order;
  * child x stands iff u_accept[b, row of x] * (1 - removed) < r(x) in f64, where
  * removed is the mass of the children rejected so far at this node; a rejected
- * child's token leaves r.  With no child standing, or k accepted, the emitted
+ * child's token leaves r (a later sibling that carries the same token is skipped:
+ * nothing of it is left).  A row's parent must be a smaller row (as
+ * sd_tree_prepare's callers build them); tokens outside 0..V-1 are skipped.
+ * With no child standing, or k accepted, the emitted
  * token is the inverse-CDF draw (u_final[b], f64 running sum as in
  * sd_rejection_sample) from r without the rejected tokens.  Outputs and counters
  * as sd_tree_accept_greedy.  u_accept [B, q_len], u_final [B] f32 in [0, 1).    */

@@ -133,6 +133,8 @@ def accept_sample(probs, tokens: Sequence[int], parents: Sequence[int], length: 
                 if parents[c] != cur:
                     continue
                 x = int(tokens[c])
+                if x in excl:       # a rejected sibling carried this token: its mass is gone
+                    continue
                 px = np.float64(p[cur, x])
                 if np.float64(np.float32(u_accept[c])) * (np.float64(1.0) - removed) < px:
                     nxt = c

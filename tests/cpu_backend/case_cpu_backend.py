@@ -231,6 +231,8 @@ def test_tree_sampling_walk_matches_the_oracle():
         pool = rng.integers(0, V, 4)
         cands = [[int(t) for t in rng.choice(pool, rng.integers(1, k + 2))] for _ in range(rng.integers(0, 4))]
         t, p, _ = otree.build_tree(cands, k, N)
+        if b == 3:      # a tree made elsewhere with the same token on two siblings (rows 1 and 2)
+            t, p = [0, 7, 7, 8], [0, 0, 0, 0]
         trees.append((t, p))
         n = len(t)
         tok[b, :n], par[b, :n], lens[b] = torch.tensor(t), torch.tensor(p), n
@@ -239,6 +241,11 @@ def test_tree_sampling_walk_matches_the_oracle():
                 probs[b, p[r], t[r]] += rng.choice([0.5, 2.0, 10.0])
     probs = (probs / probs.sum(axis=2, keepdims=True, dtype=np.float64)).astype(np.float32)
     ua, uf = rng.random((B, q), dtype=np.float32), rng.random(B, dtype=np.float32)
+    # the duplicate sibling: token 7 is rejected at row 1; row 2 carries it again and must be
+    # skipped whatever its uniform (its mass is gone); row 3 holds all that is left and stands
+    probs[3, 0] = 0.0
+    probs[3, 0, 7], probs[3, 0, 8] = 0.4, 0.6
+    ua[3, 1], ua[3, 2], ua[3, 3] = 0.9, 0.0, 0.99
     out = torch.full((B, k + 1), -7, dtype=torch.int64)
     path = torch.full((B, k), -7, dtype=torch.int32)
     npath = torch.zeros(B, dtype=torch.int32)
@@ -252,6 +259,7 @@ def test_tree_sampling_walk_matches_the_oracle():
         assert out[b].tolist() == want_out + [-1] * (k + 1 - len(want_out)), b
         assert path[b].tolist() == want_path + [-1] * (k - len(want_path)), b
         acc += len(want_path)
+    assert path[3].tolist()[0] == 3 and out[3].tolist()[0] == 8
     assert counters[0].item() == acc and acc > 0
     oc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64, ffn=128,
                       vocab=32, max_pos=200)

@@ -280,3 +280,39 @@ def test_logit_masks_under_sampling_and_through_the_worker():
         for r, t in zip(out.req_ids, out.sampled_token_ids):
             toks[r].extend(t)
     assert all(t % 2 == 1 and t not in (13, 15) for t in toks["a"]) and toks["a"] != toks["b"]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_logprobs_of_masked_requests_are_those_of_the_raw_logits(use_graph):
+    """A request with a logit mask that asks for log-probabilities gets those of the target's RAW
+    logits (upstream's sampler takes them before the logit processors run): the top entry is the
+    raw arg-max, which the whitelist may forbid, and the emitted token's rank counts tokens the
+    mask removed.  The speculative stream reports what the autoregressive stream reports."""
+    tw, dw = _pair()
+    V = MODELS["llama"].vocab
+    allowed = list(range(0, V, 3))
+    prompt = [5, 9, 200, 31, 7]
+
+    def run(draft, k):
+        eng = _engine(tw, draft, k, use_graph=use_graph)
+        eng.logprobs_top = 1
+        toks = [eng.add_request(0, prompt, bias={"allowed_token_ids": allowed})]
+        raw = torch.log_softmax(eng.t_raw[0].double(), -1)
+        ids, lps, rank = eng.last_logprobs[0][0]
+        assert ids[0] == toks[0] and toks[0] % 3 == 0
+        assert abs(lps[0] - raw[toks[0]].item()) < 1e-4
+        assert ids[1] == int(raw.argmax()) and abs(lps[1] - raw.max().item()) < 1e-4
+        assert rank == int((raw > raw[toks[0]]).sum()) + 1
+        entries = [eng.last_logprobs[0][0]]
+        while len(toks) < 24:
+            new = eng.step()[0]
+            toks += new
+            entries += eng.last_logprobs[0]
+        return toks[:24], entries[:24]
+
+    ar_toks, ar_entries = run(None, 0)
+    sp_toks, sp_entries = run(dw, 3)
+    assert all(t % 3 == 0 for t in ar_toks) and sp_toks == ar_toks
+    assert any(e[2] > 1 for e in ar_entries)         # the mask did overrule the raw arg-max somewhere
+    for a, b in zip(ar_entries, sp_entries):
+        assert a[0] == b[0] and a[2] == b[2] and a[1] == b[1]

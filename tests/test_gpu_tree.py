@@ -345,6 +345,8 @@ def test_sampling_walk_matches_oracle(V):
         if b == 1:
             cands = [[1, 2, 3, 4], [1, 2, 5, 5], [9, 9]]
         t, p, _ = otree.build_tree(cands, k, N)
+        if b == 3:      # a tree made elsewhere with the same token on two siblings (rows 1 and 2)
+            t, p = [0, 7, 7, 8], [0, 0, 0, 0]
         trees.append((t, p))
         n = len(t)
         tok[b, :n], par[b, :n], lens[b] = torch.tensor(t), torch.tensor(p), n
@@ -364,6 +366,11 @@ def test_sampling_walk_matches_oracle(V):
     probs = (probs / probs.sum(axis=2, keepdims=True, dtype=np.float64)).astype(np.float32)
     ua = rng.random((B, q), dtype=np.float32)
     uf = rng.random(B, dtype=np.float32)
+    # the duplicate sibling: token 7 is rejected at row 1; row 2 carries it again and must be
+    # skipped whatever its uniform (its mass is gone); row 3 holds all that is left and stands
+    probs[3, 0] = 0.0
+    probs[3, 0, 7], probs[3, 0, 8] = 0.4, 0.6
+    ua[3, 1], ua[3, 2], ua[3, 3] = 0.9, 0.0, 0.99
     out = torch.full((B, k + 1), -7, dtype=torch.int64).cuda()
     path = torch.full((B, k), -7, dtype=torch.int32).cuda()
     npath = torch.zeros(B, dtype=torch.int32).cuda()
@@ -386,6 +393,7 @@ def test_sampling_walk_matches_oracle(V):
         depth += min(max(d), k)
     assert counters.tolist() == [acc, emit, depth]
     assert out[1].tolist()[:4] == [1, 2, 3, 4] and npath[1].item() == 4
+    assert path[3].tolist()[0] == 3 and out[3].tolist()[0] == 8      # the duplicate sibling was skipped
     assert acc >= 6                      # walks did descend beyond the forced chain
 
 

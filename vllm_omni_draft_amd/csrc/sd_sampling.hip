@@ -395,6 +395,11 @@ __global__ __launch_bounds__(kSampleThreads) void tree_accept_sample_kernel(
         if (par[c] != cur) continue;
         const int x = tok[c];
         if (x < 0 || x >= V) continue;
+        // a sibling that carries a token an earlier (rejected) sibling carried has nothing left
+        // to stand on: that token's mass left r already
+        bool dup = false;
+        for (int e = 1; e < c; ++e) dup |= par[e] == cur && tok[e] == x;
+        if (dup) continue;
         const double px = (double)row[x];
         if ((double)ua[c] * (1.0 - removed) < px) {
           next = c;
@@ -423,7 +428,8 @@ __global__ __launch_bounds__(kSampleThreads) void tree_accept_sample_kernel(
     int max_depth = 0;
     for (int c = 1; c < len; ++c) {
       int d = 0;
-      for (int a = c; a > 0 && d <= q_len; a = par[a]) ++d;
+      // (a parent is a smaller row; anything else ends the walk)
+      for (int a = c; a > 0 && d <= q_len; a = (par[a] >= 0 && par[a] < a) ? par[a] : 0) ++d;
       max_depth = max(max_depth, d);
     }
     if (counters) {

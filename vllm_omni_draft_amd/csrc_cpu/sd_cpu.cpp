@@ -808,6 +808,9 @@ extern "C" int sd_tree_accept_sample(const float* probs, int64_t ld, const int32
           if (par[c] != cur) continue;
           const int x = tok[c];
           if (x < 0 || x >= V) continue;
+          bool dup = false;   // a rejected sibling carried this token: its mass is gone
+          for (int e = 0; e < n_excl; ++e) dup |= excl[e] == x;
+          if (dup) continue;
           const double px = (double)row[x];
           if ((double)ua[c] * (1.0 - removed) < px) {
             next = c;

@@ -262,6 +262,7 @@ class SpecEngine:
         # slice of the logits in t_out; greedy steps exchange slice maxima (2 x 256 bytes per
         # row and rank), sampling steps gather whole rows into t_logits.
         self.tp = tp_group
+        self._tp_timeouts_seen = 0
         self.vp = tp_group is not None and target.cfg.lm_vocab > 0
         self.t_out = self.t_logits
         if self.vp:
@@ -338,6 +339,7 @@ class SpecEngine:
         # batch slot, allocated when the first such request arrives; the device flags tell the
         # kernel which sequences carry one (the rest are skipped)
         self.bias: Optional[torch.Tensor] = None
+        self.t_raw: Optional[torch.Tensor] = None     # unmasked copy of a pass's logits, for logprobs
         self.bias_on = torch.zeros(B, dtype=torch.int32, device=dev)
         self._bias_host: List[bool] = [False] * B
         # Log-probabilities of the emitted tokens (ModelRunnerOutput.logprobs): off (None) unless
@@ -488,6 +490,12 @@ class SpecEngine:
         vocabulary slice."""
         if self.bias is None:
             return
+        if self.logprobs_top is not None:
+            # log-probabilities are those of the raw logits (upstream computes them before the
+            # logit processors run): keep the rows as the pass left them
+            if self.t_raw is None:
+                self.t_raw = torch.empty_like(self.t_out)
+            self.t_raw[:n_rows].copy_(self.t_out[:n_rows])
         bias = self.bias[slot0:]
         if self.vp:
             Vl = self.target.cfg.lm_vocab
@@ -680,6 +688,7 @@ class SpecEngine:
         else:
             first = self._target_argmax(1, torch.empty(1, dtype=torch.int64, device=self.device))
         first_tok = int(first.item())
+        self._check_exchanges()
         self.tok_buf[slot, 0] = int(prompt[-1])
         self.tok_buf[slot, 1] = first_tok
         self.seq_lens[slot] = n + 1
@@ -811,6 +820,7 @@ class SpecEngine:
         self.gen_tokens[sl, 0] = first32
         self.gen_counts[sl] = 1
         firsts = [int(t) for t in first.tolist()]
+        self._check_exchanges()
         for i, n in enumerate(lens):
             self.host_lens[slot0 + i] = n + 1
             self.host_gen[slot0 + i] = 1
@@ -829,13 +839,16 @@ class SpecEngine:
         if n == 0:
             self.last_logprobs = [[] for _ in rows]
             return
-        if self.vp and not self.sampling:
-            self._target_full_rows(n)     # greedy passes exchanged slice maxima only
+        raw = self.bias is not None and self.t_raw is not None    # rows as they were before the masks
+        if self.vp and (raw or not self.sampling):
+            # (greedy passes exchanged slice maxima only; masked passes gathered masked rows)
+            self._gather_rows(self.t_raw if raw else self.t_out, self.t_logits, n)
+        src = self.t_raw if raw and not self.vp else self.t_logits
         host = torch.full((n,), -1, dtype=torch.int32)
         for rs, ts in zip(rows, toks):
             for r, t in zip(rs, ts):
                 host[r] = int(t)
-        ids, lps, ranks = ops.token_logprobs(self.t_logits[:n], host.to(self.device), int(self.logprobs_top))
+        ids, lps, ranks = ops.token_logprobs(src[:n], host.to(self.device), int(self.logprobs_top))
         ids, lps, ranks = ids.tolist(), lps.tolist(), ranks.tolist()
         self.last_logprobs = [[(ids[r], lps[r], ranks[r]) for r in rs] for rs in rows]
 
@@ -1342,7 +1355,7 @@ class SpecEngine:
         lib = _lib.load()
         if self.cfg.use_graph and _rt.on_gpu():   # (the CPU build has no stream capture)
             key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity,
-                   self.bias is not None)
+                   self.bias is not None, self.bias is not None and self.logprobs_top is not None)
             # (a tree step has one shape too: every sequence's tree is padded to tree_nodes rows)
             g = self._graphs.get(key)
             if g is None:
@@ -1399,9 +1412,29 @@ class SpecEngine:
             prev, self._inflight = self._inflight, None
             return None if prev is None else self._collect(prev, 0)
 
+    def _check_exchanges(self) -> None:
+        """Called after every synchronisation of the step path.  Two in-kernel exchanges bound
+        their waits instead of hanging: the one-shot collectives over peer-mapped memory (a late
+        or dead peer) and the fused two-layer launches (a workgroup that never published).  A
+        wait that gave up leaves unspecified values in the pass, so the tokens read back must
+        not be handed out: raise, dropping them."""
+        tp = self.tp
+        if tp is not None and hasattr(tp, "timeouts"):
+            n = tp.timeouts()
+            if n != self._tp_timeouts_seen:
+                new, self._tp_timeouts_seen = n - self._tp_timeouts_seen, n
+                raise RuntimeError(f"tensor-parallel exchange: {new} wait(s) for a peer rank timed out; "
+                                   "the step's tokens are dropped (the ranks' partial sums were not combined)")
+        for model in (self.target, self.draft):
+            st = getattr(model, "chain_state", None)
+            if st is not None and ops.chain_errors(st):
+                raise RuntimeError("fused layer launches: an exchange wait gave up; the step's tokens "
+                                   "are dropped")
+
     def _collect(self, step, later_steps: int) -> List[List[int]]:
         ev, parity, B = step
         ev.synchronize()
+        self._check_exchanges()
         rec = self._records[parity, :B].tolist()
         self._steps_pending -= 1
         out = []
@@ -1449,6 +1482,7 @@ class SpecEngine:
         if pending == 1:
             # the step's last kernel left its record in pinned host memory
             _rt.sync_current_stream()
+            self._check_exchanges()
             rec = self._records[self._parity, :B].tolist()
             out = []
             for b in range(B):
@@ -1466,6 +1500,7 @@ class SpecEngine:
                                "earlier steps are gone)")
         counts = self.gen_counts[:B].tolist()
         lens = self.seq_lens[:B].tolist()
+        self._check_exchanges()
         out: List[List[int]] = []
         for b in range(B):
             lo, hi = self.host_gen[b], counts[b]
