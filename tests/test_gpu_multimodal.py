@@ -330,3 +330,106 @@ def test_worker_runs_pixel_patches_through_the_vision_tower():
     assert via_pixels == via_rows == ar
     text_only = run(0, None)
     assert text_only != ar          # the image rows and positions reach the model
+
+
+# ---------------------------------------------------------------------------- the named multimodal configuration
+# Qwen2-VL-7B's language model (rotary sections, QKV biases, 7 query heads per KV head) as the
+# target and Qwen2.5-0.5B's shape as the text draft, both with fp8 weights, k = 5; the small pair
+# keeps the oracle fast, the full-width pair (two layers each) has the real layer shapes.
+CONFIG5 = {
+    "small": (VL, OracleConfig(arch="llama", n_layers=2, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64,
+                               ffn=256, vocab=320, norm_eps=1e-6, rope_theta=1e6, max_pos=256,
+                               tie_embeddings=True)),
+    "qwen2-vl-7b+0.5b": (
+        OracleConfig(arch="llama", n_layers=2, hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128,
+                     ffn=18944, vocab=152064, norm_eps=1e-6, rope_theta=1e6, max_pos=512,
+                     mrope_section=(16, 24, 24)),
+        OracleConfig(arch="llama", n_layers=2, hidden=896, n_heads=14, n_kv_heads=2, head_dim=64,
+                     ffn=4864, vocab=152064, norm_eps=1e-6, rope_theta=1e6, max_pos=512,
+                     tie_embeddings=True)),
+}
+
+
+def _product_fp8(oc, state):
+    from vllm_omni_draft_amd import config, weights
+    cfg = config.create_model_config(
+        None, arch=oc.arch, n_layers=oc.n_layers, hidden=oc.hidden, n_heads=oc.n_heads,
+        n_kv_heads=oc.n_kv_heads, head_dim=oc.head_dim, ffn=oc.ffn, vocab=oc.vocab,
+        norm_eps=oc.norm_eps, rope_theta=oc.rope_theta, max_pos=oc.max_pos,
+        tie_embeddings=oc.tie_embeddings, qkv_bias=True, mrope_section=oc.mrope_section)
+    return weights.from_state_dict(cfg, state, "cuda", fp8=True)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("rows", ["narrow", "wide"])
+@pytest.mark.parametrize("pair", list(CONFIG5))
+def test_image_prompts_with_fp8_weights_and_five_proposals(pair, rows):
+    """Everything the image-conditioned configuration combines, in one engine: a target with
+    rotary sections and QKV biases whose prompt carries image rows, fp8 weights on target and
+    draft, a text-only draft of Qwen2.5-0.5B's shape, k = 5, both kernel families.  (1) the fp8
+    target's logits over the image prompt (explicit three-component positions) and the text
+    behind it (cache position + delta) against the oracle run on the dequantised matrices;
+    (2) greedy speculative == greedy autoregressive for a batch of an image prompt and a text
+    prompt, and proposals are accepted and rejected along the way."""
+    from tests.test_gpu_model import _fp8_dequantised
+    from vllm_omni_draft_amd import multimodal
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    tcfg, dcfg = CONFIG5[pair]
+    wide = rows == "wide"
+    tstate = _bf(random_state(tcfg, seed=51, qkv_bias=True))
+    tw = _product_fp8(tcfg, tstate)
+    assert tw.fp8 and tw.cfg.mrope_section
+    ids, grids = _prompt([3, (1, 4, 6), 4, (1, 2, 4), 5])
+    n = len(ids)
+    img = _image_rows(sum(t == IMG for t in ids), tcfg.hidden, 7)
+    embeds, pos = multimodal.prepare_prompt(ids, tw, img.cuda(), grids, image_token_id=IMG)
+    _, delta = multimodal.mrope_positions(ids, IMG, grids)
+    tail = [11, 12, 13, 14, 15, 16]                      # one verify pass of k + 1 rows
+    model = DecoderModel(tw, 128, 128, wide=wide)
+    kv = PagedKVCache(tw.cfg, 16, 1, 128, "cuda")
+    kv.ensure_capacity(0, n + len(tail))
+    tok = torch.tensor(ids + tail, dtype=torch.int32, device="cuda")
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d_dev = torch.tensor([delta], dtype=torch.int32, device="cuda")
+    G = tcfg.n_heads // tcfg.n_kv_heads
+    step = min(8, 64 // G)                               # rows of one pass: q_len * G <= 64
+    outs, c0 = [], 0
+    while c0 < n:
+        q = min(step, n - c0)
+        lg = torch.empty(q, tcfg.vocab, dtype=torch.float32, device="cuda")
+        model.forward(kv, tok, 0, c0, zero, c0, 1, q, lg, 128,
+                      input_embeds=embeds[c0:c0 + q].contiguous(),
+                      rope_pos=pos[:, c0:c0 + q].contiguous().cuda())
+        outs.append(lg)
+        c0 += q
+    lg = torch.empty(len(tail), tcfg.vocab, dtype=torch.float32, device="cuda")
+    model.forward(kv, tok, 0, n, zero, n, 1, len(tail), lg, 128, rope_delta=d_dev)
+    outs.append(lg)
+    torch.cuda.synchronize()
+    got = torch.cat(outs).cpu()
+    lm = OracleLM(tcfg, _fp8_dequantised(tcfg, tstate), bf16_acts=True)
+    cache = lm.new_cache()
+    tail_pos = torch.tensor([[n + delta + j for j in range(len(tail))]] * 3)
+    ref = torch.cat([lm.forward(ids, 0, cache, rope_pos=pos, input_embeds=embeds.float().cpu()),
+                     lm.forward(tail, n, cache, rope_pos=tail_pos)])
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 0.03 * scale, (got - ref).abs().max().item() / scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.8
+    del lm, ref, cache, model, kv
+
+    dw = _product_fp8(dcfg, _bf(random_state(dcfg, seed=52, qkv_bias=True)))
+    assert dw.fp8 and not dw.cfg.mrope_section
+    text = list(range(30, 47))
+    requests = [(ids, embeds, pos), (text, None, None)]
+
+    def engine(draft, k):
+        return SpecEngine(tw, draft, EngineConfig(k=k, max_batch=2, max_seq_len=160, split_tokens=128,
+                                                  rows=rows))
+    ar = _generate(engine(None, 0), requests, 40)
+    eng = engine(dw, 5)
+    assert eng.wide == wide and eng.k == 5
+    assert _generate(eng, requests, 40) == ar
+    m = eng.metrics()
+    assert m["draft"] > 0 and m["draft"] % 5 == 0 and m["emitted"] >= 2 * 39

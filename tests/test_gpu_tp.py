@@ -20,13 +20,14 @@ def _cfg_of(oc, **kw):
         tie_embeddings=oc.tie_embeddings, **kw)
 
 
-class _TwoRankSum:
-    """All-reduce of two virtual ranks that enqueue on one stream from two threads."""
+class _RankSum:
+    """All-reduce / all-gather of n virtual ranks that enqueue on one stream from n threads."""
 
-    def __init__(self):
-        self.barrier = threading.Barrier(2)
-        self.slots = [None, None]
-        self.models = [None, None]
+    def __init__(self, n=2):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+        self.models = [None] * n
         self.error = None
 
     def view(self, rank, ptr, n):
@@ -42,9 +43,12 @@ class _TwoRankSum:
         def fn(ptr, n, stream):
             try:
                 self.slots[rank] = self.view(rank, ptr, n)
-                self.barrier.wait(timeout=60)          # both partial products are enqueued
-                total = self.slots[0] + self.slots[1]  # bf16 sum, as the collective does
-                self.barrier.wait(timeout=60)          # both sums are enqueued before any write
+                self.barrier.wait(timeout=120)         # every partial product is enqueued
+                total = self.slots[0].float()          # f32 sum in rank order, rounded once
+                for q in range(1, self.n):
+                    total = total + self.slots[q].float()
+                total = total.to(torch.bfloat16)
+                self.barrier.wait(timeout=120)         # every sum is enqueued before any write
                 self.slots[rank].copy_(total)
                 return 0
             except Exception as e:  # noqa: BLE001 - reported by the test thread
@@ -53,19 +57,31 @@ class _TwoRankSum:
         return fn
 
     def make_gather(self, rank):
-        """All-gather of the two virtual ranks (same stream, same barrier discipline)."""
+        """All-gather of the virtual ranks (same stream, same barrier discipline)."""
         def fn(send, recv):
             try:
                 self.slots[rank] = send
-                self.barrier.wait(timeout=60)
-                both = torch.cat([self.slots[0].reshape(-1).view(torch.uint8),
-                                  self.slots[1].reshape(-1).view(torch.uint8)])
-                self.barrier.wait(timeout=60)
-                recv.reshape(-1).view(torch.uint8).copy_(both)
+                self.barrier.wait(timeout=120)
+                every = torch.cat([self.slots[q].reshape(-1).view(torch.uint8) for q in range(self.n)])
+                self.barrier.wait(timeout=120)
+                recv.reshape(-1).view(torch.uint8).copy_(every)
             except Exception as e:  # noqa: BLE001
                 self.error = e
                 raise
         return fn
+
+
+_TwoRankSum = _RankSum
+
+
+def _run_ranks(n, worker):
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    torch.cuda.synchronize()
 
 
 @pytest.mark.parametrize("arch", ["llama", "opt"])
@@ -355,3 +371,152 @@ def test_two_rank_engine_with_sharded_draft(draft_vp, temperature):
     assert other == ar and m["draft"] > 0
     with pytest.raises(ValueError):
         SpecEngine(weights.from_state_dict(cfg, state, "cuda"), None, EngineConfig(k=0), draft_tp=True)
+
+
+# ---------------------------------------------------------------------------- the named tensor-parallel configuration
+LLAMA3_70B_2L = OracleConfig(arch="llama", n_layers=2, hidden=8192, n_heads=64, n_kv_heads=8, head_dim=128,
+                             ffn=28672, vocab=128256, rope_theta=500000.0,
+                             rope_scaling={"rope_type": "llama3", "factor": 8.0, "low_freq_factor": 1.0,
+                                           "high_freq_factor": 4.0,
+                                           "original_max_position_embeddings": 8192},
+                             max_pos=512)
+LLAMA3_8B_2L = OracleConfig(arch="llama", n_layers=2, hidden=4096, n_heads=32, n_kv_heads=8, head_dim=128,
+                            ffn=14336, vocab=128256, rope_theta=500000.0,
+                            rope_scaling=LLAMA3_70B_2L.rope_scaling, max_pos=512)
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_at_llama3_70b_width_against_the_oracle():
+    """Llama-3-70B's layer shapes (two layers) sharded over EIGHT virtual ranks as the tensor-
+    parallel configuration shards them: 8 query heads on 1 KV head per rank (the attention
+    kernel's two-tile arm at k + 1 = 5 rows), ffn 28672 / 8, the LM head split into 8 vocabulary
+    slices of 16032 rows, a Llama-3-8B-shaped draft replicated on every rank, k = 4.
+    (1) The ranks' logit slices of a prompt chunk, decode rows and a 5-row verify pass, put side
+    by side, against the oracle's logits of the unsharded model; (2) the distributed arg-max
+    (slice maxima exchanged and combined) equals the arg-max of the whole row; (3) whole engines:
+    the ranks emit the same streams, greedy speculative == greedy autoregressive, proposals
+    are made and partly accepted."""
+    from oracle.models import OracleLM
+    from vllm_omni_draft_amd import ops, parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    N, k = 8, 4
+    oc = LLAMA3_70B_2L
+    state = {n_: v.to(torch.bfloat16) for n_, v in random_state(oc, seed=17).items()}
+    cfg = _cfg_of(oc, rope_scaling=oc.rope_scaling)
+    stream = torch.cuda.Stream()
+    dev = "cuda"
+    shards = []
+    for r in range(N):
+        local, st = weights.shard_state_dict(cfg, state, N, r, vocab_parallel=True)
+        assert (local.n_heads, local.n_kv_heads, local.ffn, local.lm_vocab) == (8, 1, 3584, 16032)
+        shards.append(weights.from_state_dict(local, st, dev))
+
+    # ---- (1) + (2): forward passes of the eight shards
+    toks = torch.randint(0, oc.vocab, (18,), generator=torch.Generator().manual_seed(3)).tolist()
+    tokens = torch.tensor(toks, dtype=torch.int32, device=dev)
+    chunks = [(0, 6), (6, 1), (7, 1), (8, 5), (13, 5)]         # prompt chunk, decode rows, verify passes
+    max_ctx = 64
+    coll = _RankSum(N)
+    ranks = []
+    with torch.cuda.stream(stream):
+        for r in range(N):
+            group = parallel.CallbackAllReduce(r, coll.make(r), world_size=N)
+            m = DecoderModel(shards[r], max_ctx, 128, tp_group=group)
+            kv = PagedKVCache(shards[r].cfg, 8, 1, max_ctx, dev)
+            kv.ensure_capacity(0, max_ctx)
+            coll.models[r] = m
+            ranks.append((m, kv, [torch.empty(q, 16032, dtype=torch.float32, device=dev) for _, q in chunks]))
+    torch.cuda.synchronize()
+    zero = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def forward(r):
+        m, kv, outs = ranks[r]
+        with torch.cuda.stream(stream):
+            for (c0, q), lg in zip(chunks, outs):
+                m.forward(kv, tokens, 0, c0, zero, c0, 1, q, lg, max_ctx)
+
+    _run_ranks(N, forward)
+    assert coll.error is None, coll.error
+    got = torch.cat([torch.cat([ranks[r][2][i] for r in range(N)], dim=1) for i in range(len(chunks))]).cpu()
+    lm = OracleLM(oc, {n_: v.float() for n_, v in state.items()}, bf16_acts=True)
+    ref = lm.forward(toks, 0, lm.new_cache())
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 0.03 * scale, (got - ref).abs().max().item() / scale
+    assert (got.argmax(-1) == ref.argmax(-1)).float().mean().item() >= 0.8
+    del lm, ref
+    # slice maxima of the last verify pass, gathered in rank order and combined
+    R = chunks[-1][1]
+    n = R * ops.ARGMAX_PARTS
+    blocks = []
+    for r in range(N):
+        send = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        ops.argmax_partial(ranks[r][2][-1], send[:n].view(R, -1), send[n:].view(torch.int32).view(R, -1))
+        blocks.append(send)
+    pv = torch.empty(R, ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
+    pi = torch.empty(R, ops.ARGMAX_PARTS, dtype=torch.int32, device=dev)
+    ops.argmax_combine(torch.cat(blocks), N, R, 16032, pv, pi)
+    assert ops.argmax_from_partials(pv, pi, R).cpu().tolist() == got[-R:].argmax(-1).tolist()
+    del ranks
+
+    # ---- (3) whole engines, the draft replicated
+    dc = LLAMA3_8B_2L
+    dw = weights.from_state_dict(_cfg_of(dc, rope_scaling=dc.rope_scaling),
+                                 {n_: v.to(torch.bfloat16) for n_, v in random_state(dc, seed=18).items()}, dev)
+    prompts = [toks[:9]]
+
+    def run(kk):
+        coll = _RankSum(N)
+        engines = []
+        for r in range(N):
+            group = parallel.CallbackAllReduce(r, coll.make(r), world_size=N, gather=coll.make_gather(r))
+            eng = SpecEngine(shards[r], dw if kk else None, EngineConfig(
+                k=kk, max_batch=1, max_seq_len=80, split_tokens=128, use_graph=False), tp_group=group)
+            eng.stream = stream
+            coll.models[r] = eng.target
+            engines.append(eng)
+        torch.cuda.synchronize()
+        outs = [None] * N
+
+        def worker(r):
+            eng = engines[r]
+            t = [eng.add_request(0, prompts[0])]
+            while len(t) < 20:
+                t.extend(eng.step()[0])
+            outs[r] = t[:20]
+
+        _run_ranks(N, worker)
+        assert coll.error is None, coll.error
+        assert all(o == outs[0] for o in outs)      # the ranks agree without exchanging decisions
+        return outs[0], engines[0].metrics()
+
+    ar, _ = run(0)
+    spec, m = run(k)
+    assert spec == ar
+    assert m["draft"] > 0 and m["draft"] % k == 0 and m["emitted"] >= 19
+
+
+def test_a_timed_out_exchange_drops_the_steps_tokens():
+    """A collective that reports a wait that gave up (IpcTensorParallelGroup.timeouts) makes the
+    step raise instead of handing out tokens computed from partial sums that were never
+    combined; the next healthy step goes on."""
+    from vllm_omni_draft_amd import parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=1, hidden=128, n_heads=2, n_kv_heads=1, head_dim=64,
+                      ffn=256, vocab=256, max_pos=128)
+    cfg = _cfg_of(oc)
+    state = {k: v.to(torch.bfloat16) for k, v in random_state(oc, seed=2).items()}
+    local, st = weights.shard_state_dict(cfg, state, 1, 0)
+    group = parallel.CallbackAllReduce(0, lambda ptr, n, stream: 0, world_size=1)
+    seen = {"n": 0}
+    group.timeouts = lambda: seen["n"]
+    eng = SpecEngine(weights.from_state_dict(local, st, "cuda"), None,
+                     EngineConfig(k=0, max_batch=1, max_seq_len=64, split_tokens=128, use_graph=False),
+                     tp_group=group)
+    eng.add_request(0, [1, 2, 3])
+    assert len(eng.step()[0]) == 1
+    seen["n"] = 2
+    with pytest.raises(RuntimeError, match="timed out"):
+        eng.step()
+    assert len(eng.step()[0]) == 1          # counted once; later steps are served
