@@ -84,6 +84,17 @@ def parse():
     ap.add_argument("--cpu-baseline-worker", action="store_true",
                     help="internal: the child process of the cpu_baseline leg (SD_AMD_BACKEND=cpu)")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    # The tensor-parallel configuration (BASELINE.json configs[3]): ONE job over all ranks.
+    ap.add_argument("--tp", type=int, default=int(os.environ.get("SD_BENCH_TP", "0") or 0),
+                    help="tensor-parallel degree (= WORLD_SIZE): the target's verify pass is sharded over "
+                         "the ranks, one sequence for the whole job; target / draft / k default to "
+                         "llama-3-70b / llama-3-8b / 4")
+    ap.add_argument("--tp-collective", choices=["rccl", "ipc"], default="rccl",
+                    help="rccl: the library's RCCL group; ipc: one-shot all-reduce kernels over "
+                         "peer-mapped memory")
+    ap.add_argument("--tp-draft", choices=["replicated", "sharded"], default="replicated",
+                    help="the draft whole on every rank (no exchange in its passes), or sharded "
+                         "like the target with a vocabulary-parallel head")
     return ap.parse_args()
 
 
@@ -371,10 +382,139 @@ def cpu_baseline_worker(budget_s):
                   f"and sequence (every proposal accepted: draft == target), prefill {prefill_s:.1f} s"}))
 
 
+def main_tp(args):
+    """One tensor-parallel job over WORLD_SIZE ranks (one process per GPU): the target's shards
+    with seeded random values (every rank draws its own; norms and embedding are the same on all
+    ranks), the draft replicated or sharded, every rank running the same steps in lockstep; the
+    verify pass's two all-reduces per layer and the head's slice-maxima exchange go through the
+    chosen collective inside the step graph.  value = the job's tokens/s (one sequence)."""
+    from vllm_omni_draft_amd import config, parallel, weights
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("SD_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if world != args.tp:
+        raise SystemExit(f"--tp {args.tp} needs WORLD_SIZE == {args.tp} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU path)")
+    backend = os.environ.get("SD_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    red_device = device if backend == "nccl" else torch.device("cpu")
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or not dist.is_initialized():
+        dist.init_process_group(backend, **({"device_id": device} if backend == "nccl" else {}))
+    target = args.target if args.target != "llama-3-8b" else "llama-3-70b"
+    draft = args.draft if args.draft != "llama-3.2-1b" else "llama-3-8b"
+    k = args.k if args.k != 5 else 4
+    over = {"n_layers": args.layers} if args.layers else {}
+    full_t, full_d = config.preset(target, **over), config.preset(draft, **over)
+    tcfg = full_t.tp_shard(world, vocab_parallel=True)
+    sharded_draft = args.tp_draft == "sharded"
+    dcfg = full_d.tp_shard(world, vocab_parallel=True) if sharded_draft else full_d
+    if args.tp_collective == "ipc":
+        group = parallel.IpcTensorParallelGroup(rank, world, max_message_bytes=256 * full_t.hidden * 2)
+    else:
+        group = parallel.TensorParallelGroup(rank, world)
+    tw = weights.random_init(tcfg, seed=1, device=device, tp_rank=rank)
+    dw = weights.random_init(dcfg, seed=2, device=device, tp_rank=rank if sharded_draft else 0)
+    torch.cuda.empty_cache()     # the f32 temporaries of the initialisation go back to the device
+    free_b, total_b = torch.cuda.mem_get_info()
+    print(f"[rank {rank}] weights {(streamed_weight_bytes(tw) + streamed_weight_bytes(dw)) / 2**30:.1f} GiB, "
+          f"reserved {torch.cuda.memory_reserved() / 2**30:.1f} GiB, device free {free_b / 2**30:.1f} of "
+          f"{total_b / 2**30:.1f} GiB", file=sys.stderr, flush=True)
+    g = torch.Generator().manual_seed(1234)
+    prompt = torch.randint(0, full_t.vocab, (args.prompt_len,), generator=g).tolist()
+    n_truth = (args.warmup + args.steps) * (k + 1) + 8
+    max_seq = args.prompt_len + n_truth + 16
+
+    def engine(kk, d=None):
+        return SpecEngine(tw, d, EngineConfig(k=kk, max_seq_len=max_seq, split_tokens=args.split_tokens,
+                                              draft_split_tokens=args.draft_split_tokens,
+                                              use_graph=not args.no_graph, gen_capacity=n_truth + 64),
+                          tp_group=group, draft_tp=sharded_draft and d is not None)
+
+    ar = engine(0)
+    torch.cuda.synchronize()
+    dist.barrier()       # the ranks' kernels wait for each other with bounded waits: start together
+    warm = 0
+    if hasattr(group, "warm_up"):
+        t0 = time.perf_counter()
+        warm = group.warm_up(256 * full_t.hidden * 2)
+        print(f"[rank {rank}] first exchange: {time.perf_counter() - t0:.2f} s, {warm} waits gave up",
+              file=sys.stderr, flush=True)
+        dist.barrier()
+    if hasattr(group, "timeouts"):
+        ar._tp_timeouts_seen = group.timeouts()
+    ar_tokens, ar_n, ar_dt, _ = run_generation(ar, prompt, n_truth - 4 - args.warmup, args.warmup, dist.barrier)
+    truth = torch.zeros(1, max_seq, dtype=torch.int32)
+    truth[0, :len(prompt)] = torch.tensor(prompt)
+    truth[0, len(prompt):len(prompt) + len(ar_tokens)] = torch.tensor(ar_tokens)
+    del ar
+    torch.cuda.empty_cache()
+    eng = engine(k, dw)
+    if hasattr(group, "timeouts"):
+        eng._tp_timeouts_seen = group.timeouts()
+    eng.set_synthetic_acceptance(truth.to(device), args.accept_prob, seed=-args.warmup,
+                                 pattern_len=min(args.steps, 64))
+    torch.cuda.synchronize()
+    dist.barrier()
+    toks, n_timed, dt, prefill = run_generation(eng, prompt, args.steps, args.warmup, dist.barrier)
+    n_cmp = min(len(toks), len(ar_tokens))
+    exact = toks[:n_cmp] == ar_tokens[:n_cmp]
+    t = torch.tensor([dt, ar_dt], dtype=torch.float64, device=red_device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # every rank emitted the same stream: a checksum of it must agree, and all must be exact
+    chk = float(sum((i + 1) * tok for i, tok in enumerate(toks)) % 1000003)
+    c = torch.tensor([chk, -chk, float(exact)], dtype=torch.float64, device=red_device)
+    dist.all_reduce(c, op=dist.ReduceOp.MIN)
+    same_stream = c[0].item() == chk and -c[1].item() == chk
+    timeouts = group.timeouts() if hasattr(group, "timeouts") else 0
+    if rank == 0:
+        dt, ar_dt = float(t[0].item()), float(t[1].item())
+        ms = dt / args.steps * 1e3
+        ctx_mid = args.prompt_len + (args.warmup + args.steps / 2) * n_timed / args.steps
+        rank_bytes = (streamed_weight_bytes(tw) + k * streamed_weight_bytes(dw)
+                      + tcfg.kv_bytes_per_token() * ctx_mid + k * dcfg.kv_bytes_per_token() * ctx_mid)
+        print(json.dumps({
+            "metric": f"output tokens/sec (+ accept-len), {target} TP={world} + {draft} draft, k={k}, greedy",
+            "value": round(n_timed / dt, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (seeded random shards; random-token prompt; acceptance imposed by a fixed "
+                    f"cyclic schedule at probability {args.accept_prob})",
+            "config": {"workload": f"{target} target sharded over {world} ranks (heads, ffn columns, "
+                                   f"vocabulary-parallel head) + {draft} draft {args.tp_draft}, k={k}, "
+                                   f"batch 1, prompt {args.prompt_len} (BASELINE.json configs[3])",
+                       "parallelism": f"tp{world}", "tensor_parallel_collective": args.tp_collective,
+                       "draft": args.tp_draft, "hipgraph": not args.no_graph,
+                       "ranks_share_one_gpu": "SD_BENCH_DEVICE" in os.environ},
+            "accept_len": round(n_timed / args.steps - 1.0, 3),
+            "spec_stream_equals_ar_stream": bool(c[2].item() == 1.0),
+            "ranks_emit_the_same_stream": bool(same_stream), "exchange_timeouts": int(timeouts),
+            "ar_tokens_per_s": round(ar_n / ar_dt, 2),
+            "speedup_vs_ar": round(n_timed / dt / (ar_n / ar_dt), 3), "prefill_s": round(prefill, 3),
+            "step_roofline": {"bound": "hbm", "bytes_per_step_per_rank": int(rank_bytes),
+                              "achieved": round(rank_bytes / (ms * 1e-3) * 1e-9, 1), "peak": HBM_PEAK_GBS,
+                              "unit": "GB/s per GPU", "frac": round(rank_bytes / (ms * 1e-3) * 1e-9 / HBM_PEAK_GBS, 4)},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    dist.barrier()
+    del eng
+    if hasattr(group, "close"):
+        torch.cuda.synchronize()
+        dist.barrier()
+        group.close()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.cpu_budget)
+        return
+    if args.tp:
+        main_tp(args)
         return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

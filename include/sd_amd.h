@@ -731,7 +731,7 @@ int sd_model_forward(sd_model* m, const sd_kv_cache* kv,
  * publishes the message in the rank's buffer, raises per-slice flags, waits for the peers'
  * flags and combines the ranks' data IN RANK ORDER, so every rank ends with the same bits.
  * Calls are stream-ordered kernels only (capturable); call counters live in device memory.
- * Every rank must make the same sequence of calls.  A peer that does not arrive within ~4 s
+ * Every rank must make the same sequence of calls.  A peer that does not arrive within ~20 s
  * makes the waiting workgroup give up (garbage result, sd_ipc_comm_errors > 0), never a hang.
  * Limits: <= 8 ranks, messages <= max_message_bytes <= 16 MiB, multiples of 16 bytes.
  * sd_ipc_allreduce is an sd_allreduce_fn (ctx = the sd_ipc_comm*); sd_ipc_allgather has
@@ -747,6 +747,11 @@ sd_ipc_comm* sd_ipc_comm_create(int rank, int world_size, void* const* bufs,
                                 size_t max_message_bytes);
 void sd_ipc_comm_destroy(sd_ipc_comm* comm);
 int sd_ipc_comm_errors(sd_ipc_comm* comm, int* n_timeouts); /* synchronises */
+/* How long a wait for a peer may last in the calls enqueued from now on (0: back to the
+ * default, ~20 s; calls already captured into a graph keep theirs).  Processes that have just
+ * started may lag each other by more than the default on the host side (cold page cache,
+ * first launches): give them a generous bound for a warm-up pass, then restore it.         */
+int sd_ipc_comm_set_timeout_ms(sd_ipc_comm* comm, int milliseconds);
 int sd_ipc_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t stream);
 int sd_ipc_allgather(const void* send, void* recv, size_t bytes_per_rank, void* ctx,
                      sd_stream_t stream);

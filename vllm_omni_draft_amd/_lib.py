@@ -142,6 +142,7 @@ SIGNATURES = {
     "sd_ipc_comm_create": (vp, [i32, i32, C.POINTER(vp), C.c_size_t]),
     "sd_ipc_comm_destroy": (None, [vp]),
     "sd_ipc_comm_errors": (i32, [vp, C.POINTER(i32)]),
+    "sd_ipc_comm_set_timeout_ms": (i32, [vp, i32]),
     "sd_ipc_allreduce": (i32, [vp, C.c_size_t, vp, vp]),
     "sd_ipc_allgather": (i32, [vp, vp, C.c_size_t, vp, vp]),
     "sd_fill_uniforms": (i32, [vp, i32, C.c_uint64, vp, vp]),

@@ -29,7 +29,10 @@ constexpr size_t kSliceBytes = 8192;
 constexpr int kThreads = 256;
 constexpr size_t kHeaderBytes = 16384;   // flags[kMaxSlices] + counters[kMaxSlices] (u32 each)
 constexpr int kMaxSlices = 2048;         // 16 MiB per message at most
-constexpr unsigned long long kSpinTicks = 400000000ull;  // 4 s of the 100 MHz wall clock (default)
+// How long a wait for a peer may last (100 MHz wall clock): 20 s by default.  Two ranks of a
+// 70B model as two processes on one card needed more than 4 s at their first exchange (the
+// card time-slices processes); a dead peer still ends the wait, and the step raises.
+constexpr unsigned long long kSpinTicks = 2000000000ull;
 
 struct IpcPeers {
   unsigned char* buf[kMaxRanks];  // buf[rank] = this rank's own buffer
@@ -54,8 +57,13 @@ template <bool GATHER>
 __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(IpcPeers p, const unsigned char* send,
                                                                 unsigned char* out, size_t bytes) {
   __shared__ unsigned s_seq;
-  const int w = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   unsigned char* own = p.buf[p.rank];
+  const int n_slices = (int)((bytes + kSliceBytes - 1) / kSliceBytes);
+  // A workgroup walks its slices one after the other (messages of more than kMaxGrid slices:
+  // prefill passes); every slice is an exchange of its own, so no workgroup of this grid waits
+  // for another one of this grid.
+  for (int w = blockIdx.x; w < n_slices; w += gridDim.x) {
   if (tid == 0) s_seq = counters_of(own)[w] + 1;
   __syncthreads();
   const unsigned seq = s_seq;
@@ -112,7 +120,15 @@ __global__ __launch_bounds__(kThreads) void ipc_exchange_kernel(IpcPeers p, cons
     }
   }
   if (tid == 0) counters_of(own)[w] = seq;
+  __syncthreads();   // the next slice rewrites s_seq
+  }
 }
+
+// Workgroups per launch at most: a waiting grid must leave compute units free.  Where the
+// ranks are processes on ONE card (rehearsals), a peer's next kernel may need a whole unit's
+// LDS; a grid that holds a little LDS on every unit while it waits for that peer would never
+// see it arrive.
+constexpr int kMaxGrid = 96;
 
 }  // namespace
 
@@ -211,6 +227,12 @@ extern "C" void sd_ipc_comm_destroy(sd_ipc_comm* c) {
   delete c;
 }
 
+extern "C" int sd_ipc_comm_set_timeout_ms(sd_ipc_comm* c, int milliseconds) {
+  SD_REQUIRE(c && milliseconds >= 0, SD_ERR_INVALID, "sd_ipc_comm_set_timeout_ms: bad arguments");
+  c->peers.spin_ticks = milliseconds ? (unsigned long long)milliseconds * 100000ull : kSpinTicks;
+  return SD_OK;
+}
+
 extern "C" int sd_ipc_comm_errors(sd_ipc_comm* c, int* n_timeouts) {
   SD_REQUIRE(c && n_timeouts, SD_ERR_INVALID, "sd_ipc_comm_errors: null pointer");
   unsigned n = 0;
@@ -231,7 +253,7 @@ extern "C" int sd_ipc_allreduce(void* buf, size_t n_bf16, void* ctx, sd_stream_t
              "sd_ipc_allreduce: %zu bytes exceed the exchange buffers (%zu)", bytes, c->max_bytes);
   if (bytes == 0) return SD_OK;
   const int slices = (int)((bytes + kSliceBytes - 1) / kSliceBytes);
-  hipLaunchKernelGGL((ipc_exchange_kernel<false>), dim3(slices), dim3(kThreads), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((ipc_exchange_kernel<false>), dim3(slices < kMaxGrid ? slices : kMaxGrid), dim3(kThreads), 0, (hipStream_t)stream,
                      c->peers, (const unsigned char*)buf, (unsigned char*)buf, bytes);
   SD_CHECK_LAUNCH("sd_ipc_allreduce");
   return SD_OK;
@@ -248,7 +270,7 @@ extern "C" int sd_ipc_allgather(const void* send, void* recv, size_t bytes_per_r
              "sd_ipc_allgather: %zu bytes exceed the exchange buffers (%zu)", bytes_per_rank, c->max_bytes);
   if (bytes_per_rank == 0) return SD_OK;
   const int slices = (int)((bytes_per_rank + kSliceBytes - 1) / kSliceBytes);
-  hipLaunchKernelGGL((ipc_exchange_kernel<true>), dim3(slices), dim3(kThreads), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((ipc_exchange_kernel<true>), dim3(slices < kMaxGrid ? slices : kMaxGrid), dim3(kThreads), 0, (hipStream_t)stream,
                      c->peers, (const unsigned char*)send, (unsigned char*)recv, bytes_per_rank);
   SD_CHECK_LAUNCH("sd_ipc_allgather");
   return SD_OK;

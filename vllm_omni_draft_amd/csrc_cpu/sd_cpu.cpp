@@ -1233,6 +1233,7 @@ extern "C" sd_ipc_comm* sd_ipc_comm_create(int, int, void* const*, size_t) {
 }
 extern "C" void sd_ipc_comm_destroy(sd_ipc_comm*) {}
 extern "C" int sd_ipc_comm_errors(sd_ipc_comm*, int*) { UNSUPPORTED("sd_ipc_comm_errors"); }
+extern "C" int sd_ipc_comm_set_timeout_ms(sd_ipc_comm*, int) { UNSUPPORTED("sd_ipc_comm_set_timeout_ms"); }
 extern "C" int sd_ipc_allreduce(void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_ipc_allreduce"); }
 extern "C" int sd_ipc_allgather(const void*, void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_ipc_allgather"); }
 extern "C" int sd_graph_begin(sd_stream_t) { UNSUPPORTED("sd_graph_begin"); }

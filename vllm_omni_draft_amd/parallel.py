@@ -183,6 +183,26 @@ class IpcTensorParallelGroup:
         _lib.check(self._lib.sd_ipc_allgather(send.data_ptr(), recv.data_ptr(), nbytes, self._comm,
                                               torch.cuda.current_stream().cuda_stream), "sd_ipc_allgather")
 
+    def set_timeout_ms(self, milliseconds: int) -> None:
+        """Bound of a wait for a peer in the calls enqueued from now on (0: the default, ~20 s).
+        Freshly started processes may lag each other by more than that on the host side (cold
+        page cache, first launches): run a warm-up pass under a generous bound, then restore it
+        before anything is captured into a graph."""
+        from . import _lib
+        _lib.check(self._lib.sd_ipc_comm_set_timeout_ms(self._comm, int(milliseconds)),
+                   "sd_ipc_comm_set_timeout_ms")
+
+    def warm_up(self, nbytes: int) -> int:
+        """One all-reduce of `nbytes` (zeros) on the current stream, waited for: the first
+        exchange of a group maps the peers' pages and may find a peer seconds behind (still
+        loading weights); doing it here, before the first timed or served pass, keeps that out of
+        the passes.  Returns the waits that gave up during it (0: every peer arrived)."""
+        before = self.timeouts()
+        t = torch.zeros(max(nbytes // 2, 8), dtype=torch.bfloat16, device="cuda")
+        self.all_reduce(t)
+        torch.cuda.current_stream().synchronize()
+        return self.timeouts() - before
+
     def timeouts(self) -> int:
         """Waits that gave up since the group was made (synchronises); 0 in a healthy run."""
         from . import _lib

@@ -681,6 +681,11 @@ class SpecDecodeWorker:
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
             posterior_alpha=c.typical_acceptance_sampler_posterior_alpha),
             tp_group=getattr(self, "tp_group", None), draft_tp=draft_tp)
+        if tp > 1:
+            # the ranks' kernels wait for each other with bounded waits: no rank may start a pass
+            # while a peer is still loading its shard
+            _rt.synchronize(_rt.device(self.local_rank))
+            torch.distributed.barrier()
         self._wire()
 
     def _wire(self) -> None:

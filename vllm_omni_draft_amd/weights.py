@@ -241,10 +241,13 @@ def shard_state_dict(cfg: ModelConfig, state: Dict[str, torch.Tensor], tp_size: 
 
 
 def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.02,
-                fp8: bool = False, head_subset=None) -> ModelWeights:
+                fp8: bool = False, head_subset=None, tp_rank: int = 0) -> ModelWeights:
     """Seeded random weights generated directly on the device in the fused
     layout (no host copy: an 8B model is 16 GB).  head_subset: as for from_state_dict (the
-    other tensors are those of the same seed without it)."""
+    other tensors are those of the same seed without it).  tp_rank: cfg is one rank's share
+    of a tensor-parallel model (ModelConfig.tp_shard); every rank draws the same replicated
+    tensors (norms, embedding) and its own sharded matrices (rank 0's, rotated along the input
+    dimension), so that the ranks' partial products differ as real shards' do."""
     cfg.validate()
     sub = None
     full_rows = cfg.head_rows
@@ -255,9 +258,12 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
     def _tile(w, mode=ops.TILE_PLAIN, head_dim=0):
         return _tile_matrix(w, mode, head_dim, fp8=fp8)
 
-    def rn(*shape, s=std):
-        return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s
-                ).to(torch.bfloat16)
+    def rn(*shape, s=std, sharded=True):
+        w = (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s
+             ).to(torch.bfloat16)
+        if tp_rank and sharded and len(shape) == 2:
+            w = w.roll(17 * tp_rank, dims=1)
+        return w
 
     def ones(n):
         return (1.0 + torch.randn(n, generator=gen, device=device) * 0.05).to(torch.bfloat16)
@@ -278,7 +284,7 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
                 qkv_b=rn(cfg.qkv_rows), o_w=_tile(rn(H, cfg.n_heads * cfg.head_dim)), o_b=rn(H),
                 mlp_norm_w=ones(H), mlp_norm_b=rn(H), up_w=_tile(rn(F, H)), up_b=rn(F),
                 down_w=_tile(rn(H, F)), down_b=rn(H)))
-    embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5)
+    embed = rn(cfg.vocab, H, s=1.0 if cfg.arch == "llama" else 0.5, sharded=False)
     embed, lm_head, tied = _embed_and_head(embed, None if cfg.tie_embeddings else rn(full_rows, H),
                                            device, fp8, sub)
     w = ModelWeights(cfg=cfg, embed=embed, embed_tiled=tied, final_norm_w=ones(H), lm_head=lm_head,
@@ -286,7 +292,7 @@ def random_init(cfg: ModelConfig, seed: int = 0, device="cuda", std: float = 0.0
     if cfg.arch == "llama":
         w.rope_cs = rope_table(cfg, device)
     else:
-        w.pos_table = rn(cfg.max_pos + cfg.pos_bias, H, s=0.5)
+        w.pos_table = rn(cfg.max_pos + cfg.pos_bias, H, s=0.5, sharded=False)
         w.final_norm_b = rn(H)
     return w
 
