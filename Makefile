@@ -2,7 +2,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := vllm_omni_draft_amd/csrc
-SRCS  := $(CSRC)/sd_runtime.hip $(CSRC)/sd_sampling.hip $(CSRC)/sd_linear.hip $(CSRC)/sd_linear_wide.hip $(CSRC)/sd_attention.hip $(CSRC)/sd_ipc.hip $(CSRC)/sd_chain.hip
+SRCS  := $(CSRC)/sd_runtime.hip $(CSRC)/sd_sampling.hip $(CSRC)/sd_linear.hip $(CSRC)/sd_linear_wide.hip $(CSRC)/sd_attention.hip $(CSRC)/sd_ipc.hip $(CSRC)/sd_chain.hip $(CSRC)/sd_draft_layer.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vllm_omni_draft_amd/libsd_amd.so
 EXTRA ?=
@@ -34,7 +34,7 @@ STAMP_LIB := $(STAMP_DIR)/libsd_amd_stamps.so
 STAMP_OBJS := $(patsubst $(CSRC)/%.hip,$(STAMP_DIR)/%.o,$(SRCS))
 $(STAMP_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
 	@mkdir -p $(STAMP_DIR)
-	$(HIPCC) $(FLAGS) -DSD_ATTN_STAMPS -DSD_LIN_STAMPS -DSD_CHAIN_STAMPS -c $< -o $@
+	$(HIPCC) $(FLAGS) -DSD_ATTN_STAMPS -DSD_LIN_STAMPS -DSD_CHAIN_STAMPS -DSD_DRAFT_STAMPS -c $< -o $@
 $(STAMP_LIB): $(STAMP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(STAMP_OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 stamps: $(STAMP_LIB)

@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--draft-layers", choices=["three", "five"], default="five",
+                    help="five: the draft's passes on the five-launch layer (the target's kernels); "
+                         "three: three launches per layer where the shapes allow it (measured no faster)")
     ap.add_argument("--layers", type=int, default=0, help="debug only: truncate both models")
     ap.add_argument("--cpu-baseline-worker", action="store_true",
                     help="internal: the child process of the cpu_baseline leg (SD_AMD_BACKEND=cpu)")
@@ -201,7 +204,7 @@ def kernel_roofline(eng, tw, rows, reps=3):
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
-def draft_pass_roofline(dw, device, ctx, split_tokens):
+def draft_pass_roofline(dw, device, ctx, split_tokens, fused_layers=False):
     """One decode pass of the draft model (one row, `ctx` cached tokens, LM head included) in a
     replayed graph of four passes on a cache of its own: the bytes a pass must stream (every
     weight matrix once, the context's K/V once) over its duration.  The k passes of a step run
@@ -212,7 +215,7 @@ def draft_pass_roofline(dw, device, ctx, split_tokens):
     from vllm_omni_draft_amd.model_runner import DecoderModel
     cfg = dw.cfg
     max_ctx = ctx + 64
-    model = DecoderModel(dw, max_ctx, split_tokens)
+    model = DecoderModel(dw, max_ctx, split_tokens, fused_layers=fused_layers)
     kv = PagedKVCache(cfg, PagedKVCache.pages_for(cfg, 1, max_ctx), 1, max_ctx, device)
     kv.ensure_capacity(0, max_ctx)
     kv.k.normal_(0, 0.5)
@@ -246,7 +249,8 @@ def draft_pass_roofline(dw, device, ctx, split_tokens):
     gbs = nbytes / us * 1e-3
     return {"what": f"one decode pass of the draft ({cfg.n_layers} layers + LM head), 1 row, {ctx} cached "
                     f"tokens, in a replayed graph", "bound": "hbm", "bytes_per_pass": int(nbytes),
-            "us_per_pass": round(us, 1), "launches_per_pass": 5 * cfg.n_layers + 2,
+            "us_per_pass": round(us, 1),
+            "launches_per_pass": (3 if model.fused_layers else 5) * cfg.n_layers + 2,
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(gbs / HBM_PEAK_GBS, 4)}
 
@@ -571,6 +575,7 @@ def main():
     def spec_run(alpha, steps, warmup, overlapped=ovl, draft=None):
         eng = SpecEngine(tw, draft or dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
                                               draft_split_tokens=args.draft_split_tokens,
+                                              draft_fused_layers=args.draft_layers == "three",
                                               use_graph=not args.no_graph, gen_capacity=n_truth + 64))
         # A fixed cyclic schedule decides how many proposals each step accepts (the timed
         # region covers whole cycles, so its accept-len is the schedule's mean, run after run);
@@ -613,7 +618,8 @@ def main():
                     *((streamed_weight_bytes(tw), streamed_weight_bytes(dw)) if fp8 else ()))
     roof = kernel_roofline(eng, tw, k + 1)
     attn = attention_roofline(device, k)
-    draft_pass = draft_pass_roofline(dw, device, int(ctx_mid), args.draft_split_tokens or args.split_tokens)
+    draft_pass = draft_pass_roofline(dw, device, int(ctx_mid), args.draft_split_tokens or args.split_tokens,
+                                     fused_layers=args.draft_layers == "three")
     sweep = []
     other_mode = None
     fp8_draft = None

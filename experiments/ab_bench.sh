@@ -1,0 +1,12 @@
+#!/bin/bash
+# Same-box A/B of the headline bench between two sets of bench.py options (variants are only
+# comparable inside one GPU call).  Usage: experiments/ab_bench.sh "<options A>" "<options B>"
+A=${1:---draft-layers five}
+B=${2:---draft-layers three}
+for round in 1 2; do
+  for v in "$A" "$B"; do
+    timeout -k 10 200 python bench.py --steps 64 --warmup 8 --no-sweep --no-cpu-baseline $v 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('[$v]', 'tok/s',d['value'],'ms/step',d['ms_per_step'],'AR',d['ar_tokens_per_s'],'speedup',d['speedup_vs_ar'],'exact',d['spec_stream_equals_ar_stream'],'draft pass us',d['draft_pass_roofline']['us_per_pass'])" || exit 1
+  done
+done

@@ -512,6 +512,77 @@ int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x,
                      int pos_offset, int B, int q_len, int Hq, int Hkv, int D,
                      int K, const sd_rope_positions* rope_pos, sd_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * A decoder layer of the DRAFT model as three launches instead of five, for
+ * passes of 1..SD_DRAFT_LAYER_MAX_ROWS token rows (one or two per sequence):
+ *   1. sd_norm_qkv_rope_adds   RMSNorm + QKV + rotary + cache append
+ *   2. sd_draft_attn_oproj     attention over the whole context + output projection
+ *   3. sd_draft_mlp            RMSNorm + gate/up + SiLU*mul + down projection
+ * A linear layer whose input is produced distributed over workgroups is computed
+ * by the producers: each multiplies its slice of the input with the matching
+ * weight columns and contributes a partial output row (launch 2: one f32 slab per
+ * KV head, summed by launch 3 while it stages its input; launch 3: float atomics
+ * into one f32 accumulator row).  The residual stream travels as (h, pending
+ * sums): a normalising launch computes bf16(h + sums) itself and one workgroup
+ * stores it for the launches behind.  Rows differ from the five-launch layer's in
+ * the last bits (other summation order; the atomics' order is not fixed): for the
+ * draft model, whose rounding shows only in what is proposed.  No counterpart in
+ * the reference tree (replaces launches of spec_decode.multi_step_worker's model
+ * passes).                                                                     */
+#define SD_DRAFT_LAYER_MAX_ROWS 4
+#define SD_DRAFT_LAYER_MAX_CTX 2048   /* keys one workgroup attends per KV head */
+
+/* Pending f32 partial sums of the rows a fused norm reads: the staging normalises
+ * x + add (rounded to bf16 first) and, when x_out is given, one workgroup stores
+ * that sum as the new residual rows.  add == NULL: none.                       */
+typedef struct {
+  const float* add;   /* [M][ld_add] f32 */
+  int64_t ld_add;
+  void* x_out;        /* [M][ldx] bf16, or NULL */
+} sd_row_adds;
+
+/* sd_norm_linear / sd_norm_qkv_rope with an additive input (RMSNorm, bf16 weights;
+ * epilogue F32 for sd_norm_linear_adds).  adds == NULL: the plain forms.        */
+int sd_norm_linear_adds(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                        const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                        const void* bias, void* out, int64_t ldo, int M, int N, int K,
+                        int epilogue, const sd_row_adds* adds, sd_stream_t stream);
+int sd_norm_qkv_rope_adds(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                          const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                          const void* bias, void* q_out, int64_t ldq, const float* rope_cs,
+                          int max_pos, void* k_cache, void* v_cache,
+                          const int32_t* block_tables, int max_blocks_per_seq,
+                          const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
+                          int Hkv, int D, int K, const sd_rope_positions* rope_pos,
+                          const sd_row_adds* adds, sd_stream_t stream);
+/* 1 if launches 2 and 3 take the shape: rows = B*q_len <= SD_DRAFT_LAYER_MAX_ROWS,
+ * q_len <= 2, head_dim 64 or 128, (Hq/Hkv)*q_len <= 32, (Hq/Hkv)*D <= 512,
+ * hidden a multiple of 128 up to 4096, ffn a multiple of 32, max_ctx <=
+ * SD_DRAFT_LAYER_MAX_CTX.                                                      */
+int sd_draft_layer_supported(int rows, int q_len, int hidden, int n_heads, int n_kv_heads,
+                             int head_dim, int ffn, int max_ctx);
+/* Launch 2.  q [B*q_len, Hq*D] (rotated, from launch 1), caches and block table as
+ * sd_paged_attention; o_w [H, Hq*D] tiled SD_TILE_PLAIN.  One workgroup per (KV
+ * head, 128 projection rows, sequence) attends the head's WHOLE context (no key
+ * splits across workgroups: max_ctx <= SD_DRAFT_LAYER_MAX_CTX) and multiplies the
+ * head group's normalised output with its columns of o_w.  slabs [Hkv][B*q_len][H]
+ * f32: every element is written.  zero / zero_n: f32 words this launch clears
+ * (the accumulator launch 3 adds into), or NULL / 0.                           */
+int sd_draft_attn_oproj(const void* q, int64_t ldq, const void* k_cache, const void* v_cache,
+                        const int32_t* block_tables, int max_blocks_per_seq,
+                        const int32_t* seq_lens, int pos_offset, const void* o_w, float* slabs,
+                        float* zero, int zero_n, int B, int q_len, int Hq, int Hkv, int D, int H,
+                        float scale, int max_ctx, sd_stream_t stream);
+/* Launch 3.  x = bf16(h + sum of the n_add slabs add[s][m][:], s in order); h_out
+ * (or NULL) receives x; acc[m][:] += down(silu(gate(norm(x))) * up(norm(x))) by
+ * float atomics (acc must hold the sums pending so far, usually zeros).  up_w:
+ * [2F, H] tiled SD_TILE_GATED; down_w_km: the SD_TILE_PLAIN tiles of [H, F] ordered
+ * k-step first ([F/32][H/16][64][8]), so that the 32 input columns a workgroup
+ * owns are contiguous.  M <= SD_DRAFT_LAYER_MAX_ROWS, n_add <= 8.              */
+int sd_draft_mlp(const void* h, int64_t ldh, const float* add, int n_add, void* h_out,
+                 const void* norm_w, float eps, const void* up_w, const void* down_w_km,
+                 float* acc, int M, int H, int F, sd_stream_t stream);
+
 /* out = bf16(bf16(x * rsqrt(mean(x^2) + eps)) * w) per row; rows x H bf16. */
 int sd_rmsnorm(const void* x, int64_t ldx, const void* w, void* out,
                int64_t ldo, int rows, int H, float eps, sd_stream_t stream);
@@ -621,6 +692,9 @@ typedef struct {
   const float* o_s;
   const float* up_s;
   const float* down_s;
+  /* down_w's tiles ordered k-step first (sd_draft_mlp), or NULL: needed only by a
+   * model whose passes may run with sd_forward_args.draft_fused.              */
+  const void* down_w_km;
 } sd_layer_weights;
 
 typedef struct {
@@ -708,6 +782,12 @@ typedef struct {
    * every layer as attention + sd_chain_o_up + sd_chain_down_qkv, three launches
    * instead of five, with the same bits.                                      */
   void* chain_state;
+  /* != 0: a pass whose shape sd_draft_layer_supported accepts (narrow family, RMSNorm
+   * model with bf16 weights and down_w_km in every layer, no tensor parallelism, no
+   * tree, no multimodal positions) runs every layer as three launches
+   * (sd_norm_qkv_rope_adds, sd_draft_attn_oproj, sd_draft_mlp).  Logits differ from
+   * the five-launch pass in the last bits: for draft models only.              */
+  int draft_fused;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

@@ -25,7 +25,7 @@ class SdError(RuntimeError):
 class LayerWeights(C.Structure):
     _fields_ = [(n, vp) for n in (
         "attn_norm_w", "attn_norm_b", "qkv_w", "qkv_b", "o_w", "o_b", "mlp_norm_w", "mlp_norm_b",
-        "up_w", "up_b", "down_w", "down_b", "qkv_s", "o_s", "up_s", "down_s")]
+        "up_w", "up_b", "down_w", "down_b", "qkv_s", "o_s", "up_s", "down_s", "down_w_km")]
 
 
 class ModelDesc(C.Structure):
@@ -55,11 +55,15 @@ class ForwardArgs(C.Structure):
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
                 ("split_tokens", i32), ("logits", vp), ("wide", i32),
                 ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp),
-                ("chain_state", vp)]
+                ("chain_state", vp), ("draft_fused", i32)]
 
 
 class UniformRegion(C.Structure):
     _fields_ = [("offset", i64), ("n", i32), ("stride_j", i64), ("stride_b", i64)]
+
+
+class RowAdds(C.Structure):
+    _fields_ = [("add", vp), ("ld_add", i64), ("x_out", vp)]
 
 
 class RopePositions(C.Structure):
@@ -101,6 +105,15 @@ SIGNATURES = {
     "sd_norm_qkv_rope": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,
                                i32, vp, i32, i32, i32, i32, i32, i32, i32,
                                C.POINTER(RopePositions), vp]),
+    "sd_norm_linear_adds": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, i32, i32, i32, i32,
+                                  C.POINTER(RowAdds), vp]),
+    "sd_norm_qkv_rope_adds": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i64, vp, i32, vp, vp, vp,
+                                    i32, vp, i32, i32, i32, i32, i32, i32, i32,
+                                    C.POINTER(RopePositions), C.POINTER(RowAdds), vp]),
+    "sd_draft_layer_supported": (i32, [i32, i32, i32, i32, i32, i32, i32, i32]),
+    "sd_draft_attn_oproj": (i32, [vp, i64, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32,
+                                  i32, i32, C.c_float, i32, vp]),
+    "sd_draft_mlp": (i32, [vp, i64, vp, i32, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, vp]),
     "sd_rmsnorm": (i32, [vp, i64, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_layernorm": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, C.c_float, vp]),
     "sd_embed": (i32, [vp, i64, i64, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),

@@ -25,7 +25,9 @@ namespace {
 
 // What a workgroup stages in LDS as its activations: nothing (lanes read x from global
 // memory), RMS- or LayerNorm-ed x, or the attention output merged from per-split partials.
-enum { NORM_NONE = 0, NORM_RMS = 1, NORM_LAYER = 2, STAGE_ATTN_MERGE = 3 };
+// NORM_RMS_ADD: RMSNorm of x + add (an f32 row of pending partial sums per token row); one
+// workgroup also keeps x + add for the launches behind (the draft model's three-launch layer).
+enum { NORM_NONE = 0, NORM_RMS = 1, NORM_LAYER = 2, STAGE_ATTN_MERGE = 3, NORM_RMS_ADD = 4 };
 constexpr int kMergeMaxSplits = 8;
 constexpr int EPI_QKV_ROPE = 100;  // internal: sd_norm_qkv_rope
 constexpr int kLinThreads = 512;
@@ -76,6 +78,9 @@ struct LinArgs {
   float eps;
   RopeArgs rope;
   MergeArgs merge;
+  const float* add;        // NORM_RMS_ADD: [M][ld_add] f32
+  int64_t ld_add;
+  bf16_t* x_out;           // NORM_RMS_ADD: [M][ldx] bf16 = x + add, or NULL
 };
 
 // HALF: a work unit is 8 of a tile's 16 rows (lanes of the other 8 rows load nothing and
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   // Without a norm the activations need no staging: each lane loads its B-operand
   // pieces straight from global memory (they sit in L2) beside the weight loads.
   constexpr bool DIRECT = NORM == NORM_NONE;
+  constexpr bool ADD = NORM == NORM_RMS_ADD;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int LDX = a.KC + kXPad;
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);                               // [M+1][LDX]
@@ -221,21 +227,32 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         float s1 = 0.f, s2 = 0.f;
         for (int c0 = 0; c0 < a.K; c0 += 4096) {
           bf16x8 v[8];
+          f32x4 p[ADD ? 8 : 1][2];
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int c = c0 + i * 512 + lane * 8;
             v[i] = c < a.K ? *reinterpret_cast<const bf16x8*>(xr + c) : z;
+            if (ADD) {
+              const float* ar = a.add + (size_t)m * a.ld_add + (c < a.K ? c : 0);
+              p[ADD ? i : 0][0] = *reinterpret_cast<const f32x4*>(ar);
+              p[ADD ? i : 0][1] = *reinterpret_cast<const f32x4*>(ar + 4);
+            }
           }
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             const int c = c0 + i * 512 + lane * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+              if (ADD && c < a.K) v[i][j] = (bf16_t)((float)v[i][j] + p[ADD ? i : 0][j >> 2][j & 3]);
               const float f = (float)v[i][j];
               s1 += f;
               s2 += f * f;
             }
-            if (c < a.K) *reinterpret_cast<bf16x8*>(xl + c) = v[i];
+            if (c < a.K) {
+              *reinterpret_cast<bf16x8*>(xl + c) = v[i];
+              if (ADD && a.x_out && blockIdx.x == 0)
+                *reinterpret_cast<bf16x8*>(a.x_out + (size_t)m * a.ldx + c) = v[i];
+            }
           }
         }
         if (NORM == NORM_LAYER) {
@@ -283,7 +300,7 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
           bf16x8 o;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (NORM == NORM_RMS)
+            if (NORM == NORM_RMS || ADD)
               o[j] = (bf16_t)(round_bf16((float)v[j] * rs) * (float)g[j]);
             else
               o[j] = (bf16_t)(((float)v[j] - mean) * rs * (float)g[j] + (float)bb[j]);
@@ -490,7 +507,7 @@ int choose_kc(int M, int K, int norm) {
   const size_t whole = (size_t)(M + 1) * (kpad + kXPad) * 2;
   // the norm weight (and LayerNorm bias) are staged in the sum buffer
   const size_t params =
-      norm == STAGE_ATTN_MERGE ? 0 : (size_t)K * 2 * (norm == NORM_LAYER ? 2 : 1);
+      norm == STAGE_ATTN_MERGE ? 0 : (size_t)K * 2 * (norm == NORM_LAYER ? 2 : 1);   // (RMS_ADD: as RMS)
   return whole <= kXBudgetNorm && params <= kRedBytes ? kpad : 0;
 }
 
@@ -537,6 +554,12 @@ int launch_one(LinArgs& a, hipStream_t st) {
 
 template <int NORM>
 int launch_n(LinArgs& a, int epi, hipStream_t st) {
+  if constexpr (NORM == NORM_RMS_ADD) {
+    if (epi == SD_EPI_F32) return launch_one<SD_EPI_F32, NORM>(a, st);
+    if (epi == EPI_QKV_ROPE) return launch_one<EPI_QKV_ROPE, NORM>(a, st);
+    sd_set_error("sd_linear: epilogue %d not available with an additive input", epi);
+    return SD_ERR_UNSUPPORTED;
+  }
   if constexpr (NORM == STAGE_ATTN_MERGE) {
     if (epi == SD_EPI_STORE) return launch_one<SD_EPI_STORE, NORM>(a, st);
     if (epi == SD_EPI_RESIDUAL) return launch_one<SD_EPI_RESIDUAL, NORM>(a, st);
@@ -569,7 +592,7 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
              SD_ERR_INVALID, "sd_linear: rows must be 16-byte aligned (ldx=%lld)", (long long)a.ldx);
   SD_REQUIRE(epi != SD_EPI_RESIDUAL || a.residual, SD_ERR_INVALID,
              "sd_linear: residual epilogue without residual pointer");
-  SD_REQUIRE(norm == NORM_NONE || norm == STAGE_ATTN_MERGE || a.norm_w, SD_ERR_INVALID,
+  SD_REQUIRE(norm == NORM_NONE || norm == STAGE_ATTN_MERGE || a.norm_w, SD_ERR_INVALID,   // (RMS_ADD too)
              "sd_linear: fused norm without weight");
   SD_REQUIRE(!a.w_scale || a.K % 64 == 0, SD_ERR_UNSUPPORTED,
              "sd_linear: fp8 weights need K %% 64 == 0 (K=%d)", a.K);
@@ -583,6 +606,7 @@ int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
     case NORM_RMS: return launch_n<NORM_RMS>(a, epi, st);
     case NORM_LAYER: return launch_n<NORM_LAYER>(a, epi, st);
     case STAGE_ATTN_MERGE: return launch_n<STAGE_ATTN_MERGE>(a, epi, st);
+    case NORM_RMS_ADD: return launch_n<NORM_RMS_ADD>(a, epi, st);
   }
   sd_set_error("sd_linear: unknown norm mode %d", norm);
   return SD_ERR_INVALID;
@@ -882,11 +906,37 @@ extern "C" int sd_linear_attn_merge(const void* W, const float* w_scale, const v
   return linear_common(a, epilogue, STAGE_ATTN_MERGE, (hipStream_t)stream);
 }
 
+namespace {
+// adds != NULL with an add pointer: the staging normalises x + add and keeps it in adds->x_out.
+int apply_adds(LinArgs& a, const sd_row_adds* adds, int* norm, const char* who) {
+  if (!adds || !adds->add) return SD_OK;
+  SD_REQUIRE(*norm == NORM_RMS, SD_ERR_UNSUPPORTED, "%s: an additive input needs a fused RMSNorm", who);
+  SD_REQUIRE(!a.w_scale, SD_ERR_UNSUPPORTED, "%s: an additive input needs bf16 weights", who);
+  SD_REQUIRE(adds->ld_add >= a.K && adds->ld_add % 4 == 0 && sd_aligned16(adds->add) &&
+                 sd_aligned16(adds->x_out) && a.K % 8 == 0,
+             SD_ERR_INVALID, "%s: additive rows must be 16-byte aligned (ld_add=%lld)", who,
+             (long long)adds->ld_add);
+  a.add = adds->add;
+  a.ld_add = adds->ld_add;
+  a.x_out = (bf16_t*)adds->x_out;
+  *norm = NORM_RMS_ADD;
+  return SD_OK;
+}
+}  // namespace
+
 extern "C" int sd_norm_linear(const void* W, const float* w_scale, const void* x, int64_t ldx,
                               const void* norm_w,
                               const void* norm_b, float eps, int layer_norm, const void* bias,
                               void* out, int64_t ldo, int M, int N, int K, int epilogue,
                               sd_stream_t stream) {
+  return sd_norm_linear_adds(W, w_scale, x, ldx, norm_w, norm_b, eps, layer_norm, bias, out, ldo, M, N,
+                             K, epilogue, nullptr, stream);
+}
+
+extern "C" int sd_norm_linear_adds(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                                   const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                                   const void* bias, void* out, int64_t ldo, int M, int N, int K,
+                                   int epilogue, const sd_row_adds* adds, sd_stream_t stream) {
   SD_REQUIRE(epilogue == SD_EPI_STORE || epilogue == SD_EPI_SILU_MUL || epilogue == SD_EPI_RELU ||
                  epilogue == SD_EPI_F32, SD_ERR_UNSUPPORTED,
              "sd_norm_linear: epilogue %d not supported with a fused norm", epilogue);
@@ -897,7 +947,10 @@ extern "C" int sd_norm_linear(const void* W, const float* w_scale, const void* x
   a.w_scale = w_scale;
   a.n_tiles = tiles_for(N, epilogue);
   a.norm_w = (const bf16_t*)norm_w; a.norm_b = (const bf16_t*)norm_b; a.eps = eps;
-  return linear_common(a, epilogue, layer_norm ? NORM_LAYER : NORM_RMS, (hipStream_t)stream);
+  int norm = layer_norm ? NORM_LAYER : NORM_RMS;
+  const int rc = apply_adds(a, adds, &norm, "sd_norm_linear_adds");
+  if (rc != SD_OK) return rc;
+  return linear_common(a, epilogue, norm, (hipStream_t)stream);
 }
 
 extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x, int64_t ldx,
@@ -908,6 +961,19 @@ extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void*
                                 int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
                                 int B, int q_len, int Hq, int Hkv, int D, int K,
                                 const sd_rope_positions* rope_pos, sd_stream_t stream) {
+  return sd_norm_qkv_rope_adds(W, w_scale, x, ldx, norm_w, norm_b, eps, layer_norm, bias, q_out, ldq,
+                               rope_cs, max_pos, k_cache, v_cache, block_tables, max_blocks_per_seq,
+                               seq_lens, pos_offset, B, q_len, Hq, Hkv, D, K, rope_pos, nullptr, stream);
+}
+
+extern "C" int sd_norm_qkv_rope_adds(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                                     const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                                     const void* bias, void* q_out, int64_t ldq, const float* rope_cs,
+                                     int max_pos, void* k_cache, void* v_cache,
+                                     const int32_t* block_tables, int max_blocks_per_seq,
+                                     const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
+                                     int Hkv, int D, int K, const sd_rope_positions* rope_pos,
+                                     const sd_row_adds* adds, sd_stream_t stream) {
   SD_REQUIRE(q_out && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
              "sd_norm_qkv_rope: null pointer");
   SD_REQUIRE(!rope_pos || (rope_pos->section_t >= 0 && rope_pos->section_h >= 0 &&
@@ -926,7 +992,9 @@ extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void*
   a.rope = RopeArgs{rope_cs, max_pos, (bf16_t*)k_cache, (bf16_t*)v_cache, block_tables,
                     max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D,
                     sd_make_rope_pos(rope_pos, B * q_len)};
-  const int norm = norm_w ? (layer_norm ? NORM_LAYER : NORM_RMS) : NORM_NONE;
+  int norm = norm_w ? (layer_norm ? NORM_LAYER : NORM_RMS) : NORM_NONE;
+  const int rc = apply_adds(a, adds, &norm, "sd_norm_qkv_rope_adds");
+  if (rc != SD_OK) return rc;
   return linear_common(a, EPI_QKV_ROPE, norm, (hipStream_t)stream);
 }
 

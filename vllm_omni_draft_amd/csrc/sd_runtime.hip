@@ -127,7 +127,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, wide_ws, wide_ws_bytes, total;
+  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, wide_ws, wide_ws_bytes, slabs, acc, total;
 };
 
 // wide: the pass uses the 17..256-row linear kernels (and their partial-sum scratch).
@@ -159,6 +159,11 @@ Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int spli
     for (size_t n : need) w.wide_ws_bytes = n > w.wide_ws_bytes ? n : w.wide_ws_bytes;
   }
   w.wide_ws = off; off += align256(w.wide_ws_bytes);
+  // the three-launch draft layer: one f32 partial row per KV head and token row, and the f32
+  // accumulator of the down projection
+  const size_t fr = (size_t)(rows < SD_DRAFT_LAYER_MAX_ROWS ? rows : SD_DRAFT_LAYER_MAX_ROWS);
+  w.slabs = off; off += align256(fr * d.n_kv_heads * d.hidden * sizeof(float));
+  w.acc = off;   off += align256(fr * d.hidden * sizeof(float));
   w.total = off;
   return w;
 }
@@ -238,6 +243,46 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   const bool chain = a->chain_state && !wide && llama && !d.allreduce && !tree && !rpp &&
                      sd_fused_norm_fits(rows, H, false) &&
                      sd_chain_supported(rows, H, Hq * D, F) != 0;
+  // The draft model's three-launch layer: launch 1 here, launches 2 and 3 in sd_draft_layer.hip.
+  bool fused3 = a->draft_fused && !wide && llama && !d.allreduce && !tree && !rpp && !chain &&
+                !d.weight_fp8 && !a->input_embeds && sd_fused_norm_fits(rows, H, false) &&
+                sd_draft_layer_supported(rows, a->q_len, H, Hq, Hkv, D, F, a->max_ctx) != 0;
+  for (int li = 0; fused3 && li < d.n_layers; ++li)
+    fused3 = m->layers[li].down_w_km && !m->layers[li].qkv_b && !m->layers[li].o_b &&
+             !m->layers[li].up_b && !m->layers[li].down_b;
+  if (fused3) {
+    float* slabs = (float*)(base + w.slabs);
+    float* acc = (float*)(base + w.acc);
+    void* h_cur = h;
+    void* h_alt = xn;
+    for (int li = 0; li < d.n_layers; ++li) {
+      const sd_layer_weights& l = m->layers[li];
+      void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;
+      void* vc = (char*)kv->v_cache + (size_t)li * kv->layer_stride_bytes;
+      // 1. (h, the previous layer's down-projection sums) -> q, cache entries, new residual rows
+      const sd_row_adds in1{li ? acc : nullptr, H, h_alt};
+      SD_TRY(sd_norm_qkv_rope_adds(l.qkv_w, nullptr, h_cur, H, l.attn_norm_w, nullptr, d.norm_eps, 0,
+                                   nullptr, qkv, (int64_t)Hq * D, d.rope_cs, d.max_pos, kc, vc,
+                                   kv->block_tables, kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,
+                                   a->B, a->q_len, Hq, Hkv, D, H, nullptr, &in1, stream));
+      if (li) { void* t = h_cur; h_cur = h_alt; h_alt = t; }
+      // 2. attention + output projection -> one partial row per KV head; clears the accumulator
+      SD_TRY(sd_draft_attn_oproj(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables, kv->max_blocks_per_seq,
+                                 a->seq_lens, a->pos_offset, l.o_w, slabs, acc, rows * H, a->B,
+                                 a->q_len, Hq, Hkv, D, H, d.attn_scale, a->max_ctx, stream));
+      // 3. (h, the Hkv partial rows) -> new residual rows; MLP sums into the accumulator
+      SD_TRY(sd_draft_mlp(h_cur, H, slabs, Hkv, h_alt, l.mlp_norm_w, d.norm_eps, l.up_w, l.down_w_km,
+                          acc, rows, H, F, stream));
+      { void* t = h_cur; h_cur = h_alt; h_alt = t; }
+    }
+    if (a->logits) {
+      const int lm_vocab = d.lm_vocab > 0 ? d.lm_vocab : d.vocab;
+      const sd_row_adds fin{acc, H, nullptr};
+      SD_TRY(sd_norm_linear_adds(d.lm_head, nullptr, h_cur, H, d.final_norm_w, nullptr, d.norm_eps, 0,
+                                 nullptr, a->logits, lm_vocab, rows, lm_vocab, H, SD_EPI_F32, &fin, stream));
+    }
+    return SD_OK;
+  }
   for (int li = 0; li < d.n_layers; ++li) {
     const sd_layer_weights& l = m->layers[li];
     void* kc = (char*)kv->k_cache + (size_t)li * kv->layer_stride_bytes;

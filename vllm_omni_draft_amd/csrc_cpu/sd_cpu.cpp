@@ -1232,6 +1232,39 @@ extern "C" sd_ipc_comm* sd_ipc_comm_create(int, int, void* const*, size_t) {
   return nullptr;
 }
 extern "C" void sd_ipc_comm_destroy(sd_ipc_comm*) {}
+// the draft model's three-launch layer is a GPU-side launch optimisation: the CPU build runs
+// the ordinary layer (sd_forward_args.draft_fused is ignored) and refuses the kernels
+extern "C" int sd_draft_layer_supported(int, int, int, int, int, int, int, int) { return 0; }
+extern "C" int sd_draft_attn_oproj(const void*, int64_t, const void*, const void*, const int32_t*, int,
+                                   const int32_t*, int, const void*, float*, float*, int, int, int, int,
+                                   int, int, int, float, int, sd_stream_t) {
+  UNSUPPORTED("sd_draft_attn_oproj");
+}
+extern "C" int sd_draft_mlp(const void*, int64_t, const float*, int, void*, const void*, float, const void*,
+                            const void*, float*, int, int, int, sd_stream_t) {
+  UNSUPPORTED("sd_draft_mlp");
+}
+extern "C" int sd_norm_linear_adds(const void* W, const float* ws, const void* x, int64_t ldx,
+                                   const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                                   const void* bias, void* out, int64_t ldo, int M, int N, int K,
+                                   int epilogue, const sd_row_adds* adds, sd_stream_t stream) {
+  if (adds && adds->add) UNSUPPORTED("sd_norm_linear_adds");
+  return sd_norm_linear(W, ws, x, ldx, norm_w, norm_b, eps, layer_norm, bias, out, ldo, M, N, K, epilogue,
+                        stream);
+}
+extern "C" int sd_norm_qkv_rope_adds(const void* W, const float* ws, const void* x, int64_t ldx,
+                                     const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                                     const void* bias, void* q_out, int64_t ldq, const float* rope_cs,
+                                     int max_pos, void* k_cache, void* v_cache,
+                                     const int32_t* block_tables, int max_blocks_per_seq,
+                                     const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
+                                     int Hkv, int D, int K, const sd_rope_positions* rope_pos,
+                                     const sd_row_adds* adds, sd_stream_t stream) {
+  if (adds && adds->add) UNSUPPORTED("sd_norm_qkv_rope_adds");
+  return sd_norm_qkv_rope(W, ws, x, ldx, norm_w, norm_b, eps, layer_norm, bias, q_out, ldq, rope_cs,
+                          max_pos, k_cache, v_cache, block_tables, max_blocks_per_seq, seq_lens,
+                          pos_offset, B, q_len, Hq, Hkv, D, K, rope_pos, stream);
+}
 extern "C" int sd_ipc_comm_errors(sd_ipc_comm*, int*) { UNSUPPORTED("sd_ipc_comm_errors"); }
 extern "C" int sd_ipc_comm_set_timeout_ms(sd_ipc_comm*, int) { UNSUPPORTED("sd_ipc_comm_set_timeout_ms"); }
 extern "C" int sd_ipc_allreduce(void*, size_t, void*, sd_stream_t) { UNSUPPORTED("sd_ipc_allreduce"); }

@@ -90,6 +90,13 @@ class EngineConfig:
     # same proposals bit for bit, three launches per layer instead of five.  Off by default:
     # measured slower than the five launches on MI355X.
     draft_fused_pairs: bool = False
+    # Draft passes of <= 4 rows with every layer as THREE launches (attention + output projection
+    # in one, gate/up + down in one; DecoderModel fused_layers).  The draft's rows then differ
+    # from the five-launch layer's in the last bits (and from run to run: float atomics), which
+    # changes at most what is proposed, never what is emitted.  Off by default: measured on
+    # MI355X the three launches take as long as the five they replace (a 1B draft's layer:
+    # 11.5 vs 11.2 us and 23.7 vs 23.1 us for the two pairs).
+    draft_fused_layers: bool = False
 
 
 def acceptance_pattern(accept_prob: float, k: int, length: int = 16, rotate: int = 0) -> List[int]:
@@ -186,7 +193,9 @@ class SpecEngine:
             draft_wide = self.wide if cfg.draft_rows == "same" else cfg.draft_rows == "wide"
         self.draft = (DecoderModel(draft, self.max_ctx, cfg.draft_split_tokens or cfg.split_tokens,
                                    wide=draft_wide, tp_group=tp_group if draft_tp else None,
-                                   fused_pairs=cfg.draft_fused_pairs)
+                                   fused_pairs=cfg.draft_fused_pairs,
+                                   fused_layers=bool(cfg.draft_fused_layers) and not cfg.draft_fused_pairs
+                                   and not draft_tp)
                       if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self._lanes: List[torch.cuda.Stream] = []

@@ -29,7 +29,7 @@ def _ptr(t):
 class DecoderModel:
     def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
                  tp_group=None, wide: bool = False, wide_prefill: bool = True,
-                 fused_pairs: bool = False):
+                 fused_pairs: bool = False, fused_layers: bool = False):
         """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
@@ -50,10 +50,22 @@ class DecoderModel:
         self.max_ctx = max_ctx
         self.split_tokens = split_tokens
         lib = _lib.load()
+        # fused_layers (draft models): passes of up to ops.DRAFT_LAYER_MAX_ROWS rows run every
+        # layer as three launches (sd_draft_attn_oproj, sd_draft_mlp); they need the down
+        # projection's tiles a second time, ordered k-step first.  The rows differ from the
+        # five-launch layer's in the last bits, which a draft model may.
+        self.fused_layers = bool(
+            fused_layers and tp_group is None and not fp8 and cfg.arch == "llama" and not cfg.mrope_section
+            and not cfg.qkv_bias and ops.on_gpu()
+            and ops.draft_layer_supported(1, 1, cfg.hidden, cfg.n_heads, cfg.n_kv_heads, cfg.head_dim,
+                                          cfg.ffn, min(max_ctx, ops.DRAFT_LAYER_MAX_CTX)))
+        self._down_km = [ops.kmajor_tiles(l.down_w) for l in weights.layers] if self.fused_layers else None
         layers = (_lib.LayerWeights * cfg.n_layers)()
         for i, l in enumerate(weights.layers):
             for name, _ in _lib.LayerWeights._fields_:
-                if name.endswith("_s"):   # scale of the fp8 matrix of the same stem
+                if name == "down_w_km":
+                    setattr(layers[i], name, _ptr(self._down_km[i]) if self._down_km else None)
+                elif name.endswith("_s"):   # scale of the fp8 matrix of the same stem
                     setattr(layers[i], name, _ptr(getattr(l, name[:-2] + "_w").scale))
                 else:
                     setattr(layers[i], name, _ptr(getattr(l, name)))
@@ -156,7 +168,8 @@ class DecoderModel:
                                 logits=_ptr(logits), wide=int(self.wide if wide is None else wide),
                                 input_embeds=_ptr(input_embeds), rope_pos=_ptr(rope_pos),
                                 rope_delta=_ptr(rope_delta), tree_mask=_ptr(tree_mask),
-                                chain_state=_ptr(self.chain_state) if workspace is None else None)
+                                chain_state=_ptr(self.chain_state) if workspace is None else None,
+                                draft_fused=int(self.fused_layers))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
                                           ops._stream())

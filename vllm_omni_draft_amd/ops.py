@@ -825,6 +825,91 @@ def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache,
     return q
 
 
+# ---------------------------------------------------------------- the draft model's three-launch layer
+DRAFT_LAYER_MAX_ROWS = 4
+DRAFT_LAYER_MAX_CTX = 2048
+
+
+def draft_layer_supported(rows: int, q_len: int, hidden: int, n_heads: int, n_kv_heads: int,
+                          head_dim: int, ffn: int, max_ctx: int) -> bool:
+    return bool(_lib.load().sd_draft_layer_supported(rows, q_len, hidden, n_heads, n_kv_heads,
+                                                     head_dim, ffn, max_ctx))
+
+
+def kmajor_tiles(W: "TiledWeight") -> torch.Tensor:
+    """The SD_TILE_PLAIN tiles of a bf16 weight ordered k-step first ([K/32][N/16][64][8]): the
+    32 input columns a workgroup of sd_draft_mlp owns are then contiguous."""
+    if W.mode != TILE_PLAIN or W.scale is not None or W.data.dtype != torch.bfloat16:
+        raise _lib.SdError("kmajor_tiles: a bf16 weight tiled in TILE_PLAIN mode expected")
+    n_tiles, ks = (W.N + 15) // 16, W.K // 32
+    return W.data.view(n_tiles, ks, 512).transpose(0, 1).contiguous().view(-1)
+
+
+def norm_qkv_rope_adds(W, x, norm_w, eps, rope_cs, k_cache, v_cache, block_tables, seq_lens, pos_offset,
+                       B, q_len, Hq, Hkv, D, add=None, x_out=None) -> torch.Tensor:
+    """sd_norm_qkv_rope_adds: RMSNorm of bf16(x + add) -> QKV -> rotary -> cache append; x_out
+    (bf16 like x) receives x + add.  Returns rotated q."""
+    _need(x, torch.bfloat16, "x")
+    Wt = _tiled(W, EPI_STORE, head_dim=D)
+    M, K = x.shape
+    q = torch.empty(M, Hq * D, dtype=torch.bfloat16, device=x.device)
+    adds = None
+    if add is not None:
+        _need(add, torch.float32, "add")
+        adds = C.byref(_lib.RowAdds(add=_p(add), ld_add=add.shape[-1], x_out=_p(x_out)))
+    _lib.check(_lib.load().sd_norm_qkv_rope_adds(
+        _p(Wt.data), _p(Wt.scale), _p(x), K, _p(norm_w), None, float(eps), 0, None, _p(q), Hq * D,
+        _p(rope_cs), 0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache),
+        _p(block_tables), block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
+        None, adds, _stream()), "sd_norm_qkv_rope_adds")
+    return q
+
+
+def norm_linear_adds(W, x, norm_w, eps, add=None, x_out=None) -> torch.Tensor:
+    """sd_norm_linear_adds with the F32 epilogue (an LM head): logits of RMSNorm(bf16(x + add))."""
+    _need(x, torch.bfloat16, "x")
+    Wt = _tiled(W, EPI_F32)
+    M, K = x.shape
+    out = torch.empty(M, Wt.N, dtype=torch.float32, device=x.device)
+    adds = None
+    if add is not None:
+        _need(add, torch.float32, "add")
+        adds = C.byref(_lib.RowAdds(add=_p(add), ld_add=add.shape[-1], x_out=_p(x_out)))
+    _lib.check(_lib.load().sd_norm_linear_adds(
+        _p(Wt.data), _p(Wt.scale), _p(x), K, _p(norm_w), None, float(eps), 0, None, _p(out), Wt.N, M,
+        Wt.N, K, EPI_F32, adds, _stream()), "sd_norm_linear_adds")
+    return out
+
+
+def draft_attn_oproj(q, k_cache, v_cache, block_tables, seq_lens, pos_offset, o_w, B, q_len, Hq, Hkv, D,
+                     scale, max_ctx, zero: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sd_draft_attn_oproj: attention over the whole context + output projection; returns the
+    slabs [Hkv, B*q_len, H] f32 (one partial projection row per KV head).  zero: an f32 tensor
+    the launch clears."""
+    _need(q, torch.bfloat16, "q")
+    Wt = _tiled(o_w, EPI_STORE)
+    H = Wt.N
+    slabs = torch.empty(Hkv, B * q_len, H, dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().sd_draft_attn_oproj(
+        _p(q), q.shape[1], _p(k_cache), _p(v_cache), _p(block_tables), block_tables.shape[1],
+        _p(seq_lens), pos_offset, _p(Wt.data), _p(slabs), _p(zero), 0 if zero is None else zero.numel(),
+        B, q_len, Hq, Hkv, D, H, float(scale), max_ctx, _stream()), "sd_draft_attn_oproj")
+    return slabs
+
+
+def draft_mlp(h, add, norm_w, eps, up_w, down_km, acc, F: int, h_out=None) -> None:
+    """sd_draft_mlp: acc [M, H] f32 += down(silu(gate(n)) * up(n)), n = RMSNorm(bf16(h + sum of the
+    slabs add [n_add, M, H])); h_out receives bf16(h + sum)."""
+    _need(h, torch.bfloat16, "h")
+    _need(acc, torch.float32, "acc")
+    M, H = h.shape
+    Wu = _tiled(up_w, EPI_SILU_MUL)
+    n_add = 0 if add is None else add.shape[0]
+    _lib.check(_lib.load().sd_draft_mlp(
+        _p(h), H, _p(add), n_add, _p(h_out), _p(norm_w), float(eps), _p(Wu.data), _p(down_km), _p(acc),
+        M, H, F, _stream()), "sd_draft_mlp")
+
+
 # ---------------------------------------------------------------- fused two-layer launches
 def chain_state(hidden: int, device="cuda") -> torch.Tensor:
     """The device state of the fused launches below (sd_chain_state_init): tagged-word exchange

@@ -541,6 +541,10 @@ class SpecDecodeConfig:
     # that fraction of the head, the draft can only propose those tokens, the target still emits
     # any token (greedy decoding only).
     draft_vocab_subset: Optional[Sequence[int]] = None
+    # The draft's passes of up to 4 rows with every layer as three launches instead of five
+    # (EngineConfig.draft_fused_layers; measured no faster on MI355X, hence off).  The draft's
+    # rows then differ from the five-launch layer's in the last bits; what is emitted does not.
+    draft_fused_layers: bool = False
 
 
 @dataclass
@@ -679,7 +683,8 @@ class SpecDecodeWorker:
             disable_by_batch_size=c.speculative_disable_by_batch_size,
             acceptance_method=c.spec_decoding_acceptance_method,
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
-            posterior_alpha=c.typical_acceptance_sampler_posterior_alpha),
+            posterior_alpha=c.typical_acceptance_sampler_posterior_alpha,
+            draft_fused_layers=c.draft_fused_layers),
             tp_group=getattr(self, "tp_group", None), draft_tp=draft_tp)
         if tp > 1:
             # the ranks' kernels wait for each other with bounded waits: no rank may start a pass
