@@ -294,6 +294,116 @@ def attention_roofline(device, k):
             "bytes_per_launch": kv_bytes, "avg_us": round(us, 2)}
 
 
+def attention_roofline_headline(device, k, ctx, split_tokens, max_ctx):
+    """The verify attention as the headline step really launches it: one sequence, ctx cached
+    tokens, k+1 query rows, `split_tokens` keys per workgroup up to the context bucket max_ctx,
+    the split merge launch included; a replayed graph of 32 launches over 32 distinct caches
+    (Llama-3-8B head shape).  Latency-bound: a few MB of K/V over 40-64 workgroups."""
+    import ctypes as C
+    from vllm_omni_draft_amd import _lib, ops
+    Hq, Hkv, D, q_len, L = 32, 8, 128, k + 1, 32
+    pages = (max_ctx + 15) // 16
+    kcs = [(torch.randn(pages, Hkv, D * 16, device=device) * 0.5).to(torch.bfloat16) for _ in range(L)]
+    vcs = [(torch.randn(pages, Hkv, D * 16, device=device) * 0.5).to(torch.bfloat16) for _ in range(L)]
+    bt = torch.randperm(pages, device=device).to(torch.int32).view(1, pages).contiguous()
+    q = torch.randn(q_len, Hq * D, device=device).to(torch.bfloat16)
+    sl = torch.full((1,), ctx, dtype=torch.int32, device=device)
+    ws = torch.empty(ops.paged_attention_workspace_bytes(1, q_len, Hq, D, max_ctx, split_tokens),
+                     dtype=torch.uint8, device=device)
+    lib = _lib.load()
+    stream = torch.cuda.Stream()
+
+    def enqueue():
+        for kc, vc in zip(kcs, vcs):
+            ops.paged_attention(q, kc, vc, bt, sl, 0, 1, q_len, Hq, Hkv, D, D ** -0.5, max_ctx,
+                                split_tokens, workspace=ws)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        enqueue()
+        torch.cuda.synchronize()
+        g = C.c_void_p()
+        _lib.check(lib.sd_graph_begin(stream.cuda_stream), "sd_graph_begin")
+        enqueue()
+        _lib.check(lib.sd_graph_end(stream.cuda_stream, C.byref(g)), "sd_graph_end")
+        ts = []
+        for _ in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            lib.sd_graph_launch(g, stream.cuda_stream)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / L)
+        lib.sd_graph_destroy(g)
+    us = sorted(ts)[len(ts) // 2]
+    kv_bytes = (ctx + q_len) * Hkv * D * 2 * 2
+    gbs = kv_bytes / us * 1e-3
+    return {"kernel": f"paged_attn_kernel<D=128> + merge, B=1 ctx={ctx} q_len={q_len}, {split_tokens} keys per "
+                      f"workgroup, context bucket {max_ctx}", "bound": "hbm (latency-bound at this size)",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "bytes_per_launch": kv_bytes, "avg_us": round(us, 2)}
+
+
+def grid_point(tw, dw, B, prompt_len, k, steps, warmup, accept_prob, use_graph=True, temperature=0.0,
+               split_tokens=256):
+    """One more point of the measurement grid: B sequences with prompts of prompt_len random
+    tokens, autoregressive baseline on the same kernel family first (its stream is the truth the
+    acceptance schedule is imposed with), then the speculative run.  temperature > 0: seeded
+    sampling on both sides; acceptance cannot be imposed then (it is what random weights give)
+    and the streams are not comparable token for token."""
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    V = min(tw.cfg.vocab, dw.cfg.vocab)
+    g = torch.Generator().manual_seed(4321 + prompt_len + B)
+    prompts = [torch.randint(0, V, (prompt_len,), generator=g).tolist() for _ in range(B)]
+    n_new = (steps + warmup) * (k + 1) + 8
+    max_seq = prompt_len + n_new + 16
+    rows = "wide" if B * (k + 1) > 16 else "narrow"
+    sampling = temperature > 0.0
+
+    def run(eng, n_steps, n_warm):
+        kw = [dict(seed=1000 + i) if sampling else {} for i in range(B)]
+        t0 = time.perf_counter()
+        outs = [[eng.add_request(i, p, **kw[i])] for i, p in enumerate(prompts)]
+        torch.cuda.synchronize()
+        prefill = time.perf_counter() - t0
+        for _ in range(n_warm):
+            for o, new in zip(outs, eng.step()):
+                o.extend(new)
+        torch.cuda.synchronize()
+        n0 = sum(len(o) for o in outs)
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            for o, new in zip(outs, eng.step()):
+                o.extend(new)
+        torch.cuda.synchronize()
+        return outs, sum(len(o) for o in outs) - n0, time.perf_counter() - t0, prefill
+
+    common = dict(max_batch=B, max_seq_len=max_seq, rows=rows, gen_capacity=n_new + 64,
+                  use_graph=use_graph, temperature=temperature, split_tokens=split_tokens)
+    ar = SpecEngine(tw, None, EngineConfig(k=0, **common))
+    ar_steps = n_new - 8 - warmup if not sampling else steps * 2
+    ar_out, ar_n, ar_dt, _ = run(ar, ar_steps, warmup)
+    del ar
+    torch.cuda.empty_cache()
+    eng = SpecEngine(tw, dw, EngineConfig(k=k, **common))
+    if not sampling:
+        truth = torch.zeros(B, max_seq, dtype=torch.int32)
+        for b in range(B):
+            truth[b, :prompt_len] = torch.tensor(prompts[b])
+            truth[b, prompt_len:prompt_len + len(ar_out[b])] = torch.tensor(ar_out[b])
+        eng.set_synthetic_acceptance(truth.to(tw.embed.device), accept_prob, seed=-warmup,
+                                     pattern_len=min(steps, 64))
+    out, n, dt, prefill = run(eng, steps, warmup)
+    exact = None if sampling else all(o[:min(len(o), len(a))] == a[:min(len(o), len(a))]
+                                      for o, a in zip(out, ar_out))
+    del eng
+    torch.cuda.empty_cache()
+    return {"batch": B, "prompt_len": prompt_len, "k": k, "temperature": temperature, "kernel_family": rows,
+            "tokens_per_s": round(n / dt, 1), "ms_per_step": round(dt / steps * 1e3, 4),
+            "accept_len": round(n / steps / B - 1.0, 3), "ar_tokens_per_s": round(ar_n / ar_dt, 1),
+            "speedup_vs_ar": round(n / dt / (ar_n / ar_dt), 3), "spec_stream_equals_ar_stream": exact,
+            "prefill_s": round(prefill, 3)}
+
+
 def _check_attention(run, kc, vc, bt, q, seqs, ctx, q_len, Hq, Hkv, D):
     """Output rows of the timed attention launch against oracle.attention (the checker, on the
     CPU) for the sequences `seqs`.  Raises on a mismatch; returns True."""
@@ -671,6 +781,25 @@ def main():
                               r["tokens"] / r["seconds"] / ar_tps, 3), "exact": r["exact"]})
             del e2
             torch.cuda.empty_cache()
+    grid = {}
+    if not args.no_sweep and world == 1:
+        # the other points of the measurement grid, a few seconds each
+        bucket = args.split_tokens
+        while bucket < ctx_mid + k + 2:
+            bucket *= 2
+        grid["verify_attention_roofline_headline"] = attention_roofline_headline(
+            device, k, int(ctx_mid), args.split_tokens, bucket)
+        gs, gw = max(16, args.steps // 2), 4
+        grid["prompt_sweep"] = [grid_point(tw, dw, 1, n, k, gs, gw, args.accept_prob, not args.no_graph,
+                                           split_tokens=args.split_tokens) for n in (128, 4096)]
+        grid["batch8"] = grid_point(tw, dw, 8, args.prompt_len, k, gs, gw, args.accept_prob, not args.no_graph,
+                                    split_tokens=args.split_tokens)
+        t1 = grid_point(tw, dw, 1, args.prompt_len, k, gs, gw, args.accept_prob, not args.no_graph,
+                        temperature=1.0, split_tokens=args.split_tokens)
+        t1["note"] = ("temperature 1.0, seeded per-sequence streams, rejection sampling; acceptance is "
+                      "what seeded random weights give (near 0), so this point prices the sampling path's "
+                      "step (softmax, draws, rejection kernels), not a speed-up")
+        grid["sampling_t1"] = t1
     cpu = None
     if not args.no_cpu_baseline and world == 1:   # reported at N = 1 only
         try:
@@ -718,6 +847,10 @@ def main():
         "roofline": roof,
         "verify_attention_roofline": attn,
         "draft_pass_roofline": draft_pass,
+        "verify_attention_roofline_headline": grid.get("verify_attention_roofline_headline"),
+        "prompt_sweep": grid.get("prompt_sweep"),
+        "batch8": grid.get("batch8"),
+        "sampling_t1": grid.get("sampling_t1"),
         "accept_sweep": sweep,
         "cpu_baseline": cpu,
     }
