@@ -125,33 +125,55 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   const int xc = lane & 15, xq = lane >> 4;
   const bf16_t* xrow = xs + (size_t)(xc < M ? xc : M) * LDX + 8 * xq;           // LDS
   const bf16_t* xglob = a.x + (size_t)(xc < M ? xc : 0) * a.ldx + 8 * xq;        // DIRECT
-  const bool x_live = xc < M;
   // the grid is even in HALF mode, so a workgroup keeps one row half for all its units
   const int row_half = HALF ? (int)(blockIdx.x & 1) : 0;
-  const bool w_live = !HALF || ((lane >> 3) & 1) == row_half;
+  // Lanes whose output nobody reads (HALF: the other 8 rows of the tile; DIRECT: token
+  // columns >= M) ask for the address of a lane that is read, so every load of a segment is
+  // unconditional: a row of A only reaches its own output row, a column of B its own
+  // column, and a doubled address costs no memory traffic.
+  const int wlane = (HALF && ((lane >> 3) & 1) != row_half) ? lane ^ 8 : lane;
 
   // A fragments (and, DIRECT, B fragments) of this wave's next segment
   constexpr int kWLoads = W8 ? kSeg / 2 : kSeg;   // 16-byte loads per segment
   constexpr int kWSteps = W8 ? 2 : 1;             // k-steps per load
   bf16x8 nxt[kWLoads];
   bf16x8 nxt_x[DIRECT ? kSeg : 1];
-  auto load_seg = [&](int tile, int seg) {
+  auto seg_ptr = [&](int tile, int seg) {
     // 512 bf16 (1 KiB) per wave load either way
-    const bf16_t* p = a.W + ((size_t)tile * (KS / kWSteps) + (size_t)seg * kWLoads) * 512 + lane * 8;
+    return a.W + ((size_t)tile * (KS / kWSteps) + (size_t)seg * kWLoads) * 512 + wlane * 8;
+  };
+  auto load_whole_seg = [&](int tile, int seg) {  // all of the segment's k-steps exist
+    const bf16_t* p = seg_ptr(tile, seg);
+    const bf16_t* q = xglob + (size_t)seg * kSeg * 32;
 #pragma unroll
-    for (int j = 0; j < kWLoads; ++j) {
-      bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (seg * kSeg + j * kWSteps < KS && w_live)
-        v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + (size_t)j * 512));
-      nxt[j] = v;
-    }
+    for (int j = 0; j < kWLoads; ++j)
+      nxt[j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + (size_t)j * 512));
     if (DIRECT) {
 #pragma unroll
-      for (int j = 0; j < kSeg; ++j) {
+      for (int j = 0; j < kSeg; ++j)
+        nxt_x[DIRECT ? j : 0] = *reinterpret_cast<const bf16x8*>(q + (size_t)j * 32);
+    }
+  };
+  auto load_seg = [&](int tile, int seg) {
+    if (seg * kSeg + kSeg <= KS) {  // the usual case: nothing to check
+      load_whole_seg(tile, seg);
+    } else {
+      const bf16_t* p = seg_ptr(tile, seg);
+      const bf16_t* q = xglob + (size_t)seg * kSeg * 32;
+#pragma unroll
+      for (int j = 0; j < kWLoads; ++j) {
         bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (seg * kSeg + j < KS && x_live)
-          v = *reinterpret_cast<const bf16x8*>(xglob + (size_t)(seg * kSeg + j) * 32);
-        nxt_x[DIRECT ? j : 0] = v;
+        if (seg * kSeg + j * kWSteps < KS)
+          v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p + (size_t)j * 512));
+        nxt[j] = v;
+      }
+      if (DIRECT) {
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) {
+          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (seg * kSeg + j < KS) v = *reinterpret_cast<const bf16x8*>(q + (size_t)j * 32);
+          nxt_x[DIRECT ? j : 0] = v;
+        }
       }
     }
   };
@@ -163,6 +185,20 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   bf16_t* gs = reinterpret_cast<bf16_t*>(red);
   bf16_t* bs = gs + a.K;  // LayerNorm only
   float rs_m[2] = {0.f, 0.f}, mean_m[2] = {0.f, 0.f};  // rows wave, wave + 8
+  const int n_units = HALF ? 2 * a.n_tiles : a.n_tiles;
+  auto tile_of = [&](int unit) { return HALF ? unit >> 1 : unit; };
+  int unit = blockIdx.x;
+  // the wave's first segment: in flight while x is staged (a wave with no segment is never
+  // asked for its fragments)
+  const int first_tile = tile_of(min(unit, n_units - 1));
+  const int first_seg = max(min(wave, n_seg - 1), 0);
+  // With at most one row per wave and one 4096-column piece per row (and registers to
+  // spare: not LayerNorm, no additive input), every load of the staging is asked for before
+  // the wave's first weight segment and the segment before anything waits on the row: no
+  // wave's weights wait for a round trip.  Otherwise the segment follows part 1.
+  constexpr bool kStaged = !DIRECT && NORM != STAGE_ATTN_MERGE;
+  const bool early = kStaged && !ADD && NORM != NORM_LAYER && M <= kLinWaves && a.K <= 4096 &&
+                     KS % kSeg == 0 && KS > 0;
   if (NORM == STAGE_ATTN_MERGE) {
     // x[m][c] = (sum_s f_s o_s) / (sum_s f_s l_s), f_s = exp2(m_s - max m), splits in index
     // order: the arithmetic of the stand-alone merge kernel.  Every split's partial is
@@ -218,71 +254,108 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
       b_pre[i] = (NORM == NORM_LAYER && c < a.K && a.norm_b)
                      ? *reinterpret_cast<const bf16x8*>(a.norm_b + c) : z;
     }
+    // sums one 4096-column piece of row m into (s1, s2) and parks it raw in LDS
+    auto sum_park = [&](int m, int c0, bf16x8* v, f32x4 (*p)[2], float& s1, float& s2) {
+      bf16_t* xl = xs + (size_t)m * LDX;
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int m = wave + rr * kLinWaves;
-      if (m < M) {
-        const bf16_t* xr = a.x + (size_t)m * a.ldx;
-        bf16_t* xl = xs + (size_t)m * LDX;
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + i * 512 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (ADD && c < a.K) v[i][j] = (bf16_t)((float)v[i][j] + p[ADD ? i : 0][j >> 2][j & 3]);
+          const float f = (float)v[i][j];
+          s1 += f;
+          s2 += f * f;
+        }
+        if (c < a.K) {
+          *reinterpret_cast<bf16x8*>(xl + c) = v[i];
+          if (ADD && a.x_out && blockIdx.x == 0)
+            *reinterpret_cast<bf16x8*>(a.x_out + (size_t)m * a.ldx + c) = v[i];
+        }
+      }
+    };
+    // the row's scale (and mean) from its sums
+    auto row_stats = [&](int rr, int m, float s1, float s2) {
+      if (NORM == NORM_LAYER) {
+        // variance around the mean, from the parked values (same-wave LDS round trip)
+        const bf16_t* xl = xs + (size_t)m * LDX;
+        const float mean = wave_sum(s1) / (float)a.K;
+        float ss = 0.f;
+        for (int c = lane * 8; c < a.K; c += 512) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(xl + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float f = (float)v[j] - mean;
+            ss += f * f;
+          }
+        }
+        mean_m[rr] = mean;
+        rs_m[rr] = rsqrtf(wave_sum(ss) / (float)a.K + a.eps);
+      } else {
+        rs_m[rr] = rsqrtf(wave_sum(s2) / (float)a.K + a.eps);
+      }
+    };
+    auto park_params = [&]() {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid * 8 + i * kLinThreads * 8;
+        if (c < a.K) {
+          *reinterpret_cast<bf16x8*>(gs + c) = g_pre[i];
+          if (NORM == NORM_LAYER) *reinterpret_cast<bf16x8*>(bs + c) = b_pre[i];
+        }
+      }
+    };
+    if (early) {
+      // Straight-line, so that each wait below names exactly the loads it needs (they return
+      // in issue order): every wave asks for a row (waves without one for row 0, and pieces
+      // past K for the row's start: read and dropped).
+      bf16x8 v0[8];
+      const bf16_t* xr = a.x + (size_t)(wave < M ? wave : 0) * a.ldx;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = i * 512 + lane * 8;
+        v0[i] = *reinterpret_cast<const bf16x8*>(xr + (c < a.K ? c : 0));
+      }
+      load_whole_seg(first_tile, first_seg);
+      park_params();
+      if (wave < M) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i * 512 + lane * 8 >= a.K) v0[i] = z;
         float s1 = 0.f, s2 = 0.f;
-        for (int c0 = 0; c0 < a.K; c0 += 4096) {
-          bf16x8 v[8];
-          f32x4 p[ADD ? 8 : 1][2];
+        sum_park(wave, 0, v0, nullptr, s1, s2);
+        row_stats(0, wave, s1, s2);
+      }
+    } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int c = c0 + i * 512 + lane * 8;
-            v[i] = c < a.K ? *reinterpret_cast<const bf16x8*>(xr + c) : z;
-            if (ADD) {
-              const float* ar = a.add + (size_t)m * a.ld_add + (c < a.K ? c : 0);
-              p[ADD ? i : 0][0] = *reinterpret_cast<const f32x4*>(ar);
-              p[ADD ? i : 0][1] = *reinterpret_cast<const f32x4*>(ar + 4);
+      for (int rr = 0; rr < 2; ++rr) {
+        const int m = wave + rr * kLinWaves;
+        if (m < M) {
+          const bf16_t* xr = a.x + (size_t)m * a.ldx;
+          float s1 = 0.f, s2 = 0.f;
+          for (int c0 = 0; c0 < a.K; c0 += 4096) {
+            bf16x8 v[8];
+            f32x4 p[ADD ? 8 : 1][2];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int c = c0 + i * 512 + lane * 8;
+              v[i] = c < a.K ? *reinterpret_cast<const bf16x8*>(xr + c) : z;
+              if (ADD) {
+                const float* ar = a.add + (size_t)m * a.ld_add + (c < a.K ? c : 0);
+                p[ADD ? i : 0][0] = *reinterpret_cast<const f32x4*>(ar);
+                p[ADD ? i : 0][1] = *reinterpret_cast<const f32x4*>(ar + 4);
+              }
             }
+            sum_park(m, c0, v, p, s1, s2);
           }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int c = c0 + i * 512 + lane * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              if (ADD && c < a.K) v[i][j] = (bf16_t)((float)v[i][j] + p[ADD ? i : 0][j >> 2][j & 3]);
-              const float f = (float)v[i][j];
-              s1 += f;
-              s2 += f * f;
-            }
-            if (c < a.K) {
-              *reinterpret_cast<bf16x8*>(xl + c) = v[i];
-              if (ADD && a.x_out && blockIdx.x == 0)
-                *reinterpret_cast<bf16x8*>(a.x_out + (size_t)m * a.ldx + c) = v[i];
-            }
-          }
-        }
-        if (NORM == NORM_LAYER) {
-          // variance around the mean, from the parked values (same-wave LDS round trip)
-          const float mean = wave_sum(s1) / (float)a.K;
-          float ss = 0.f;
-          for (int c = lane * 8; c < a.K; c += 512) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xl + c);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float f = (float)v[j] - mean;
-              ss += f * f;
-            }
-          }
-          mean_m[rr] = mean;
-          rs_m[rr] = rsqrtf(wave_sum(ss) / (float)a.K + a.eps);
-        } else {
-          rs_m[rr] = rsqrtf(wave_sum(s2) / (float)a.K + a.eps);
+          row_stats(rr, m, s1, s2);
         }
       }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int c = tid * 8 + i * kLinThreads * 8;
-      if (c < a.K) {
-        *reinterpret_cast<bf16x8*>(gs + c) = g_pre[i];
-        if (NORM == NORM_LAYER) *reinterpret_cast<bf16x8*>(bs + c) = b_pre[i];
-      }
+      park_params();
     }
   }
+  if (!early) load_seg(first_tile, first_seg);
+  LSTAMP(1);
   // Part 2, while the first weight segment is in flight: scale the parked rows in place.
   auto finish_norm = [&]() {
     __syncthreads();  // norm parameters are in LDS
@@ -312,16 +385,6 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     __syncthreads();
   };
 
-  const int n_units = HALF ? 2 * a.n_tiles : a.n_tiles;
-  auto tile_of = [&](int unit) { return HALF ? unit >> 1 : unit; };
-  int unit = blockIdx.x;
-  if (wave < n_seg) {
-    load_seg(tile_of(min(unit, n_units - 1)), wave);  // in flight while x is staged
-  } else {
-#pragma unroll
-    for (int j = 0; j < kWLoads; ++j) nxt[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  }
-  LSTAMP(1);
   if (!DIRECT) finish_norm();
   LSTAMP(2);
 
@@ -399,20 +462,25 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
       if (seg + kLinWaves < n_seg) load_seg(tile, seg + kLinWaves);
       else if (next_unit < n_units) load_seg(tile_of(next_unit), wave);
       const bf16_t* xp = xrow + (size_t)seg * kSeg * 32;
-#pragma unroll
-      for (int j = 0; j < kSeg; ++j) {
-        if (seg * kSeg + j < KS) {
-          const bf16x8 b = DIRECT ? cur_x[DIRECT ? j : 0]
-                                  : *reinterpret_cast<const bf16x8*>(xp + j * 32);
-          bf16x8 w;
-          if constexpr (W8) {
-            const u32x4 raw = __builtin_bit_cast(u32x4, cur[j >> 1]);
-            w = fp8x8_to_bf16(raw[2 * (j & 1)], raw[2 * (j & 1) + 1]);
-          } else {
-            w = cur[j];
-          }
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc, 0, 0, 0);
+      auto step = [&](int j) {
+        const bf16x8 b = DIRECT ? cur_x[DIRECT ? j : 0]
+                                : *reinterpret_cast<const bf16x8*>(xp + j * 32);
+        bf16x8 w;
+        if constexpr (W8) {
+          const u32x4 raw = __builtin_bit_cast(u32x4, cur[j >> 1]);
+          w = fp8x8_to_bf16(raw[2 * (j & 1)], raw[2 * (j & 1) + 1]);
+        } else {
+          w = cur[j];
         }
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, b, acc, 0, 0, 0);
+      };
+      if (seg * kSeg + kSeg <= KS) {
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j) step(j);
+      } else {
+#pragma unroll
+        for (int j = 0; j < kSeg; ++j)
+          if (seg * kSeg + j < KS) step(j);
       }
     }
 
