@@ -83,6 +83,10 @@ def parse():
     ap.add_argument("--draft-layers", choices=["three", "five"], default="five",
                     help="five: the draft's passes on the five-launch layer (the target's kernels); "
                          "three: three launches per layer where the shapes allow it (measured no faster)")
+    ap.add_argument("--read-ahead-mb", default="0,0", metavar="TARGET,DRAFT",
+                    help="MiB of the next launches' weights that each layer's attention launch reads "
+                         "ahead on its idle compute units, for the target's and the draft's passes "
+                         "(EngineConfig.target_read_ahead_mb / draft_read_ahead_mb; same bits)")
     ap.add_argument("--layers", type=int, default=0, help="debug only: truncate both models")
     ap.add_argument("--cpu-baseline-worker", action="store_true",
                     help="internal: the child process of the cpu_baseline leg (SD_AMD_BACKEND=cpu)")
@@ -204,7 +208,7 @@ def kernel_roofline(eng, tw, rows, reps=3):
             "bytes_per_launch": bytes_per_launch, "avg_us": round(us, 2), "launches": n}
 
 
-def draft_pass_roofline(dw, device, ctx, split_tokens, fused_layers=False):
+def draft_pass_roofline(dw, device, ctx, split_tokens, fused_layers=False, read_ahead_mb=0):
     """One decode pass of the draft model (one row, `ctx` cached tokens, LM head included) in a
     replayed graph of four passes on a cache of its own: the bytes a pass must stream (every
     weight matrix once, the context's K/V once) over its duration.  The k passes of a step run
@@ -215,7 +219,7 @@ def draft_pass_roofline(dw, device, ctx, split_tokens, fused_layers=False):
     from vllm_omni_draft_amd.model_runner import DecoderModel
     cfg = dw.cfg
     max_ctx = ctx + 64
-    model = DecoderModel(dw, max_ctx, split_tokens, fused_layers=fused_layers)
+    model = DecoderModel(dw, max_ctx, split_tokens, fused_layers=fused_layers, read_ahead_mb=read_ahead_mb)
     kv = PagedKVCache(cfg, PagedKVCache.pages_for(cfg, 1, max_ctx), 1, max_ctx, device)
     kv.ensure_capacity(0, max_ctx)
     kv.k.normal_(0, 0.5)
@@ -659,6 +663,7 @@ def main():
 
     k = args.k
     fp8 = args.weights == "fp8"
+    ra_t, ra_d = (int(v) for v in args.read_ahead_mb.split(","))
     tw, data_kind = load_weights(args.target, 1, device, args.layers, fp8)
     dw, _ = load_weights(args.draft, 2, device, args.layers, fp8)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -669,6 +674,7 @@ def main():
 
     # 1) autoregressive baseline (k = 0) on the same kernels: the truth stream
     ar = SpecEngine(tw, None, EngineConfig(k=0, max_seq_len=max_seq, split_tokens=args.split_tokens,
+                                           target_read_ahead_mb=ra_t,
                                            use_graph=not args.no_graph, gen_capacity=n_truth + 64))
     ovl = args.read_back == "overlapped"
     ar_tokens, ar_n, ar_dt, ar_prefill = run_generation(ar, prompt, n_truth - 4 - args.warmup,
@@ -686,6 +692,7 @@ def main():
         eng = SpecEngine(tw, draft or dw, EngineConfig(k=k, max_seq_len=max_seq, split_tokens=args.split_tokens,
                                               draft_split_tokens=args.draft_split_tokens,
                                               draft_fused_layers=args.draft_layers == "three",
+                                              target_read_ahead_mb=ra_t, draft_read_ahead_mb=ra_d,
                                               use_graph=not args.no_graph, gen_capacity=n_truth + 64))
         # A fixed cyclic schedule decides how many proposals each step accepts (the timed
         # region covers whole cycles, so its accept-len is the schedule's mean, run after run);
@@ -729,7 +736,7 @@ def main():
     roof = kernel_roofline(eng, tw, k + 1)
     attn = attention_roofline(device, k)
     draft_pass = draft_pass_roofline(dw, device, int(ctx_mid), args.draft_split_tokens or args.split_tokens,
-                                     fused_layers=args.draft_layers == "three")
+                                     fused_layers=args.draft_layers == "three", read_ahead_mb=ra_d)
     sweep = []
     other_mode = None
     fp8_draft = None

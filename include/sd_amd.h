@@ -788,6 +788,12 @@ typedef struct {
    * (sd_norm_qkv_rope_adds, sd_draft_attn_oproj, sd_draft_mlp).  Logits differ from
    * the five-launch pass in the last bits: for draft models only.              */
   int draft_fused;
+  /* > 0: on the five-launch path of the narrow family, the idle compute units of every
+   * layer's attention launch read ahead up to this many MiB of the weights that the next
+   * launches stream (output projection, then gate/up), into the L2 of the XCD that will
+   * ask for them.  Results are unchanged (nothing is written); needs a KV-head count that
+   * is a multiple of 8, else ignored.                                          */
+  int read_ahead_mb;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

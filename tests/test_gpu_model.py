@@ -47,12 +47,12 @@ def _bf(state):
     return {k: v.to(torch.bfloat16).float() for k, v in state.items()}
 
 
-def _logits_via_engine(w, tokens, chunks, wide=False):
+def _logits_via_engine(w, tokens, chunks, wide=False, read_ahead_mb=0):
     """Feeds `tokens` through the native forward in the given chunk sizes."""
     from vllm_omni_draft_amd.kv_cache import PagedKVCache
     from vllm_omni_draft_amd.model_runner import DecoderModel
     cfg = w.cfg
-    model = DecoderModel(w, max_ctx=128, split_tokens=128, wide=wide)
+    model = DecoderModel(w, max_ctx=128, split_tokens=128, wide=wide, read_ahead_mb=read_ahead_mb)
     kv = PagedKVCache(cfg, 16, 1, 128, "cuda")
     kv.ensure_capacity(0, len(tokens))
     tok = torch.tensor(tokens, dtype=torch.int32, device="cuda")
@@ -147,6 +147,21 @@ def test_full_width_layers_against_the_oracle(pair, wide):
     assert _generate(eng, [toks], 24)[0] == ar
     m = eng.metrics()
     assert m["draft"] > 0 and m["emitted"] >= 24 - 1
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_weight_read_ahead_in_the_attention_launch_changes_no_bit(which):
+    """The read-ahead workgroups behind the attention grid only load: logits of prompt chunks,
+    decode tokens and a 6-row pass at Llama-3-8B / 3.2-1B width (8 KV heads: the workgroups know
+    their XCD) equal those of the plain launches bit for bit, for caps that end inside the
+    output projection, inside gate/up, and past both."""
+    cfg = FULL_WIDTH["llama3-8b+1b"][which]
+    w = _product(cfg, _bf(random_state(cfg, seed=33)))
+    toks = torch.randint(0, cfg.vocab, (20,), generator=torch.Generator().manual_seed(10)).tolist()
+    ref = _logits_via_engine(w, toks, [8, 1, 1, 6, 4])
+    for mb in (1, 24, 4096):
+        got = _logits_via_engine(w, toks, [8, 1, 1, 6, 4], read_ahead_mb=mb)
+        assert torch.equal(got, ref), mb
 
 
 @pytest.mark.parametrize("name", list(MODELS))

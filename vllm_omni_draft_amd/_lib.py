@@ -55,7 +55,7 @@ class ForwardArgs(C.Structure):
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
                 ("split_tokens", i32), ("logits", vp), ("wide", i32),
                 ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp),
-                ("chain_state", vp), ("draft_fused", i32)]
+                ("chain_state", vp), ("draft_fused", i32), ("read_ahead_mb", i32)]
 
 
 class UniformRegion(C.Structure):

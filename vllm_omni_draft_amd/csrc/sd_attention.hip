@@ -52,7 +52,53 @@ struct AttnArgs {
   // tree_mask[b * q_len + t] says that new token t of sequence b attends new token j (its
   // ancestors and itself; j <= t).  Keys before the first new token are seen by every row.
   const unsigned long long* tree_mask;
+  // Read-ahead of weights by workgroups with blockIdx.y >= n_splits (pf_rows rows of them).
+  const char* pf_base[2];
+  unsigned pf_tile_bytes[2], pf_units[2], pf_half[2];
+  int pf_rows;
 };
+
+// A read-ahead workgroup: touches 4 bytes of every 64 of its share of the units, so that they
+// sit in its XCD's L2 (and in the memory-side cache) when the launch that streams them starts.
+// Workgroups go round the XCDs in linear-id order and the grid's x extent is a multiple of 8
+// here, so blockIdx.x % 8 is this workgroup's XCD; it takes the units whose consumer
+// workgroup lands on the same XCD.  Nothing is written.
+__device__ __forceinline__ void read_ahead(const AttnArgs& a) {
+  const unsigned tid = threadIdx.x;
+  const unsigned xcd = blockIdx.x & 7;
+  const unsigned gx8 = gridDim.x >> 3;
+  const unsigned rank = (blockIdx.x >> 3) + gx8 * ((blockIdx.y - a.n_splits) + a.pf_rows * blockIdx.z);
+  const unsigned n_rank = gx8 * a.pf_rows * gridDim.z;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const char* base = a.pf_base[r];
+    if (!base) continue;
+    const unsigned tb = a.pf_tile_bytes[r], half = a.pf_half[r];
+    const unsigned pieces = (half ? tb / 2 : tb) / 64;  // 64-byte pieces of a unit
+    // this workgroup's units: those whose consumer sits on this XCD (u % 8 == xcd: the
+    // consumer's grid is a multiple of 8), dealt round the XCD's read-ahead workgroups
+    const unsigned n_units = a.pf_units[r];
+    const unsigned first = xcd + 8 * rank;
+    if (first >= n_units) continue;
+    const unsigned mine = (n_units - first + 8 * n_rank - 1) / (8 * n_rank);
+    const unsigned total = mine * pieces;
+    for (unsigned i0 = tid; i0 < total; i0 += 256 * 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        unsigned i = i0 + j * 256;
+        i = i < total ? i : i0;
+        const unsigned k = i / pieces, q = i - k * pieces;
+        const unsigned u = first + k * 8 * n_rank;
+        const char* t = base + (size_t)(half ? u >> 1 : u) * tb;
+        const size_t off = half ? (size_t)(q >> 1) * 256 + (u & 1) * 128 + (q & 1) * 64 : (size_t)q * 64;
+        v[j] = *reinterpret_cast<const unsigned*>(t + off);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(v[j]));
+    }
+  }
+}
 
 #ifdef SD_ATTN_STAMPS
 __device__ unsigned long long sd_stamps[16];
@@ -71,6 +117,10 @@ __device__ unsigned long long sd_stamps[16];
 // per launch).
 template <int D, int MT, int NBUF, int BT_PER_THREAD, bool RELOAD, bool TREE = false>
 __global__ __launch_bounds__(256, NBUF == 1 && MT == 1 ? 2 : 1) void paged_attn_kernel(AttnArgs a) {
+  if ((int)blockIdx.y >= a.n_splits) {
+    read_ahead(a);
+    return;
+  }
   STAMP(0);
   constexpr int KS = D / 16;  // k-steps of the K.Q^T product
   constexpr int DT = D / 32;  // 32-row tiles of O^T
@@ -496,8 +546,8 @@ int launch_attn_bt(const AttnArgs& a, int B, hipStream_t stream) {
     sd_set_error("sd_paged_attention: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
     return SD_ERR_HIP;
   }
-  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD, TREE>), dim3(a.Hkv, a.n_splits, B), dim3(256),
-                     lds, stream, a);
+  hipLaunchKernelGGL((paged_attn_kernel<D, MT, NBUF, BTP, RELOAD, TREE>),
+                     dim3(a.Hkv, a.n_splits + a.pf_rows, B), dim3(256), lds, stream, a);
   SD_CHECK_LAUNCH("sd_paged_attention");
   if (a.n_splits > 1 && a.out) {
     hipLaunchKernelGGL((attn_merge_kernel<D>), dim3(a.Hq, a.q_len, B), dim3(D), 0, stream, a,
@@ -544,7 +594,16 @@ int n_splits_for(int max_ctx, int split_tokens) {
   return max(1, (max_ctx + split_tokens - 1) / split_tokens);
 }
 
+// read-ahead asked for the next attention launch of this host thread
+thread_local sd_pf_range t_pf[2];
+thread_local int t_pf_n = 0;
+
 }  // namespace
+
+void sd_attn_prefetch_next(const sd_pf_range* r, int n) {
+  t_pf_n = n < 0 ? 0 : (n > 2 ? 2 : n);
+  for (int i = 0; i < t_pf_n; ++i) t_pf[i] = r[i];
+}
 
 #ifdef SD_ATTN_STAMPS
 extern "C" int sd_debug_read_stamps(unsigned long long* host) {
@@ -664,6 +723,29 @@ static int attention_launch(const void* q, int64_t ldq, const void* k_cache, con
   a.part_o = nullptr;
   a.part_ml = nullptr;
   a.tree_mask = (const unsigned long long*)tree_mask;
+  a.pf_rows = 0;
+  for (int r = 0; r < 2; ++r) {
+    a.pf_base[r] = nullptr;
+    a.pf_tile_bytes[r] = a.pf_units[r] = a.pf_half[r] = 0;
+  }
+  const int n_pf = t_pf_n;
+  t_pf_n = 0;
+  // Read-ahead workgroups fill the launch up to one workgroup per compute unit; they need the
+  // grid's x extent (Hkv) to be a multiple of 8 to know their XCD.
+  const long attn_wgs = (long)Hkv * a.n_splits * B * q_blocks;
+  if (n_pf > 0 && Hkv % 8 == 0 && attn_wgs <= 192) {
+    int used = 0;
+    for (int r = 0; r < n_pf; ++r) {
+      const sd_pf_range& f = t_pf[r];
+      if (!f.base || f.n_units == 0 || f.tile_bytes % 128 != 0 || f.consumer_grid % 8 != 0) continue;
+      a.pf_base[used] = (const char*)f.base;
+      a.pf_tile_bytes[used] = f.tile_bytes;
+      a.pf_units[used] = f.n_units;
+      a.pf_half[used] = f.half;
+      ++used;
+    }
+    if (used) a.pf_rows = (int)((256 - attn_wgs) / ((long)Hkv * B * q_blocks));
+  }
   SD_REQUIRE(out || a.n_splits > 1, SD_ERR_INVALID,
              "sd_paged_attention: out == NULL (partials only) needs more than one split");
   const int MT = q_len * G <= 32 ? 1 : 2;

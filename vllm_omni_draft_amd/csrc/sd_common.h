@@ -20,6 +20,20 @@ void sd_set_error(const char* fmt, ...);
 // True if sd_norm_linear / sd_norm_qkv_rope can hold M normalised rows of K columns in LDS.
 bool sd_fused_norm_fits(int M, int K, bool layer_norm);
 
+// Weight ranges that the idle compute units of an attention launch read ahead of the launches
+// that stream them (extra workgroups behind the attention grid): a matrix in 16-row tiles of
+// tile_bytes, its first n_units work units (tiles, or half tiles: the 128-byte halves of every
+// 256 bytes), unit u wanted by the XCD (u % consumer_grid) % 8.
+struct sd_pf_range {
+  const void* base;
+  unsigned tile_bytes, n_units, half, consumer_grid;
+};
+// The range sd_linear (and its fused-norm forms) reads first for this matrix, at most max_bytes.
+sd_pf_range sd_linear_pf_range(const void* W, int N, int K, int epi, int fp8, int fused_norm,
+                               size_t max_bytes);
+// Applies to the next attention launch of this host thread (then forgotten); n <= 2.
+void sd_attn_prefetch_next(const sd_pf_range* r, int n);
+
 #define SD_REQUIRE(cond, code, ...)            \
   do {                                         \
     if (!(cond)) {                             \

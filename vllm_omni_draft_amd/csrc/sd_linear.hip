@@ -651,6 +651,28 @@ int launch_n(LinArgs& a, int epi, hipStream_t st) {
   return SD_ERR_UNSUPPORTED;
 }
 
+}  // namespace
+
+// Mirrors launch_one / launch_w: which units the launch's workgroups ask for first.
+sd_pf_range sd_linear_pf_range(const void* W, int N, int K, int epi, int fp8, int fused_norm,
+                               size_t max_bytes) {
+  const bool paired = epi == SD_EPI_SILU_MUL || epi == EPI_QKV_ROPE;
+  const int n_tiles = paired ? (N + 7) / 8 : (N + 15) / 16;
+  const bool half = !paired && !fused_norm && n_tiles < 256;  // as launch_one decides
+  const unsigned tile_bytes = (unsigned)(16 * (size_t)K * (fp8 ? 1 : 2));
+  const unsigned n_units = half ? 2 * n_tiles : n_tiles;
+  const unsigned unit_bytes = half ? tile_bytes / 2 : tile_bytes;
+  sd_pf_range r;
+  r.base = W;
+  r.tile_bytes = tile_bytes;
+  r.half = half;
+  r.consumer_grid = n_units < 512 ? n_units : 512;
+  const size_t cap = max_bytes / unit_bytes;
+  r.n_units = (unsigned)(cap < n_units ? cap : n_units);
+  return r;
+}
+
+namespace {
 int linear_common(LinArgs& a, int epi, int norm, hipStream_t st) {
   SD_REQUIRE(a.W && a.x && a.out, SD_ERR_INVALID, "sd_linear: null pointer");
   SD_REQUIRE(a.M >= 0 && a.M <= 16, SD_ERR_UNSUPPORTED, "sd_linear: M=%d outside 0..16", a.M);

@@ -350,6 +350,16 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     const int n_splits = (a->max_ctx + a->split_tokens - 1) / a->split_tokens;
     const bool merge_in_proj = n_splits > 1 && n_splits <= 8 && rows * n_splits <= 16 &&
                                sd_fused_norm_fits(rows, Hq * D, false);
+    if (a->read_ahead_mb > 0 && !chain) {
+      // the attention launch's idle compute units fetch what the next two launches stream
+      const size_t cap = (size_t)a->read_ahead_mb << 20;
+      sd_pf_range pf[2];
+      pf[0] = sd_linear_pf_range(l.o_w, H, Hq * D, SD_EPI_RESIDUAL, l.o_s != nullptr, 0, cap);
+      const size_t took = (size_t)pf[0].n_units * (pf[0].half ? pf[0].tile_bytes / 2 : pf[0].tile_bytes);
+      pf[1] = sd_linear_pf_range(l.up_w, F, H, llama ? SD_EPI_SILU_MUL : SD_EPI_RELU,
+                                 l.up_s != nullptr, fuse, cap > took ? cap - took : 0);
+      sd_attn_prefetch_next(pf, 2);
+    }
     if (tree) {
       SD_TRY(sd_paged_attention_tree(qkv, (int64_t)Hq * D, kc, vc, kv->block_tables,
                                      kv->max_blocks_per_seq, a->seq_lens, a->pos_offset,

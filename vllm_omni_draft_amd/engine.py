@@ -97,6 +97,11 @@ class EngineConfig:
     # MI355X the three launches take as long as the five they replace (a 1B draft's layer:
     # 11.5 vs 11.2 us and 23.7 vs 23.1 us for the two pairs).
     draft_fused_layers: bool = False
+    # MiB of weights (output projection, then gate/up) that the idle compute units of each
+    # layer's attention launch read into L2 ahead of the launches that stream them, for the
+    # target's and the draft's narrow-family passes.  Same bits either way.
+    target_read_ahead_mb: int = 0
+    draft_read_ahead_mb: int = 0
 
 
 def acceptance_pattern(accept_prob: float, k: int, length: int = 16, rotate: int = 0) -> List[int]:
@@ -184,7 +189,7 @@ class SpecEngine:
             raise ValueError("rows must be 'auto', 'narrow' or 'wide'")
         self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * q_max > MAX_ROWS)
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
-                                   wide=self.wide)
+                                   wide=self.wide, read_ahead_mb=cfg.target_read_ahead_mb)
         if cfg.draft_rows not in ("auto", "same", "narrow", "wide"):
             raise ValueError("draft_rows must be 'auto', 'same', 'narrow' or 'wide'")
         if cfg.draft_rows == "auto":
@@ -195,7 +200,7 @@ class SpecEngine:
                                    wide=draft_wide, tp_group=tp_group if draft_tp else None,
                                    fused_pairs=cfg.draft_fused_pairs,
                                    fused_layers=bool(cfg.draft_fused_layers) and not cfg.draft_fused_pairs
-                                   and not draft_tp)
+                                   and not draft_tp, read_ahead_mb=cfg.draft_read_ahead_mb)
                       if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self._lanes: List[torch.cuda.Stream] = []

@@ -29,7 +29,8 @@ def _ptr(t):
 class DecoderModel:
     def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
                  tp_group=None, wide: bool = False, wide_prefill: bool = True,
-                 fused_pairs: bool = False, fused_layers: bool = False):
+                 fused_pairs: bool = False, fused_layers: bool = False,
+                 read_ahead_mb: int = 0):
         """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
@@ -49,6 +50,9 @@ class DecoderModel:
             raise ValueError(f"max_ctx {max_ctx} exceeds the model's max_pos {cfg.max_pos}")
         self.max_ctx = max_ctx
         self.split_tokens = split_tokens
+        # MiB of the next launches' weights that every layer's attention launch reads ahead on
+        # its idle compute units (sd_forward_args.read_ahead_mb); results do not change
+        self.read_ahead_mb = int(read_ahead_mb)
         lib = _lib.load()
         # fused_layers (draft models): passes of up to ops.DRAFT_LAYER_MAX_ROWS rows run every
         # layer as three launches (sd_draft_attn_oproj, sd_draft_mlp); they need the down
@@ -169,7 +173,8 @@ class DecoderModel:
                                 input_embeds=_ptr(input_embeds), rope_pos=_ptr(rope_pos),
                                 rope_delta=_ptr(rope_delta), tree_mask=_ptr(tree_mask),
                                 chain_state=_ptr(self.chain_state) if workspace is None else None,
-                                draft_fused=int(self.fused_layers))
+                                draft_fused=int(self.fused_layers),
+                                read_ahead_mb=int(self.read_ahead_mb))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
                                           ops._stream())
