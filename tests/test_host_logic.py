@@ -95,9 +95,10 @@ class FakeEngine:
         self.owners = []
         self.steps = 0
 
-    def add_request(self, slot, prompt):
+    def add_request(self, slot, prompt, decoded_from=None):
         assert slot == self.active
         self.prompts = getattr(self, "prompts", []) + [list(prompt)]
+        self.decoded_from = getattr(self, "decoded_from", []) + [decoded_from]
         self.owners.append(prompt[0])
         self.active += 1
         return prompt[0] * 100
@@ -475,10 +476,10 @@ def test_worker_accepts_the_v1_scheduler_output():
 class _PieceEngine(FakeEngine):
     """FakeEngine with piecewise prefill: the last piece admits the sequence."""
 
-    def prefill_begin(self, prompt):
+    def prefill_begin(self, prompt, decoded_from=None):
         self._pending = getattr(self, "_pending", {})
         h = len(self._pending) + 1
-        self._pending[h] = [list(prompt), 0]
+        self._pending[h] = [list(prompt), 0, decoded_from]
         return h
 
     def prefill_advance(self, h, n):
@@ -488,7 +489,7 @@ class _PieceEngine(FakeEngine):
         if p[1] < len(p[0]):
             return None
         del self._pending[h]
-        return self.add_request(self.active, p[0])
+        return self.add_request(self.active, p[0], decoded_from=p[2])
 
     def prefill_abort(self, h):
         del self._pending[h]
@@ -518,6 +519,7 @@ def test_a_skipped_request_returns_whole_and_a_preempted_one_in_pieces(old_layou
     out = w.execute_model(so)
     assert not w._parked and not w._prefill_of and eng.owners == [1, 2]
     assert eng.prompts[-1] == w._tokens["b"][:n_b]         # rebuilt whole from prompt + emitted
+    assert eng.decoded_from[-1] == 4 and eng.decoded_from[:2] == [None, None]   # its own tokens start at 4
     assert len(out.sampled_token_ids[1]) == 1              # and it emitted in that step
     # a real preemption: recomputed from position 0 in the scheduler's pieces
     w.execute_model(S(cached=["a"]))
@@ -530,6 +532,7 @@ def test_a_skipped_request_returns_whole_and_a_preempted_one_in_pieces(old_layou
     so.num_scheduled_tokens["b"] = n_b - 3
     out = w.execute_model(so)
     assert len(out.sampled_token_ids[1]) == 1 and not w._prefill_of and eng.owners == [1, 2]
+    assert eng.decoded_from[-1] == 4                       # the pieces carry it too
     # resumed with prefix-cache hits: refused, nothing ran, the request stays parked
     w.execute_model(S(cached=["a"]))
     steps = eng.steps

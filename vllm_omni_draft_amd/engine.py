@@ -430,7 +430,7 @@ class SpecEngine:
                     truth_row: Optional[Sequence[int]] = None,
                     seed: Optional[int] = None, temperature: Optional[float] = None,
                     top_k: int = 0, top_p: float = 1.0, min_p: float = 0.0,
-                    bias: Optional[dict] = None) -> int:
+                    bias: Optional[dict] = None, decoded_from: Optional[int] = None) -> int:
         """Prefills both models with `prompt` into batch slot `slot`, emits the
         first token from the target and returns it (this synchronises).
         Multimodal prompts (multimodal.prepare_prompt builds both): input_embeds
@@ -446,7 +446,10 @@ class SpecEngine:
         top_p / min_p filter the target distribution the request samples from (0 / 1.0 / 0.0: off).
         bias: the request's logit mask, {"logit_bias": {token: value}, "allowed_token_ids": [...],
         "bad_token_ids": [...]} (any subset), added to the target's logits before every argmax /
-        softmax of the request (see _set_bias)."""
+        softmax of the request (see _set_bias).  decoded_from (a sequence that is being rebuilt
+        from its own tokens): the position of the first token that decode passes produced; the
+        tokens from there on are recomputed by passes of the family and shape limits of a decode
+        pass, so that their cache entries get the bits they had (see _prefill_range)."""
         with _rt.stream_ctx(self.stream):
             if truth_row is not None:
                 if self.truth is None:
@@ -455,7 +458,8 @@ class SpecEngine:
                 self.truth[slot, :row.numel()].copy_(row)
             self._set_temperature(slot, temperature, top_k, top_p, min_p)
             self._set_bias(slot, bias)
-            return self._add_request(slot, prompt, input_embeds, rope_positions, seed)
+            return self._add_request(slot, prompt, input_embeds, rope_positions, seed,
+                                     decoded_from=decoded_from)
 
     def _bias_row(self, spec: Optional[dict]) -> Optional[torch.Tensor]:
         """The f32 row [V] of a request's logit mask, or None if it has none.  allowed_token_ids
@@ -549,7 +553,8 @@ class SpecEngine:
     # ---- prompts prefilled in pieces (a scheduler with chunked prefill)
     def prefill_begin(self, prompt: Sequence[int], seed: Optional[int] = None,
                       temperature: Optional[float] = None, top_k: int = 0, top_p: float = 1.0,
-                      min_p: float = 0.0, bias: Optional[dict] = None) -> int:
+                      min_p: float = 0.0, bias: Optional[dict] = None,
+                      decoded_from: Optional[int] = None) -> int:
         """Reserves a batch slot for a text prompt that will be prefilled piece by piece and
         returns its handle.  The sequence joins the batch when prefill_advance has consumed the
         whole prompt; until then steps of the active sequences go on as usual."""
@@ -564,7 +569,8 @@ class SpecEngine:
         slot = max(s for s in range(self.active, self.cfg.max_batch) if s not in used)
         h, self._next_handle = self._next_handle, self._next_handle + 1
         self._prefilling[h] = dict(prompt=[int(t) for t in prompt], done=0, slot=slot, seed=seed,
-                                   sampling=(temperature, top_k, top_p, min_p), bias=bias)
+                                   sampling=(temperature, top_k, top_p, min_p), bias=bias,
+                                   decoded_from=decoded_from)
         with _rt.stream_ctx(self.stream):
             self.t_kv.ensure_capacity(slot, n + self._slack)
             if self.d_kv is not None:
@@ -603,8 +609,10 @@ class SpecEngine:
                 temperature, top_k, top_p, min_p = e["sampling"]
                 self._set_temperature(self.active, temperature, top_k, top_p, min_p)
                 self._set_bias(self.active, e["bias"])
-                return self._add_request(self.active, prompt, seed=e["seed"], start=done)
-            self._prefill_range(e["slot"], prompt, done, end, final=False)
+                return self._add_request(self.active, prompt, seed=e["seed"], start=done,
+                                         decoded_from=e["decoded_from"])
+            self._prefill_range(e["slot"], prompt, done, end, final=False,
+                                decoded_from=e["decoded_from"])
             e["done"] = end
             return None
 
@@ -631,10 +639,15 @@ class SpecEngine:
                 e["slot"] = free[-1]
 
     def _prefill_range(self, slot: int, prompt: Sequence[int], c_from: int, c_to: int, final: bool,
-                       rope_positions=None, input_embeds=None) -> None:
+                       rope_positions=None, input_embeds=None, decoded_from: Optional[int] = None) -> None:
         """Passes over prompt tokens c_from..c_to-1 of the sequence in `slot` (both models, chunks
         of prefill_rows tokens on the wide family).  final: c_to is the prompt's end; its last
-        token gets a pass of its own whose logits (target) land in t_out[0]."""
+        token gets a pass of its own whose logits (target) land in t_out[0].
+        decoded_from: tokens from this position on were first computed by decode passes (the
+        sequence is being rebuilt from its own output): a model whose decode passes run on the
+        narrow family recomputes them in narrow passes of at most a decode pass's rows.  A narrow
+        row's bits depend on nothing else in its pass, so the cache entries equal those the
+        decode passes wrote, whatever the grouping was then."""
         n = len(prompt)
         self.prompt_buf[c_from:c_to].copy_(torch.tensor(list(prompt[c_from:c_to]), dtype=torch.int32))
         self._ctx = self._ctx_bucket(n + self._slack)
@@ -646,9 +659,15 @@ class SpecEngine:
             # only the last token's logits are needed, so the prompt ends with a 1-token pass
             chunk = model.prefill_rows
             wide = chunk > MAX_ROWS or self.wide
-            bounds = list(range(c_from, body_end, chunk)) + ([body_end] if final else [])
-            ends = bounds[1:] + [c_to]
-            for c0, c1 in zip(bounds, ends):
+            narrow_from = n if decoded_from is None or model.wide else max(int(decoded_from), 0)
+            narrow_rows = min(MAX_ROWS, 64 // (model.cfg.n_heads // model.cfg.n_kv_heads))
+            wide_end = min(body_end, narrow_from)
+            passes = [(c0, min(c0 + chunk, wide_end), wide) for c0 in range(c_from, wide_end, chunk)]
+            passes += [(c0, min(c0 + narrow_rows, body_end), False)
+                       for c0 in range(max(c_from, wide_end), body_end, narrow_rows)]
+            if final:
+                passes.append((body_end, c_to, wide and narrow_from >= n))
+            for c0, c1, family_wide in passes:
                 if c1 <= c0:
                     continue
                 want = final and c1 == n and model is self.target
@@ -659,10 +678,11 @@ class SpecEngine:
                 if input_embeds is not None and model is self.target:
                     mm["input_embeds"] = input_embeds[c0:c1].contiguous()
                 model.forward(view, self.prompt_buf, 0, c0, zl, c0, 1, c1 - c0,
-                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=wide, **mm)
+                              self.t_out[:c1 - c0] if want else None, self._ctx, wide=family_wide, **mm)
 
     def _add_request(self, slot: int, prompt: Sequence[int], input_embeds=None,
-                     rope_positions=None, seed: Optional[int] = None, start: int = 0) -> int:
+                     rope_positions=None, seed: Optional[int] = None, start: int = 0,
+                     decoded_from: Optional[int] = None) -> int:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
         n = len(prompt)
@@ -689,7 +709,7 @@ class SpecEngine:
         self.rope_delta[slot] = delta
         # (start > 0: the tokens before it went through prefill_advance already)
         self._prefill_range(slot, prompt, start, n, final=True, rope_positions=rope_positions,
-                            input_embeds=input_embeds)
+                            input_embeds=input_embeds, decoded_from=decoded_from)
         # first generated token from the last prompt row (a 1-token pass: row 0)
         self._apply_bias(1, 1, slot0=slot)
         if self.sampling:

@@ -90,6 +90,10 @@ class SequenceGroupMetadata:
     # is then the caller's own piece size).
     resumed_from_preemption: Optional[bool] = None
     num_computed_tokens: Optional[int] = None
+    # Set by the worker on the prompt-shaped request that rebuilds a parked sequence: the
+    # position of the first token the sequence emitted (the length of its original prompt).
+    # Tokens from there on are recomputed the way decode passes computed them.
+    decoded_from: Optional[int] = None
 
 
 @dataclass
@@ -751,7 +755,9 @@ class SpecDecodeWorker:
     def _rebuilt(self, g: SequenceGroupMetadata) -> SequenceGroupMetadata:
         """The prompt-shaped request that rebuilds a parked sequence named again by the step:
         prompt + emitted tokens, prefilled whole (it then emits a token in this step) or, when
-        the scheduler recomputes it from position 0 in pieces, in those pieces."""
+        the scheduler recomputes it from position 0 in pieces, in those pieces.  The tokens it
+        emitted are recomputed by decode-shaped passes (decoded_from), so a greedy stream goes
+        on bit for bit as if the sequence had never left."""
         rid = g.request_id
         first, toks = self._request[rid], self._tokens[rid]
         piece = g.num_prompt_tokens
@@ -772,7 +778,8 @@ class SpecDecodeWorker:
                                    & 0x7FFFFFFFFFFFFFFF})
         return SequenceGroupMetadata(
             rid, True, list(toks), sp, multi_modal_data=first.multi_modal_data,
-            num_prompt_tokens=piece if piece is not None and 1 <= piece < len(toks) else None)
+            num_prompt_tokens=piece if piece is not None and 1 <= piece < len(toks) else None,
+            decoded_from=len(first.prompt_token_ids))
 
     def _plan_step(self, req: ExecuteModelRequest) -> "_StepPlan":
         """Sorts the step's requests into what happens to them and validates all of it; nothing
@@ -918,7 +925,7 @@ class SpecDecodeWorker:
         while i < len(prompts):
             j = i
             while (j < len(prompts) and not mm_inputs[prompts[j].request_id]
-                   and hasattr(eng, "add_requests")):
+                   and prompts[j].decoded_from is None and hasattr(eng, "add_requests")):
                 j += 1
             if j - i >= 2:
                 group = prompts[i:j]
@@ -936,6 +943,8 @@ class SpecDecodeWorker:
                           min_p=sp0.min_p) if seeded else {}
                 if _bias_of(sp0):
                     kw["bias"] = _bias_of(sp0)
+                if group[0].decoded_from is not None:
+                    kw["decoded_from"] = group[0].decoded_from
                 firsts = [eng.add_request(eng.active, group[0].prompt_token_ids,
                                           **mm_inputs[group[0].request_id], **kw)]
             for n, (g, first) in enumerate(zip(group, firsts)):
@@ -957,6 +966,8 @@ class SpecDecodeWorker:
                       min_p=sp.min_p) if seeded else {}
             if _bias_of(sp):
                 kw["bias"] = _bias_of(sp)
+            if g.decoded_from is not None:
+                kw["decoded_from"] = g.decoded_from
             self._prefill_of[g.request_id] = eng.prefill_begin(g.prompt_token_ids, **kw)
             self._prefill_left[g.request_id] = len(g.prompt_token_ids)
         for g in plan.pieces + plan.continued:
