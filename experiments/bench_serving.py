@@ -1,7 +1,9 @@
 """Continuous batching end to end (config 3's shape): N requests arrive at t0 with ragged prompts
 (64..1024 tokens, seed 7), each generates 256 tokens, at most 32 run at once; the scheduler admits
 waiting requests as slots free up.  Output tokens/s of the whole job, prefill included:
-autoregressive, speculative, and speculative switched off above a batch threshold.  Random
+autoregressive, speculative, and speculative under the engine's own policy (speculative_policy=
+"auto": per step, whichever of the two kinds of step has been yielding more tokens per second at
+the current batch size); THRESHOLDS=1 adds fixed batch thresholds.  Random
 weights: as in the other benches every proposal is replaced by the target's own token with
 probability 0.8 (the autoregressive run provides each request's stream).
     python experiments/bench_serving.py [n_requests] [max_num_seqs] [max_tokens]
@@ -39,10 +41,11 @@ class Worker(SpecDecodeWorker):
         return {} if row is None else {"truth_row": row}
 
 
-def run(name, k, disable=0, truth=None):
+def run(name, k, disable=0, truth=None, policy="always"):
     w = Worker(SpecDecodeConfig(target=tw, draft=dw if k else None, num_speculative_tokens=k,
                                           max_num_seqs=S, max_model_len=1024 + T + 8,
                                           speculative_disable_by_batch_size=disable,
+                                          speculative_policy=policy,
                                           rows="wide" if S > 2 else "auto"))
     w.init_device()
     w.load_model()
@@ -69,6 +72,11 @@ def run(name, k, disable=0, truth=None):
     acc = m["accepted"] / max(m["draft"], 1)
     print(f"{name}: {n} tokens in {dt:.2f} s = {n / dt:.0f} tok/s, {sched.steps - steps0} steps, "
           f"draft acceptance {acc:.2f}", flush=True)
+    if policy == "auto":
+        for B, st in sorted(w.engine.policy_state().items()):
+            if st["t_spec"] and st["t_ar"]:
+                print(f"    B={B}: spec {st['t_spec'] * 1e3:.2f} ms x {st['emitted'] or 0:.2f} tok, "
+                      f"plain {st['t_ar'] * 1e3:.2f} ms -> {st['mode']}", flush=True)
     out = [r.output_token_ids for r in reqs]
     del sched, w
     torch.cuda.empty_cache()
@@ -77,6 +85,9 @@ def run(name, k, disable=0, truth=None):
 
 base = run("autoregressive      ", 0)
 spec = run("speculative k=5     ", 5, truth=base)
-half = run("k=5, off above 8 seq", 5, disable=8, truth=base)
-mid = run("k=5, off above 16   ", 5, disable=16, truth=base)
-print("streams equal:", base == spec == half == mid)
+auto = run("k=5, policy auto   ", 5, truth=base, policy="auto")
+print("streams equal:", base == spec == auto)
+if os.environ.get("THRESHOLDS"):
+    half = run("k=5, off above 8 seq", 5, disable=8, truth=base)
+    mid = run("k=5, off above 16   ", 5, disable=16, truth=base)
+    print("streams equal:", base == half == mid)

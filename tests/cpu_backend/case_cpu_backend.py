@@ -179,6 +179,49 @@ def test_prompts_prefilled_together_give_the_streams_of_one_at_a_time():
     assert run(True) == run(False)
 
 
+def _policy_run(SpecEngine, EngineConfig, w, d, prompts, n_new, **kw):
+    """Three sequences; the second leaves half-way and another prompt takes its place."""
+    eng = SpecEngine(w, d, EngineConfig(max_batch=3, max_seq_len=140, split_tokens=128, **kw))
+    outs = {i: [eng.add_request(i, p)] for i, p in enumerate(prompts[:3])}
+    owner = [0, 1, 2]
+    modes, swapped = [], False
+    while min(len(outs[i]) for i in owner) < n_new:
+        for slot, new in enumerate(eng.step()):
+            outs[owner[slot]].extend(new)
+        modes.append(eng._spec_disabled())
+        if not swapped and len(outs[1]) >= n_new // 2:
+            swapped = True
+            eng.remove_request(1)                 # the last sequence moves into slot 1
+            owner = [0, 2]
+            outs[3] = [eng.add_request(2, prompts[3])]
+            owner.append(3)
+    return {i: o[:n_new] for i, o in outs.items()}, modes, eng
+
+
+def test_the_speculation_policy_changes_no_greedy_stream():
+    """spec_policy="auto" with a probe every 3 steps: the engine keeps switching between
+    speculative steps and plain target steps that leave the draft out; the draft's cache is
+    caught up in between (also for a one-token prompt and a sequence admitted mid-way).  Every
+    stream is the autoregressive one, both kinds of step ran, and with draft == target nearly
+    every proposal is accepted (the draft's cache is intact after every catch-up)."""
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=128, n_heads=4, n_kv_heads=2, head_dim=64, ffn=256,
+                      vocab=256, max_pos=160)
+    w = _product(oc, _bf(random_state(oc, seed=3)))
+    rng = np.random.default_rng(5)
+    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in (9, 1, 30, 3)]
+    want, _, _ = _policy_run(SpecEngine, EngineConfig, w, None, prompts, 40, k=0)
+    got, modes, eng = _policy_run(SpecEngine, EngineConfig, w, w, prompts, 40, k=3, spec_policy="auto",
+                                  policy_probe_every=3, policy_probe_steps=2)
+    assert got[0] == want[0] and got[2] == want[2] and got[3][:20] == want[3][:20]
+    assert got[1][:len(want[1]) // 2] == want[1][:len(want[1]) // 2]
+    assert any(modes) and not all(modes)
+    m = eng.metrics()
+    assert m["draft"] > 0 and m["accepted"] >= 0.9 * m["draft"], m
+    st = eng.policy_state()
+    assert all(v["t_spec"] and v["t_ar"] for v in st.values() if v["t_spec"] is not None), st
+
+
 def test_token_trees_on_the_cpu_build():
     """Multi-candidate verification through the CPU build: the host's tree construction and
     lookup equal the oracle's, and the stream is the autoregressive one."""

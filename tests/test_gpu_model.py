@@ -852,6 +852,33 @@ def test_disable_by_batch_size_keeps_streams_and_draft_cache(use_graph):
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("rows", ["narrow", "wide"])
+def test_the_speculation_policy_changes_no_greedy_stream(use_graph, rows):
+    """spec_policy="auto" with a probe every 3 steps: the engine keeps switching between
+    speculative steps and plain target steps that leave the draft out; the draft's cache is
+    caught up by a wide pass in between (also for a one-token prompt and a sequence admitted
+    mid-way).  Every stream is the autoregressive one on both kernel families, both kinds of step
+    ran, and with draft == target nearly every proposal is accepted (the draft's cache is intact
+    after every catch-up; the wide pass rounds differently, so not necessarily all)."""
+    from tests.cpu_backend.case_cpu_backend import _policy_run
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    tcfg = MODELS["llama"]
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    rng = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(0, tcfg.vocab, (n,), generator=rng).tolist() for n in (9, 1, 30, 3)]
+    want, _, _ = _policy_run(SpecEngine, EngineConfig, tw, None, prompts, 40, k=0, rows=rows,
+                             use_graph=use_graph)
+    got, modes, eng = _policy_run(SpecEngine, EngineConfig, tw, tw, prompts, 40, k=3, rows=rows,
+                                  use_graph=use_graph, spec_policy="auto", policy_probe_every=3,
+                                  policy_probe_steps=2)
+    assert got[0] == want[0] and got[2] == want[2] and got[3][:20] == want[3][:20]
+    assert got[1][:20] == want[1][:20]
+    assert any(modes) and not all(modes)
+    m = eng.metrics()
+    assert m["draft"] > 0 and m["accepted"] >= 0.85 * m["draft"], m
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
 def test_narrow_draft_sub_batches_on_parallel_streams(use_graph):
     """20 sequences: the narrow draft's passes run as sub-batches of 16 rows on parallel
     streams (forked and joined inside the step).  The stream equals the autoregressive one and

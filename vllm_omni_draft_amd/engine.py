@@ -71,6 +71,20 @@ class EngineConfig:
     # speculate): one target token per sequence, and one draft pass that only keeps the
     # draft's KV cache in step (upstream's speculative_disable_by_batch_size).
     disable_by_batch_size: int = 0
+    # "always": every step speculates (unless disable_by_batch_size says no).  "auto": the engine
+    # times its own steps per batch size in both modes (wall clock from one step's start to the
+    # next one's, so the host's share counts; intervals with an admission, a removal or a graph
+    # capture in them are left out) and speculates in a step only while tokens per second of
+    # speculative steps (emitted per step / step time, running means) beat the plain target step's; the other mode is probed for policy_probe_steps
+    # steps every policy_probe_every steps, so a change in acceptance or context is noticed.
+    # Steps that do not speculate then leave the draft out altogether: its cache is brought up
+    # to date by one wide pass over the missing tokens every few steps and before the next
+    # speculative step.  Greedy streams do not depend on the choice; a seeded sampling stream
+    # does (the modes draw different numbers of uniforms).  Draft-model proposals only (no
+    # trees, no host-made proposals), one rank only.
+    spec_policy: str = "always"
+    policy_probe_every: int = 96
+    policy_probe_steps: int = 2
     # Acceptance rule under sampling (temperature > 0): "rejection_sampler" (lossless,
     # Leviathan et al.) or "typical_acceptance_sampler" (a proposal stands if the target gives
     # it more than min(posterior_threshold, posterior_alpha * exp(-entropy)); the first
@@ -315,6 +329,21 @@ class SpecEngine:
         self._parity = 0
         self._inflight = None   # (event, record parity, sequences) of a step not yet read back
         self._steps_pending = 0               # steps enqueued since the last read-back
+        # speculate-or-not policy (EngineConfig.spec_policy)
+        if cfg.spec_policy not in ("always", "auto"):
+            raise ValueError("spec_policy must be 'always' or 'auto'")
+        self._auto = (cfg.spec_policy == "auto" and self.draft is not None and not self.tree
+                      and not self.host_props)
+        if self._auto and tp_group is not None:
+            raise ValueError("spec_policy='auto' times the steps of one rank: not with tensor parallelism")
+        self._lazy_draft = self._auto      # steps that do not speculate leave the draft out
+        self._lag = 0                      # such steps since the draft cache was last complete
+        self._lag_max = min(8, self._slack + 1)   # (positions a catch-up pass may touch stay allocated)
+        self._no_spec_now = False          # this step's decision
+        self._pol: dict = {}               # batch size -> running means, see _decide_no_spec
+        self._last_start = None            # (wall clock, batch size, mode) of the last step's start
+        self._clean = False                # nothing but that step happened since (no admission, no capture)
+        self._arange = torch.arange(16, dtype=torch.int32, device=dev)
         self.sampling = cfg.temperature > 0.0
         if self.sampling:
             f32 = dict(dtype=torch.float32, device=dev)
@@ -384,6 +413,7 @@ class SpecEngine:
 
     def _reset(self) -> None:
         self._inflight = None
+        self._lag, self._no_spec_now, self._last_start, self._clean = 0, False, None, False
         for b in range(self.cfg.max_batch):
             self.t_kv.release(b)
             if self.d_kv is not None:
@@ -589,6 +619,7 @@ class SpecEngine:
         if e is None:
             raise KeyError(f"no prompt is being prefilled under handle {handle}")
         prompt, done = e["prompt"], e["done"]
+        self._clean = False
         n = len(prompt)
         if n_tokens < 1 or done + n_tokens > n:
             raise ValueError(f"{n_tokens} tokens asked for, {n - done} of the prompt remain")
@@ -685,6 +716,7 @@ class SpecEngine:
                      decoded_from: Optional[int] = None) -> int:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
+        self._clean = False
         n = len(prompt)
         if n < 1 or n + 1 > self.cfg.max_seq_len:
             raise ValueError(f"prompt length {n} outside 1..{self.cfg.max_seq_len - 1}")
@@ -775,6 +807,7 @@ class SpecEngine:
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
         Bp, slot0 = len(prompts), self.active
+        self._clean = False
         if Bp == 0:
             return []
         if slot0 + Bp + len(self._prefilling) > self.cfg.max_batch:
@@ -1049,15 +1082,99 @@ class SpecEngine:
                                      0, self._records[self._parity, :B])
 
     def _spec_disabled(self) -> bool:
+        """Whether the current step (the last one _prepare_step prepared) leaves speculation out."""
+        if self._auto:
+            return self._no_spec_now
         t = self.cfg.disable_by_batch_size
         return self.k > 0 and t > 0 and self.active > t
+
+    # -- speculate or not, step by step (spec_policy="auto") ---------------------------------
+    def _decide_no_spec(self) -> bool:
+        """True if the coming step should not speculate.  Per batch size the engine keeps running
+        means of the step time in both modes and of the tokens a speculative step emits per
+        sequence; the mode with the higher tokens per second runs, the other one is probed
+        now and then."""
+        t = self.cfg.disable_by_batch_size
+        if t > 0 and self.active > t:
+            return True
+        st = self._pol.setdefault(self.active, {"t": {}, "n": {"spec": 0, "ar": 0}, "emit": None,
+                                                "mode": "spec", "run": 0, "probe": 0})
+        if st["probe"] > 0:                     # a probe of the other mode is under way
+            st["probe"] -= 1
+            return st["mode"] == "spec"
+        if st["n"]["spec"] < 3:
+            return False
+        if st["n"]["ar"] < 3:
+            return True
+        rate_spec = (st["emit"] or 1.0) / st["t"]["spec"]
+        rate_ar = 1.0 / st["t"]["ar"]
+        best = "spec" if rate_spec >= rate_ar else "ar"
+        if best != st["mode"] and max(rate_spec, rate_ar) > 1.03 * min(rate_spec, rate_ar):
+            st["mode"], st["run"] = best, 0
+        st["run"] += 1
+        if st["run"] >= self.cfg.policy_probe_every:
+            st["run"] = 0
+            st["probe"] = max(self.cfg.policy_probe_steps - 1, 0)
+            return st["mode"] == "spec"
+        return st["mode"] == "ar"
+
+    def _note_step_time(self, B: int, mode: str, seconds: float) -> None:
+        st = self._pol.get(B)
+        if st is None:
+            return
+        old = st["t"].get(mode)
+        st["t"][mode] = seconds if old is None else 0.7 * old + 0.3 * seconds
+        st["n"][mode] += 1
+
+    def _note_emitted(self, B: int, out: List[List[int]], spec: bool) -> None:
+        st = self._pol.get(B)
+        if st is None or not spec or not out:
+            return
+        e = sum(len(o) for o in out) / len(out)
+        st["emit"] = e if st["emit"] is None else 0.8 * st["emit"] + 0.2 * e
+
+    def policy_state(self) -> dict:
+        """The policy's running means per batch size (seconds per step in both modes, tokens a
+        speculative step emits per sequence, the mode that currently runs)."""
+        return {B: {"t_spec": st["t"].get("spec"), "t_ar": st["t"].get("ar"), "emitted": st["emit"],
+                    "mode": st["mode"]} for B, st in self._pol.items()}
+
+    def _draft_catch_up(self) -> None:
+        """Brings the draft's cache up to date after steps that left the draft out: one pass over
+        the last _lag_max positions before the two that every proposal pass re-feeds anyway
+        (never before a sequence's first generated token: the prompt is always complete).
+        Positions that were valid are written again with the same tokens; rows of a young
+        sequence that reach past its end write slots that are rewritten before anything reads
+        them.  Token ids come from the generated-token log on the device; positions from the
+        device's lengths, so a step still in flight does not matter."""
+        B, L = self.active, self._lag_max
+        if B == 0 or self.draft is None:
+            self._lag = 0
+            return
+        model = self.draft
+        plen = self.seq_lens[:B] - self.gen_counts[:B]
+        base = torch.maximum(self.seq_lens[:B] - (L + 2), plen).contiguous()
+        gi = (base - plen).unsqueeze(1) + self._arange[:L].unsqueeze(0)
+        toks = self.gen_tokens[:B].gather(1, gi.clamp_(0, self.gen_tokens.shape[1] - 1).long())
+        toks = toks.to(torch.int32).contiguous()
+        wide = model.prefill_rows > MAX_ROWS or model.wide
+        rows_cap = model.prefill_rows if wide else model.max_rows
+        q_cap = max(1, 64 // (model.cfg.n_heads // model.cfg.n_kv_heads))
+        for b0 in range(0, B, min(B, rows_cap)):
+            nb = min(min(B, rows_cap), B - b0)
+            q_chunk = max(1, min(rows_cap // nb, q_cap, L))
+            delta = self.rope_delta[b0:] if model.cfg.mrope_section else None
+            for c in range(0, L, q_chunk):
+                model.forward(_KvView(self.d_kv, b0), toks.view(-1)[b0 * L:], L, c, base[b0:], c, nb,
+                              min(q_chunk, L - c), None, self._ctx, wide=wide, rope_delta=delta)
+        self._lag = 0
 
     def _enqueue_no_spec_step(self) -> None:
         """A step of a speculative engine that does not speculate (batch above
         disable_by_batch_size): the target scores the last token only; the draft re-feeds the
         last two tokens without its LM head, so its KV cache stays complete."""
         B, k = self.active, self.k
-        if self.draft is not None:
+        if self.draft is not None and not self._lazy_draft:   # (lazy: _draft_catch_up, later)
             self._forward(self.draft, self.d_kv, self.tok_buf, k + 2, 0, self.seq_lens, -2, B, 2, None)
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, 1,
                       self.t_out)
@@ -1252,6 +1369,7 @@ class SpecEngine:
         that active sequences stay contiguous (synchronises)."""
         if self._inflight is not None:
             raise RuntimeError("flush() the step in flight before changing the batch")
+        self._clean = False
         with _rt.stream_ctx(self.stream):
             last = self.active - 1
             if not 0 <= slot <= last:
@@ -1370,6 +1488,12 @@ class SpecEngine:
             self.prop_lens.copy_(self._lens_host, non_blocking=True)
         if self.sampling:
             self._refresh_uniforms()
+        if self._auto:
+            self._no_spec_now = self._decide_no_spec()
+            if self._lag and (not self._no_spec_now or self._lag >= self._lag_max):
+                self._draft_catch_up()
+            if self._no_spec_now:
+                self._lag += 1
 
     def finish_step(self) -> List[List[int]]:
         """After a step's kernels were enqueued piecewise: reads the emitted
@@ -1385,6 +1509,13 @@ class SpecEngine:
         if B == 0:
             return [] if sync else None
         self._prepare_step()
+        if self._auto:
+            import time
+            now = time.perf_counter()
+            if self._last_start is not None and self._clean:
+                self._note_step_time(self._last_start[1], self._last_start[2], now - self._last_start[0])
+            self._last_start = (now, B, "ar" if self._no_spec_now else "spec")
+            self._clean = True
         stream = ops._stream()
         lib = _lib.load()
         if self.cfg.use_graph and _rt.on_gpu():   # (the CPU build has no stream capture)
@@ -1403,6 +1534,7 @@ class SpecEngine:
                     rc = lib.sd_graph_end(stream, C.byref(g))
                 _lib.check(rc, "sd_graph_end")
                 self._graphs[key] = g
+                self._clean = False           # (a capture is no sample of the step's time)
                 # the captured step has not run: the warm-up step is this call's step
             else:
                 _lib.check(lib.sd_graph_launch(g, stream), "sd_graph_launch")
@@ -1437,7 +1569,7 @@ class SpecEngine:
             self._step(False)
             ev = torch.cuda.Event()
             ev.record()
-            self._inflight = (ev, self._parity, self.active)
+            self._inflight = (ev, self._parity, self.active, not self._no_spec_now)
             return None if prev is None else self._collect(prev, 1)
 
     def flush(self) -> Optional[List[List[int]]]:
@@ -1466,7 +1598,7 @@ class SpecEngine:
                                    "are dropped")
 
     def _collect(self, step, later_steps: int) -> List[List[int]]:
-        ev, parity, B = step
+        ev, parity, B = step[:3]
         ev.synchronize()
         self._check_exchanges()
         rec = self._records[parity, :B].tolist()
@@ -1478,6 +1610,8 @@ class SpecEngine:
             self.host_gen[b] += n
             # exact after that step, plus the bound of the steps enqueued since
             self.host_lens[b] = rec[b][1] + later_steps * (self.k + 1)
+        if self._auto:
+            self._note_emitted(B, out, step[3])
         return out
 
     def _ctx_bucket(self, need: Optional[int] = None) -> int:
@@ -1528,6 +1662,8 @@ class SpecEngine:
                     self.history[b].extend(out[-1])
             if self.logprobs_top is not None:
                 self._emitted_logprobs(out)
+            if self._auto:
+                self._note_emitted(B, out, not self._no_spec_now)
             return out
         if self.logprobs_top is not None and pending > 1:
             raise RuntimeError("log-probabilities need a read-back after every step (the logits of "

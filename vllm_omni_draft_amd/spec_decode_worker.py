@@ -505,6 +505,10 @@ class SpecDecodeConfig:
     rows: str = "auto"             # kernel family, see EngineConfig.rows
     draft_rows: str = "auto"       # the draft's kernel family, see EngineConfig.draft_rows
     speculative_disable_by_batch_size: int = 0   # 0 = speculate at every batch size
+    # "always", or "auto": the engine times its own steps and speculates in a step only while
+    # that yields more tokens per second than the plain target step at the current batch size
+    # (EngineConfig.spec_policy); speculative_disable_by_batch_size stays a hard upper bound.
+    speculative_policy: str = "always"
     spec_decoding_acceptance_method: str = "rejection_sampler"  # or "typical_acceptance_sampler"
     typical_acceptance_sampler_posterior_threshold: float = 0.09
     typical_acceptance_sampler_posterior_alpha: float = 0.3
@@ -685,6 +689,7 @@ class SpecDecodeWorker:
             external_proposals=c.external_proposals,
             tree_candidates=c.speculative_tree_candidates, tree_nodes=c.speculative_tree_nodes,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
+            spec_policy=c.speculative_policy,
             acceptance_method=c.spec_decoding_acceptance_method,
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
             posterior_alpha=c.typical_acceptance_sampler_posterior_alpha,
@@ -1027,8 +1032,9 @@ class SpecDecodeWorker:
     def _run_speculative_decoding_step(self, req: ExecuteModelRequest) -> List[List[int]]:
         """propose -> score -> verify, as one replayed graph when enabled."""
         eng = self.engine
-        if self._foreign_proposer is None and (eng.cfg.use_graph or eng._spec_disabled()):
-            return eng.step()
+        if self._foreign_proposer is None and (eng.cfg.use_graph or eng._spec_disabled()
+                                               or getattr(eng, "_auto", False)):
+            return eng.step()        # (a policy engine decides inside the step whether to speculate)
         eng.prepare_step()
         proposals = self.proposer.get_spec_proposals(req, frozenset())
         scores = self.scorer.score_proposals(req, proposals)
