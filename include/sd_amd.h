@@ -470,6 +470,31 @@ int sd_qkv_rope_wide(const void* W, const float* w_scale, const void* x, int64_t
                      int K, const sd_rope_positions* rope_pos, void* workspace,
                      size_t workspace_bytes, sd_stream_t stream);
 
+/* fp8 activations for the wide family (opt-in; fp8 weight tiles only, K % 128 == 0):
+ * sd_row_scales_fp8 leaves, for each of M token rows of x, scales[m] = max |x[m]| / 448 and
+ * scales[M + m] = 448 / max |x[m]| (both 1 for a row of zeros; scales: 2*M floats);
+ * sd_linear_wide_a8 / sd_qkv_rope_wide_a8 are sd_linear_wide / sd_qkv_rope_wide with the
+ * rows quantised on their way into LDS, q = e4m3(clamp(x * scales[M + m], +-448)), round to
+ * nearest even, the products on the fp8 matrix instruction of gfx950
+ * (v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales) and a sum multiplied by
+ * scales[m] and the weight row's scale before the epilogue.  Epilogues: all but RELU and
+ * GELU_TANH.  A row's result depends on that row, N and K only.  Workspace as for the
+ * bf16-activation forms.  No counterpart in the reference (it names "fp8 weights (CDNA4 fp8
+ * MFMA)" for its Qwen2-VL configuration without code for it).                          */
+int sd_row_scales_fp8(const void* x, int64_t ldx, int M, int K, float* scales,
+                      sd_stream_t stream);
+int sd_linear_wide_a8(const void* W, const float* w_scale, const float* x_scales,
+                      const void* x, int64_t ldx, const void* bias, const void* residual,
+                      void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                      void* workspace, size_t workspace_bytes, sd_stream_t stream);
+int sd_qkv_rope_wide_a8(const void* W, const float* w_scale, const float* x_scales,
+                        const void* x, int64_t ldx, const void* bias, void* q_out,
+                        int64_t ldq, const float* rope_cs, int max_pos, void* k_cache,
+                        void* v_cache, const int32_t* block_tables, int max_blocks_per_seq,
+                        const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
+                        int Hkv, int D, int K, const sd_rope_positions* rope_pos,
+                        void* workspace, size_t workspace_bytes, sd_stream_t stream);
+
 /* Output projection straight from attention partials: sd_paged_attention with
  * out == NULL (and more than one split) leaves its per-split partials in the
  * workspace; this linear merges them while it stages its activations (same
@@ -794,6 +819,11 @@ typedef struct {
    * ask for them.  Results are unchanged (nothing is written); needs a KV-head count that
    * is a multiple of 8, else ignored.                                          */
   int read_ahead_mb;
+  /* != 0: passes of the wide family over a model whose matrices are all fp8 (and whose
+   * hidden, query and ffn widths are multiples of 128) quantise their activations to fp8 per
+   * token row (sd_row_scales_fp8 + the _a8 linear layers, LM head included).  Changes the
+   * rounding of those passes: choose it for all wide passes of a model or none.          */
+  int wide_a8;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,

@@ -176,6 +176,11 @@ def test_fused_qkv_rope_append_matches_unfused(Hq, Hkv, D, H, rope):
 
 
 # ------------------------------------------------------------------ fp8 weights
+def _lib_error():
+    from vllm_omni_draft_amd._lib import SdError
+    return SdError
+
+
 def _fp8_pow2(W):
     """(fp8 values, power-of-two f32 scale per row, the bf16 matrix they stand for exactly)."""
     Wf = W.float()
@@ -337,6 +342,126 @@ def test_fp8_wide_qkv_rope_matches_bf16_wide():
     for a, b in zip(*outs):
         assert torch.equal(a, b)
     assert outs[0][1].abs().sum() > 0
+
+
+# ------------------------------------------------------------------ fp8 activations (W8A8)
+def _quantise_rows(x, scales=None):
+    """The oracle's activation quantisation: per row, q = e4m3(clamp(x * (448 / amax), +-448))
+    (round to nearest even), scale = amax / 448.  scales ([2, M], the library's): quantise with
+    those factors (the two divisions may differ from torch's in the last bit)."""
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    ok = amax > 0
+    inv = torch.where(ok, 448.0 / amax, torch.ones_like(amax))
+    scale = torch.where(ok, amax / 448.0, torch.ones_like(amax))
+    if scales is not None:
+        scale, inv = scales[0], scales[1]
+    q = (xf * inv[:, None]).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    return q, scale, inv
+
+
+def test_row_scales_fp8_match_the_oracle():
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.randn(70, 1024, generator=gen, device="cuda") * 3.0).to(torch.bfloat16)
+    x[5] = 0
+    x[9] *= 1e-3
+    got = ops.row_scales_fp8(x)
+    _, scale, inv = _quantise_rows(x)
+    assert torch.allclose(got[0], scale, rtol=3e-7, atol=0) and torch.allclose(got[1], inv, rtol=3e-7, atol=0)
+    assert got[0][5].item() == 1.0 and got[1][5].item() == 1.0
+
+
+@pytest.mark.parametrize("M", [17, 50, 128, 192, 256])
+@pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (96, 14336), (20480, 256), (2048, 896)])
+def test_w8a8_wide_linear_against_the_quantising_oracle(M, N, K):
+    """fp8 weights x fp8 activations on the fp8 matrix instruction, against the f64 sum of the same
+    quantised operands.  Stated tolerance: the instruction aligns the 128 products of a step to
+    the largest one and drops what falls below about 2^-21 of it (measured: exact on small
+    integers, up to 27 on sums whose largest product is 1.2e5 over K = 512), so an output may be
+    off by K * 2^-20 * (largest |x_q| of the row) * (largest |w_q| of the weight row) in units of
+    the two scales; the quantisation itself (3 mantissa bits) is two orders above that.  Through
+    split-K partial sums and the direct epilogue, the epilogues the path has, biases, ragged N."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    x = (torch.randn(M, K, generator=gen, device="cuda") * 2.0).to(torch.bfloat16)
+    x[1] *= 30.0
+    x[2] = 0
+    bias = (torch.randn(2 * N, generator=gen, device="cuda") * 0.1).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=gen, device="cuda").to(torch.bfloat16)
+    W2 = (torch.randn(2 * N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    W2[3] *= 37.0
+    q2, s2 = ops.quantize_fp8(W2)
+    xq, xs, _ = _quantise_rows(x, ops.row_scales_fp8(x))
+    ref2 = (xq.double() @ q2.double().T) * xs.double()[:, None] * s2.double()[None, :]
+    tol = (K * 2.0 ** -20 * xq.double().abs().amax(dim=1)[:, None] * q2.double().abs().amax(dim=1)[None, :]
+           * xs.double()[:, None] * s2.double()[None, :]) + 1e-30
+    Wt = ops.tile_weights(q2[:N].contiguous(), ops.TILE_PLAIN, scale=s2[:N].contiguous())
+    ref, tol2, tol = ref2[:, :N], tol, tol[:, :N]
+    y = ops.linear_wide(Wt, x, None, None, ops.EPI_F32, fp8_activations=True)
+    assert ((y.double() - ref).abs() <= tol).all(), ((y.double() - ref).abs() / tol).max().item()
+    yb = ops.linear_wide(Wt, x, bias[:N].contiguous(), None, ops.EPI_F32, fp8_activations=True)
+    assert ((yb.double() - ref - bias[:N].double()).abs() <= tol + 1e-6 * (1 + ref.abs())).all()
+    # bf16 epilogues: the f32 result rounded as the bf16-activation kernels round theirs
+    st = ops.linear_wide(Wt, x, None, None, ops.EPI_STORE, fp8_activations=True)
+    assert torch.equal(st, y.to(torch.bfloat16))
+    rs = ops.linear_wide(Wt, x, None, res, ops.EPI_RESIDUAL, fp8_activations=True)
+    assert torch.equal(rs, (y.to(torch.bfloat16).float() + res.float()).to(torch.bfloat16))
+    Wg = ops.tile_weights(q2, ops.TILE_GATED, scale=s2)
+    g = ops.linear_wide(Wg, x, None, None, ops.EPI_SILU_MUL, fp8_activations=True).float()
+    gr, ur = ref2[:, :N].float(), ref2[:, N:].float()
+    want = torch.nn.functional.silu(gr) * ur
+    err = (g - want).abs()      # bf16 roundings of gate, silu, up and the product, plus the sums' tolerance
+    bound = 0.02 * want.abs() + 2.0 * (tol2[:, :N] * ur.abs() + tol2[:, N:] * gr.abs()).float() + 1e-6
+    assert (err <= bound).all(), (err / bound).max().item()
+    # a row's result does not depend on what shares the pass
+    if M >= 50:
+        part = ops.linear_wide(Wt, x[:33].contiguous(), None, None, ops.EPI_F32, fp8_activations=True)
+        assert torch.equal(part, y[:33])
+    with pytest.raises(_lib_error()):
+        ops.linear_wide(Wt, x, None, None, ops.EPI_RELU, fp8_activations=True)
+
+
+def test_w8a8_wide_needs_fp8_weights_and_whole_chunks():
+    ops = _ops()
+    x = torch.randn(32, 192, device="cuda").to(torch.bfloat16)
+    W = torch.randn(64, 192, device="cuda").to(torch.bfloat16)
+    with pytest.raises(_lib_error()):
+        ops.linear_wide(ops.tile_weights(W), x, fp8_activations=True)          # bf16 weights
+    q, s = ops.quantize_fp8(W)
+    with pytest.raises(_lib_error()):
+        ops.linear_wide(ops.tile_weights(q, scale=s), x, fp8_activations=True)   # K % 128 != 0
+
+
+def test_w8a8_wide_qkv_rope_against_the_bf16_activation_form():
+    """The rotary QKV launch with fp8 activations: q and the cache entries stay within the
+    quantisation error of the bf16-activation launch on the same fp8 weights (one part in 16
+    of a row's largest value, e4m3's 3-bit mantissa), and every cache slot that one writes the
+    other writes too."""
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    gen = torch.Generator(device="cuda").manual_seed(29)
+    Hq, Hkv, D, H, B, q_len = 4, 2, 64, 256, 6, 5
+    M = B * q_len
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=128)
+    cs = rope_table(cfg).cuda()
+    x = torch.randn(M, H, generator=gen, device="cuda").to(torch.bfloat16)
+    Wq = (torch.randn((Hq + 2 * Hkv) * D, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    qq, sq = ops.quantize_fp8(Wq)
+    bias = (0.1 * torch.randn((Hq + 2 * Hkv) * D, generator=gen, device="cuda")).to(torch.bfloat16)
+    bt = torch.arange(B * 3, dtype=torch.int32, device="cuda").view(B, 3)
+    seq_lens = torch.tensor([17, 30, 3, 9, 21, 12], dtype=torch.int32, device="cuda")
+    Wt = ops.tile_weights(qq, ops.TILE_ROTARY, D, scale=sq)
+    outs = []
+    for a8 in (True, False):
+        kc = torch.zeros(B * 3, Hkv, D * 16, dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        qo = ops.qkv_rope_wide(Wt, x, bias, cs, kc, vc, bt, seq_lens, -1, B, q_len, Hq, Hkv, D,
+                               fp8_activations=a8)
+        outs.append((qo, kc, vc))
+    for a, b in zip(*outs):
+        assert ((a != 0) == (b != 0)).float().mean().item() > 0.999
+        assert (a.float() - b.float()).abs().max().item() < b.float().abs().max().item() / 16
 
 
 # ------------------------------------------------------------------ 17..256 token rows

@@ -47,12 +47,13 @@ def _bf(state):
     return {k: v.to(torch.bfloat16).float() for k, v in state.items()}
 
 
-def _logits_via_engine(w, tokens, chunks, wide=False, read_ahead_mb=0):
+def _logits_via_engine(w, tokens, chunks, wide=False, read_ahead_mb=0, fp8_activations=False):
     """Feeds `tokens` through the native forward in the given chunk sizes."""
     from vllm_omni_draft_amd.kv_cache import PagedKVCache
     from vllm_omni_draft_amd.model_runner import DecoderModel
     cfg = w.cfg
-    model = DecoderModel(w, max_ctx=128, split_tokens=128, wide=wide, read_ahead_mb=read_ahead_mb)
+    model = DecoderModel(w, max_ctx=128, split_tokens=128, wide=wide, read_ahead_mb=read_ahead_mb,
+                         fp8_activations=fp8_activations)
     kv = PagedKVCache(cfg, 16, 1, 128, "cuda")
     kv.ensure_capacity(0, len(tokens))
     tok = torch.tensor(tokens, dtype=torch.int32, device="cuda")
@@ -226,6 +227,36 @@ def test_fp8_greedy_spec_equals_ar(use_graph):
     assert eng.wide
     ar_wide = _generate(_engine(tw, None, 0, max_batch=3, rows="wide", use_graph=use_graph), prompts, 40)
     assert _generate(eng, prompts, 40) == ar_wide
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fp8_activations_on_the_wide_family(use_graph):
+    """fp8 weights with fp8 activations (W8A8) on the wide family: the logits stay within the
+    quantisation error of the bf16-activation pass on the same weights (and are not the same
+    numbers), a token's logits do not depend on how the pass was cut, and greedy speculative ==
+    autoregressive on a wide engine (verify passes and prompt chunks all W8A8) as on a narrow
+    one (prompt chunks only)."""
+    tcfg = MODELS["llama"]
+    dcfg = OracleConfig(**{**vars(tcfg), "n_layers": 1})
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)), fp8=True)
+    dw = _product(dcfg, _bf(random_state(dcfg, seed=22)), fp8=True)
+    toks = torch.randint(0, tcfg.vocab, (60,), generator=torch.Generator().manual_seed(4)).tolist()
+    a16 = _logits_via_engine(tw, toks, [40, 20], wide=True)
+    a8 = _logits_via_engine(tw, toks, [40, 20], wide=True, fp8_activations=True)
+    scale = a16.abs().max().item()
+    assert 1e-4 * scale < (a8 - a16).abs().max().item() < 0.15 * scale
+    assert (a8.argmax(-1) == a16.argmax(-1)).float().mean().item() > 0.8
+    assert torch.equal(a8, _logits_via_engine(tw, toks, [17, 25, 18], wide=True, fp8_activations=True))
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 73)), [1, 2, 3]]
+    for rows in ("wide", "narrow"):
+        kw = dict(max_batch=3, rows=rows, use_graph=use_graph, fp8_activations=True)
+        ar = _generate(_engine(tw, None, 0, **kw), prompts, 40)
+        eng = _engine(tw, dw, 3, **kw)
+        assert eng.target.fp8_activations and eng.draft.fp8_activations
+        assert _generate(eng, prompts, 40) == ar
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    with pytest.raises(ValueError):
+        DecoderModel(_product(tcfg, _bf(random_state(tcfg, seed=21))), 128, 128, fp8_activations=True)
 
 
 def test_chunking_is_bit_invariant():

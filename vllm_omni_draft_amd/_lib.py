@@ -55,7 +55,8 @@ class ForwardArgs(C.Structure):
                 ("tok_offset", i64), ("seq_lens", vp), ("pos_offset", i32), ("max_ctx", i32),
                 ("split_tokens", i32), ("logits", vp), ("wide", i32),
                 ("input_embeds", vp), ("rope_pos", vp), ("rope_delta", vp), ("tree_mask", vp),
-                ("chain_state", vp), ("draft_fused", i32), ("read_ahead_mb", i32)]
+                ("chain_state", vp), ("draft_fused", i32), ("read_ahead_mb", i32),
+                ("wide_a8", i32)]
 
 
 class UniformRegion(C.Structure):
@@ -136,6 +137,10 @@ SIGNATURES = {
     "sd_linear_wide_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32]),
     "sd_linear_wide": (i32, [vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "sd_qkv_rope_wide": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
+                               i32, i32, i32, i32, i32, C.POINTER(RopePositions), vp, C.c_size_t, vp]),
+    "sd_row_scales_fp8": (i32, [vp, i64, i32, i32, vp, vp]),
+    "sd_linear_wide_a8": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
+    "sd_qkv_rope_wide_a8": (i32, [vp, vp, vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
                                i32, i32, i32, i32, i32, C.POINTER(RopePositions), vp, C.c_size_t, vp]),
     "sd_linear_attn_merge": (i32, [vp, vp, vp, C.c_size_t, vp, i32, i32, i32, i32, i32, i32, i32, i32,
                                    vp, vp, vp, i64, i32, i32, vp]),

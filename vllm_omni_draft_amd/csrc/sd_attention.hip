@@ -775,15 +775,33 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mu;
 void* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch`, per device
 
-int static_scratch(void** out) {
-  int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
-  SD_REQUIRE(e == hipSuccess && dev >= 0 && dev < kMaxDevices, SD_ERR_HIP,
-             "sd_paged_attention_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+// The array's address on the device that `stream` belongs to (the null stream: the current
+// device), looked up once per device with that device current.
+int static_scratch(hipStream_t stream, void** out) {
+  int cur = -1;
+  hipError_t e = hipGetDevice(&cur);
+  SD_REQUIRE(e == hipSuccess, SD_ERR_HIP, "sd_paged_attention_static: hipGetDevice: %s",
+             hipGetErrorString(e));
+  int dev = cur;
+  if (stream) {
+    hipDevice_t sdev = 0;
+    e = hipStreamGetDevice(stream, &sdev);
+    SD_REQUIRE(e == hipSuccess, SD_ERR_HIP, "sd_paged_attention_static: hipStreamGetDevice: %s",
+               hipGetErrorString(e));
+    dev = (int)sdev;
+  }
+  SD_REQUIRE(dev >= 0 && dev < kMaxDevices, SD_ERR_HIP,
+             "sd_paged_attention_static: device %d outside 0..%d", dev, kMaxDevices - 1);
   std::lock_guard<std::mutex> lock(g_scratch_mu);
-  if (!g_scratch_ptr[dev]) {  // first call on this device, which is the current one
+  if (!g_scratch_ptr[dev]) {  // first call for this device
+    if (dev != cur) {
+      e = hipSetDevice(dev);
+      SD_REQUIRE(e == hipSuccess, SD_ERR_HIP, "sd_paged_attention_static: hipSetDevice(%d): %s", dev,
+                 hipGetErrorString(e));
+    }
     void* p = nullptr;
     e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (dev != cur) (void)hipSetDevice(cur);
     SD_REQUIRE(e == hipSuccess && p, SD_ERR_HIP,
                "sd_paged_attention_static: hipGetSymbolAddress(scratch) on device %d: %s", dev,
                hipGetErrorString(e));
@@ -815,7 +833,7 @@ extern "C" int sd_paged_attention_static(const void* q, int64_t ldq, const void*
                need, B, Hkv, n_splits, (size_t)SD_STATIC_SCRATCH_BYTES);
   }
   void* ws = nullptr;
-  const int rc = static_scratch(&ws);
+  const int rc = static_scratch((hipStream_t)stream, &ws);
   if (rc != SD_OK) return rc;
   // Nothing in the scratch must start at zero: every partial a merge reads was written by
   // the same call's attention launch (splits past a sequence's length are never read).

@@ -58,6 +58,7 @@ struct WideEpiArgs {
   const float* part;  // [S][M][NR]
   int S, M, NR, N;
   const float* w_scale;  // fp8 weights: f32 scale per source row (indexed like bias); else null
+  const float* x_scale;  // fp8 activations: f32 scale per token row; else null
   const bf16_t* bias;
   const bf16_t* residual;
   void* out;
@@ -73,6 +74,7 @@ struct WideArgs {
   int M, K, n_tiles, ks_per_split;
   int group_tiles;  // weight tiles per workgroup (8..16)
   WideEpiArgs epi;  // direct epilogue (one split): EPI >= 0
+  const float* x_inv;  // fp8 activations: 448 / max |x[m]| per token row (wide_gemm_a8_kernel)
 };
 
 constexpr int EPI_PARTIAL = -1;  // several K splits: partial sums to the workspace
@@ -251,6 +253,14 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
 template <int EPI>
 __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile, int r0, f32x4 lo,
                                           f32x4 hi) {
+  if (a.x_scale) {  // sums of products of fp8 activations: back to the row's scale first
+    const float xs = a.x_scale[m];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo[j] *= xs;
+      hi[j] *= xs;
+    }
+  }
   if (EPI == EPI_QKV_ROPE) {
     const WideRope& rp = a.rope;
     const int D = rp.D, half = D / 2, tiles_per_head = D / 16;
@@ -370,6 +380,217 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
   }
 }
 
+// ------------------------------------------------------------------ fp8 activations (W8A8)
+// The same workgroup shape over fp8 weight tiles, with the activations quantised to e4m3 on
+// their way into LDS (per token row: x * (448 / max |x|), clamped, rounded to nearest even by
+// v_cvt_pk_fp8_f32) and the products on the block-scaled fp8 MFMA with unit scales
+// (v_mfma_scale_f32_16x16x128_f8f6f4: one instruction per tile, token tile and 128-column
+// chunk).  A chunk of a row is 128 bytes of LDS instead of 256, a weight tile's chunk 2 KiB of
+// HBM instead of 4: the kernel's two limits at 128..256 rows.  The epilogue multiplies a sum by
+// the row's scale (max |x| / 448) and the weight row's scale.  A lane's 32 weight bytes of a
+// chunk are columns 32 h + 8 q + j (h = 0..3, q = lane >> 4, j = 0..7: two 16-byte loads of the
+// fp8 tiling); the LDS image of a row puts those 32 bytes side by side, so a B fragment is two
+// 16-byte reads.  A row's arithmetic depends on that row alone.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+constexpr int kLD8 = kChunkCols + 16;  // bytes per LDS row of fp8 activations
+
+template <int MT, int EPI, int TPW>
+__global__ __launch_bounds__(kWideThreads) void wide_gemm_a8_kernel(WideArgs a) {
+  constexpr int kTilesPerWave = TPW;
+  // Weight chunks in flight per wave.  Measured on MI355X (192 rows, Llama-3-8B gate/up): 2 to 4
+  // chunks ahead are no faster than 1 (73.4 vs 72.3 us), so the weight stream's round trip is
+  // not what bounds the kernel; the ring stays in the code for shapes where it might be.
+  constexpr int kDepth = 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  unsigned char* xs = reinterpret_cast<unsigned char*>(smem_raw);  // [2][MT*16][kLD8]
+  constexpr int kRows = MT * 16;
+  constexpr int kPieces = kRows * (kChunkCols / 8) / kWideThreads;  // 8-column pieces per thread
+  static_assert(kRows * (kChunkCols / 8) % kWideThreads == 0, "MT must be even");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = a.K / 32;
+  const int NR = a.n_tiles * 16;
+  const int ks_lo = blockIdx.y * a.ks_per_split;
+  const int ks_hi = min(ks_lo + a.ks_per_split, KS);
+  const int n_chunks = (ks_hi - ks_lo + kChunkSteps - 1) / kChunkSteps;
+  const int tile0 = blockIdx.x * a.group_tiles + wave;
+  auto tile_of = [&](int t) { return tile0 + t * kWideWaves; };
+  auto tile_ok = [&](int t) {
+    return wave + t * kWideWaves < a.group_tiles && tile_of(t) < a.n_tiles;
+  };
+
+  // as in wide_gemm_kernel: every load unconditional on a clamped address
+  bf16x8 x_stage[kPieces];
+  float inv[kPieces];
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i)
+    inv[i] = a.x_inv[min((tid + i * kWideThreads) / (kChunkCols / 8), a.M - 1)];
+  auto load_x = [&](int chunk) {
+    const int col0 = (ks_lo + chunk * kChunkSteps) * 32;
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const int p = tid + i * kWideThreads;
+      const int row = min(p / (kChunkCols / 8), a.M - 1);
+      const int col = col0 + (p % (kChunkCols / 8)) * 8;
+      x_stage[i] = *reinterpret_cast<const bf16x8*>(a.x + (size_t)row * a.ldx + min(col, a.K - 8));
+    }
+  };
+  // keep: all ones for a chunk of the split, zero for the padding chunks of the last round
+  auto store_x = [&](int buf, unsigned keep) {
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const int p = tid + i * kWideThreads;
+      const int row = p / (kChunkCols / 8), c8 = p % (kChunkCols / 8);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        f[j] = fminf(fmaxf((float)x_stage[i][j] * inv[i], -448.f), 448.f);
+      unsigned w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0u, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+      unsigned w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0u, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+      // columns 8 c8 .. + 7 of the chunk: lane quarter c8 & 3, 32-column block c8 >> 2
+      // (K and the splits are whole chunks here: nothing to zero inside a chunk)
+      *reinterpret_cast<uint2*>(xs + ((size_t)buf * kRows + row) * kLD8 + 32 * (c8 & 3) + 8 * (c8 >> 2)) =
+          uint2{w0 & keep, w1 & keep};
+    }
+  };
+  u32x4 a_q[kDepth][kTilesPerWave][2];
+  auto load_a = [&](int chunk, u32x4 (&dst)[kTilesPerWave][2]) {
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int tile = min(tile_of(t), a.n_tiles - 1);
+        const int step = min((ks_lo + chunk * kChunkSteps) / 2 + j, KS / 2 - 1);
+        dst[t][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(
+            a.W + ((size_t)tile * (KS / 2) + step) * 512 + lane * 8));
+      }
+  };
+
+  f32x4 acc[kTilesPerWave][MT];
+#pragma unroll
+  for (int t = 0; t < kTilesPerWave; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_x(0);
+#pragma unroll
+  for (int d = 0; d < kDepth; ++d) load_a(d, a_q[d]);
+  store_x(0, ~0u);
+  __syncthreads();
+  const int xc = lane & 15, xq = lane >> 4;
+  // Rounds of kDepth chunks (the ring slot of a chunk is a compile-time index); the last round
+  // is filled up with chunks of zeroed activations.  Nothing in a chunk is conditional: the
+  // loads' addresses are clamped, and without a branch the chunk stays one basic block, so
+  // the order pinned below holds.
+  const int n_rounds = (n_chunks + kDepth - 1) / kDepth;
+  for (int round = 0; round < n_rounds; ++round) {
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) {
+      const int c = round * kDepth + d;
+      i32x8 a_cur[kTilesPerWave];
+#pragma unroll
+      for (int t = 0; t < kTilesPerWave; ++t) {
+        const u32x4 lo = a_q[d][t][0], hi = a_q[d][t][1];
+        a_cur[t] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3],
+                         (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      }
+      load_x(c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(c + kDepth, a_q[d]);
+      const unsigned char* xb = xs + ((size_t)(c & 1) * kRows + xc) * kLD8 + 32 * xq;
+      auto read_b = [&](int mt) {
+        const u32x4 lo = *reinterpret_cast<const u32x4*>(xb + (size_t)mt * 16 * kLD8);
+        const u32x4 hi = *reinterpret_cast<const u32x4*>(xb + (size_t)mt * 16 * kLD8 + 16);
+        return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3],
+                     (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      };
+      constexpr int kRing = 2;   // B fragments in flight (8 registers each)
+      i32x8 ring[kRing];
+#pragma unroll
+      for (int i = 0; i < kRing; ++i) ring[i] = read_b(i);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const i32x8 b = ring[mt % kRing];
+#pragma unroll
+        for (int t = 0; t < kTilesPerWave; ++t)
+          acc[t][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(
+              a_cur[t], b, acc[t][mt], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        if (mt + kRing < MT) ring[mt % kRing] = read_b(mt + kRing);
+      }
+      // pin that order (the scheduler otherwise hoists every fragment read to the top of the
+      // chunk: MT x 8 registers): kRing fragment reads, then {MFMAs of a token tile, a read} ...
+#pragma unroll
+      for (int i = 0; i < kRing; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+      for (int i = 0; i < MT - kRing; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, kTilesPerWave, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < kRing; ++i) __builtin_amdgcn_sched_group_barrier(0x008, kTilesPerWave, 0);
+      store_x((c + 1) & 1, c + 1 < n_chunks ? ~0u : 0u);
+      __syncthreads();
+    }
+  }
+
+  if (EPI == EPI_PARTIAL) {
+    float* part = a.part + (size_t)blockIdx.y * a.M * NR;
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+      if (!tile_ok(t)) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + xc;
+        if (m < a.M)
+          *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)tile_of(t) * 16 + 4 * xq) = acc[t][mt];
+      }
+    }
+  } else {
+    constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
+#pragma unroll
+    for (int t = 0; t < kTilesPerWave; ++t) {
+      const bool t_ok = tile_ok(t);  // wave-uniform
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + xc;
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+        if (PAIRED) {  // rows r+8 sit 32 lanes up
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hi[j] = __shfl(acc[t][mt][j], (lane + 32) & 63, 64);
+        }
+        if (t_ok && m < a.M && (!PAIRED || xq < 2))
+          emit_unit<EPI == EPI_PARTIAL ? 0 : EPI>(a.epi, m, tile_of(t), 4 * xq, acc[t][mt], hi);
+      }
+    }
+  }
+}
+
+// scales[m] = max |x[m]| / 448 (1 for a row of zeros), scales[M + m] = its inverse factor 448 / max |x[m]|
+__global__ __launch_bounds__(256) void row_scales_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                             int M, int K, float* __restrict__ scales) {
+  __shared__ float s_max[4];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* row = x + (size_t)m * ldx;
+  float mx = 0.f;
+  for (int c = tid * 8; c < K; c += 256 * 8) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, fabsf((float)v[j]));
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) s_max[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    mx = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const bool ok = mx > 0.f && mx < INFINITY;
+    scales[m] = ok ? mx / 448.f : 1.f;
+    scales[M + m] = ok ? 448.f / mx : 1.f;
+  }
+}
+
 // One thread = one unit (see emit_unit) of one token row.  Splits are added in index order.
 template <int EPI>
 __global__ __launch_bounds__(256) void wide_epilogue_kernel(WideEpiArgs a) {
@@ -441,7 +662,33 @@ int launch_gemm_w(const WideArgs& a, int S, hipStream_t st) {
 }
 
 template <int MT, int EPI, int TPW>
+int launch_gemm_a8(const WideArgs& a, int S, hipStream_t st) {
+  if constexpr (EPI == SD_EPI_RELU || EPI == SD_EPI_GELU_TANH) {
+    sd_set_error("sd_linear_wide_a8: epilogue %d not available with fp8 activations", EPI);
+    return SD_ERR_UNSUPPORTED;
+  } else {
+    const size_t lds = (size_t)2 * MT * 16 * kLD8;
+    static std::once_flag attr_once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(attr_once, [] {
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm_a8_kernel<MT, EPI, TPW>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (attr_err != hipSuccess) {
+      sd_set_error("sd_linear_wide_a8: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+      return SD_ERR_HIP;
+    }
+    const int groups = (a.n_tiles + a.group_tiles - 1) / a.group_tiles;
+    hipLaunchKernelGGL((wide_gemm_a8_kernel<MT, EPI, TPW>), dim3(groups, S), dim3(kWideThreads), lds,
+                       st, a);
+    SD_CHECK_LAUNCH("sd_linear_wide_a8");
+    return SD_OK;
+  }
+}
+
+template <int MT, int EPI, int TPW>
 int launch_gemm_t(const WideArgs& a, int S, hipStream_t st) {
+  if (a.x_inv) return launch_gemm_a8<MT, EPI, TPW>(a, S, st);
   return a.epi.w_scale ? launch_gemm_w<MT, EPI, TPW, true>(a, S, st)
                        : launch_gemm_w<MT, EPI, TPW, false>(a, S, st);
 }
@@ -502,7 +749,8 @@ int gemm_by_rows(const WideArgs& a, int mt, int epi, int S, hipStream_t st) {
 }
 
 int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_tiles, int epi,
-                WideEpiArgs& e, void* workspace, size_t ws_bytes, hipStream_t st) {
+                WideEpiArgs& e, void* workspace, size_t ws_bytes, hipStream_t st,
+                const float* x_scales = nullptr) {
   SD_REQUIRE(W && x && e.out && workspace, SD_ERR_INVALID, "sd_linear_wide: null pointer");
   SD_REQUIRE(M >= 0 && M <= 256, SD_ERR_UNSUPPORTED, "sd_linear_wide: M=%d outside 0..256", M);
   SD_REQUIRE(K >= 32 && K % 32 == 0 && n_tiles >= 1, SD_ERR_INVALID,
@@ -518,7 +766,15 @@ int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_t
   const size_t need = (size_t)S * M * n_tiles * 16 * sizeof(float);
   SD_REQUIRE(ws_bytes >= need, SD_ERR_WORKSPACE, "sd_linear_wide: workspace %zu < %zu bytes",
              ws_bytes, need);
-  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp, g, e};
+  if (x_scales) {  // [2][M]: the rows' scales, then their inverse factors (sd_row_scales_fp8)
+    SD_REQUIRE(e.w_scale && K % 128 == 0, SD_ERR_UNSUPPORTED,
+               "sd_linear_wide_a8: fp8 activations need fp8 weights and K %% 128 == 0 (K=%d)", K);
+    SD_REQUIRE(epi != SD_EPI_RELU && epi != SD_EPI_GELU_TANH, SD_ERR_UNSUPPORTED,
+               "sd_linear_wide_a8: epilogue %d not available with fp8 activations", epi);
+    e.x_scale = x_scales;
+  }
+  WideArgs a{(const bf16_t*)W, (const bf16_t*)x, ldx, (float*)workspace, M, K, n_tiles, ksp, g, e,
+             x_scales ? x_scales + M : nullptr};
   e.part = (const float*)workspace;
   e.S = S;
   e.M = M;
@@ -538,11 +794,10 @@ extern "C" size_t sd_linear_wide_workspace_bytes(int M, int N, int K, int epilog
   return wide_ws_bytes(M, tiles_of(N, epilogue), K);
 }
 
-extern "C" int sd_linear_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
-                              const void* bias,
-                              const void* residual, void* out, int64_t ldo, int M, int N, int K,
-                              int epilogue, void* workspace, size_t workspace_bytes,
-                              sd_stream_t stream) {
+static int linear_wide_entry(const void* W, const float* w_scale, const float* x_scales, const void* x,
+                             int64_t ldx, const void* bias, const void* residual, void* out,
+                             int64_t ldo, int M, int N, int K, int epilogue, void* workspace,
+                             size_t workspace_bytes, sd_stream_t stream) {
   SD_REQUIRE(epilogue >= SD_EPI_STORE && epilogue <= SD_EPI_GELU_TANH, SD_ERR_INVALID,
              "sd_linear_wide: unknown epilogue %d", epilogue);
   SD_REQUIRE(N >= 1 && ldo >= N, SD_ERR_INVALID, "sd_linear_wide: need N >= 1 and ldo >= N");
@@ -556,17 +811,46 @@ extern "C" int sd_linear_wide(const void* W, const float* w_scale, const void* x
   e.out = out;
   e.ldo = ldo;
   return wide_common(W, x, ldx, M, K, tiles_of(N, epilogue), epilogue, e, workspace,
-                     workspace_bytes, (hipStream_t)stream);
+                     workspace_bytes, (hipStream_t)stream, x_scales);
 }
 
-extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
-                                const void* bias,
-                                void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
-                                void* k_cache, void* v_cache, const int32_t* block_tables,
-                                int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
-                                int B, int q_len, int Hq, int Hkv, int D, int K,
-                                const sd_rope_positions* rope_pos, void* workspace,
-                                size_t workspace_bytes, sd_stream_t stream) {
+extern "C" int sd_linear_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                              const void* bias,
+                              const void* residual, void* out, int64_t ldo, int M, int N, int K,
+                              int epilogue, void* workspace, size_t workspace_bytes,
+                              sd_stream_t stream) {
+  return linear_wide_entry(W, w_scale, nullptr, x, ldx, bias, residual, out, ldo, M, N, K, epilogue,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_linear_wide_a8(const void* W, const float* w_scale, const float* x_scales,
+                                 const void* x, int64_t ldx, const void* bias, const void* residual,
+                                 void* out, int64_t ldo, int M, int N, int K, int epilogue,
+                                 void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+  SD_REQUIRE(w_scale && x_scales, SD_ERR_INVALID,
+             "sd_linear_wide_a8: needs fp8 weights (w_scale) and the rows' scales (sd_row_scales_fp8)");
+  return linear_wide_entry(W, w_scale, x_scales, x, ldx, bias, residual, out, ldo, M, N, K, epilogue,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_row_scales_fp8(const void* x, int64_t ldx, int M, int K, float* scales,
+                                 sd_stream_t stream) {
+  SD_REQUIRE(x && scales && M >= 0 && K >= 8 && K % 8 == 0 && ldx >= K && ldx % 8 == 0 &&
+                 sd_aligned16(x), SD_ERR_INVALID, "sd_row_scales_fp8: bad arguments (M=%d K=%d)", M, K);
+  if (M == 0) return SD_OK;
+  hipLaunchKernelGGL(row_scales_fp8_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, M, K, scales);
+  SD_CHECK_LAUNCH("sd_row_scales_fp8");
+  return SD_OK;
+}
+
+static int qkv_rope_wide_entry(const void* W, const float* w_scale, const float* x_scales,
+                               const void* x, int64_t ldx, const void* bias, void* q_out, int64_t ldq,
+                               const float* rope_cs, int max_pos, void* k_cache, void* v_cache,
+                               const int32_t* block_tables, int max_blocks_per_seq,
+                               const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
+                               int Hkv, int D, int K, const sd_rope_positions* rope_pos,
+                               void* workspace, size_t workspace_bytes, sd_stream_t stream) {
   SD_REQUIRE(q_out && k_cache && v_cache && block_tables && seq_lens, SD_ERR_INVALID,
              "sd_qkv_rope_wide: null pointer");
   SD_REQUIRE(B >= 0 && q_len >= 1 && Hq >= 1 && Hkv >= 1 && D % 16 == 0 && D >= 16,
@@ -587,5 +871,32 @@ extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void*
                     max_blocks_per_seq, seq_lens, pos_offset, q_len, Hq, Hkv, D,
                     sd_make_rope_pos(rope_pos, B * q_len)};
   return wide_common(W, x, ldx, B * q_len, K, N / 16, EPI_QKV_ROPE, e, workspace, workspace_bytes,
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, x_scales);
+}
+
+extern "C" int sd_qkv_rope_wide(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                                const void* bias,
+                                void* q_out, int64_t ldq, const float* rope_cs, int max_pos,
+                                void* k_cache, void* v_cache, const int32_t* block_tables,
+                                int max_blocks_per_seq, const int32_t* seq_lens, int pos_offset,
+                                int B, int q_len, int Hq, int Hkv, int D, int K,
+                                const sd_rope_positions* rope_pos, void* workspace,
+                                size_t workspace_bytes, sd_stream_t stream) {
+  return qkv_rope_wide_entry(W, w_scale, nullptr, x, ldx, bias, q_out, ldq, rope_cs, max_pos, k_cache,
+                             v_cache, block_tables, max_blocks_per_seq, seq_lens, pos_offset, B, q_len,
+                             Hq, Hkv, D, K, rope_pos, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sd_qkv_rope_wide_a8(const void* W, const float* w_scale, const float* x_scales,
+                                   const void* x, int64_t ldx, const void* bias, void* q_out,
+                                   int64_t ldq, const float* rope_cs, int max_pos, void* k_cache,
+                                   void* v_cache, const int32_t* block_tables, int max_blocks_per_seq,
+                                   const int32_t* seq_lens, int pos_offset, int B, int q_len, int Hq,
+                                   int Hkv, int D, int K, const sd_rope_positions* rope_pos,
+                                   void* workspace, size_t workspace_bytes, sd_stream_t stream) {
+  SD_REQUIRE(w_scale && x_scales, SD_ERR_INVALID,
+             "sd_qkv_rope_wide_a8: needs fp8 weights (w_scale) and the rows' scales (sd_row_scales_fp8)");
+  return qkv_rope_wide_entry(W, w_scale, x_scales, x, ldx, bias, q_out, ldq, rope_cs, max_pos, k_cache,
+                             v_cache, block_tables, max_blocks_per_seq, seq_lens, pos_offset, B, q_len,
+                             Hq, Hkv, D, K, rope_pos, workspace, workspace_bytes, stream);
 }

@@ -127,7 +127,7 @@ namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Workspace {
-  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, wide_ws, wide_ws_bytes, slabs, acc, total;
+  size_t h, xn, qkv, attn, act, attn_ws, attn_ws_bytes, wide_ws, wide_ws_bytes, slabs, acc, x_scales, total;
 };
 
 // wide: the pass uses the 17..256-row linear kernels (and their partial-sum scratch).
@@ -164,6 +164,8 @@ Workspace plan_workspace(const sd_model_desc& d, int rows, int max_ctx, int spli
   const size_t fr = (size_t)(rows < SD_DRAFT_LAYER_MAX_ROWS ? rows : SD_DRAFT_LAYER_MAX_ROWS);
   w.slabs = off; off += align256(fr * d.n_kv_heads * d.hidden * sizeof(float));
   w.acc = off;   off += align256(fr * d.hidden * sizeof(float));
+  // fp8 activations of the wide family: a scale and its inverse factor per token row
+  w.x_scales = off; off += align256((size_t)2 * rows * sizeof(float));
   w.total = off;
   return w;
 }
@@ -293,12 +295,24 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       void* wws = base + w.wide_ws;
       const bool lead = !d.allreduce || d.tp_rank == 0;
       const int proj_epi = lead ? SD_EPI_RESIDUAL : SD_EPI_STORE;
+      // fp8 activations (opt-in): every matrix of the layer is fp8 and every width a multiple of 128
+      const bool a8 = a->wide_a8 && llama && l.qkv_s && l.o_s && l.up_s && l.down_s && H % 128 == 0 &&
+                      F % 128 == 0 && (Hq * D) % 128 == 0;
+      float* xsc = reinterpret_cast<float*>(base + w.x_scales);
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.attn_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.attn_norm_w, l.attn_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_qkv_rope_wide(l.qkv_w, l.qkv_s, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
-                              llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
-                              kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
-                              Hq, Hkv, D, H, rpp, wws, w.wide_ws_bytes, stream));
+      if (a8) {
+        SD_TRY(sd_row_scales_fp8(xn, H, rows, H, xsc, stream));
+        SD_TRY(sd_qkv_rope_wide_a8(l.qkv_w, l.qkv_s, xsc, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
+                                   d.rope_cs, d.max_pos, kc, vc, kv->block_tables,
+                                   kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
+                                   Hq, Hkv, D, H, rpp, wws, w.wide_ws_bytes, stream));
+      } else {
+        SD_TRY(sd_qkv_rope_wide(l.qkv_w, l.qkv_s, xn, H, l.qkv_b, qkv, (int64_t)Hq * D,
+                                llama ? d.rope_cs : nullptr, d.max_pos, kc, vc, kv->block_tables,
+                                kv->max_blocks_per_seq, a->seq_lens, a->pos_offset, a->B, a->q_len,
+                                Hq, Hkv, D, H, rpp, wws, w.wide_ws_bytes, stream));
+      }
       // One workgroup column covers 64 / (Hq/Hkv) query tokens of a sequence; a longer chunk
       // (prefill) is attended in blocks of that many tokens by the same launch (their K/V is
       // in the cache already, the causal mask is per row).
@@ -317,15 +331,30 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
                                           d.attn_scale, a->max_ctx, a->split_tokens, attn_ws,
                                           w.attn_ws_bytes, stream));
       }
-      SD_TRY(sd_linear_wide(l.o_w, l.o_s, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
-                            Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
+      if (a8) {
+        SD_TRY(sd_row_scales_fp8(attn, (int64_t)Hq * D, rows, Hq * D, xsc, stream));
+        SD_TRY(sd_linear_wide_a8(l.o_w, l.o_s, xsc, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H,
+                                 rows, H, Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
+      } else {
+        SD_TRY(sd_linear_wide(l.o_w, l.o_s, attn, (int64_t)Hq * D, lead ? l.o_b : nullptr, h, h, H, rows, H,
+                              Hq * D, proj_epi, wws, w.wide_ws_bytes, stream));
+      }
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
       if (llama) SD_TRY(sd_rmsnorm(h, H, l.mlp_norm_w, xn, H, rows, H, d.norm_eps, stream));
       else SD_TRY(sd_layernorm(h, H, l.mlp_norm_w, l.mlp_norm_b, xn, H, rows, H, d.norm_eps, stream));
-      SD_TRY(sd_linear_wide(l.up_w, l.up_s, xn, H, l.up_b, nullptr, act, F, rows, F, H,
-                            llama ? SD_EPI_SILU_MUL : SD_EPI_RELU, wws, w.wide_ws_bytes, stream));
-      SD_TRY(sd_linear_wide(l.down_w, l.down_s, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F,
-                            proj_epi, wws, w.wide_ws_bytes, stream));
+      if (a8) {
+        SD_TRY(sd_row_scales_fp8(xn, H, rows, H, xsc, stream));
+        SD_TRY(sd_linear_wide_a8(l.up_w, l.up_s, xsc, xn, H, l.up_b, nullptr, act, F, rows, F, H,
+                                 SD_EPI_SILU_MUL, wws, w.wide_ws_bytes, stream));
+        SD_TRY(sd_row_scales_fp8(act, F, rows, F, xsc, stream));
+        SD_TRY(sd_linear_wide_a8(l.down_w, l.down_s, xsc, act, F, lead ? l.down_b : nullptr, h, h, H, rows,
+                                 H, F, proj_epi, wws, w.wide_ws_bytes, stream));
+      } else {
+        SD_TRY(sd_linear_wide(l.up_w, l.up_s, xn, H, l.up_b, nullptr, act, F, rows, F, H,
+                              llama ? SD_EPI_SILU_MUL : SD_EPI_RELU, wws, w.wide_ws_bytes, stream));
+        SD_TRY(sd_linear_wide(l.down_w, l.down_s, act, F, lead ? l.down_b : nullptr, h, h, H, rows, H, F,
+                              proj_epi, wws, w.wide_ws_bytes, stream));
+      }
       if (d.allreduce) SD_TRY(d.allreduce(h, (size_t)rows * H, d.allreduce_ctx, stream));
       continue;
     }
@@ -423,8 +452,15 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
   if (a->logits && wide) {
     if (llama) SD_TRY(sd_rmsnorm(h, H, d.final_norm_w, xn, H, rows, H, d.norm_eps, stream));
     else SD_TRY(sd_layernorm(h, H, d.final_norm_w, d.final_norm_b, xn, H, rows, H, d.norm_eps, stream));
-    SD_TRY(sd_linear_wide(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
-                          SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
+    if (a->wide_a8 && llama && d.lm_head_s && H % 128 == 0) {
+      float* xsc = reinterpret_cast<float*>(base + w.x_scales);
+      SD_TRY(sd_row_scales_fp8(xn, H, rows, H, xsc, stream));
+      SD_TRY(sd_linear_wide_a8(d.lm_head, d.lm_head_s, xsc, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows,
+                               lm_vocab, H, SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
+    } else {
+      SD_TRY(sd_linear_wide(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
+                            SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
+    }
   } else if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {
       SD_TRY(sd_norm_linear(d.lm_head, d.lm_head_s, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,

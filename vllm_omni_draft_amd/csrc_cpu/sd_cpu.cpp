@@ -995,6 +995,23 @@ extern "C" int sd_linear(const void* W, const float* ws, const void* x, int64_t 
                          sd_stream_t) {
   return linear_any(W, ws, x, ldx, nullptr, nullptr, 0.f, 0, bias, residual, out, ldo, M, N, K, epi, "sd_linear");
 }
+// fp8 activations exist for the GPU's fp8 matrix instruction only
+extern "C" int sd_row_scales_fp8(const void*, int64_t, int, int, float*, sd_stream_t) {
+  set_error("sd_row_scales_fp8: not available in the CPU build");
+  return SD_ERR_UNSUPPORTED;
+}
+extern "C" int sd_linear_wide_a8(const void*, const float*, const float*, const void*, int64_t, const void*,
+                                 const void*, void*, int64_t, int, int, int, int, void*, size_t, sd_stream_t) {
+  set_error("sd_linear_wide_a8: not available in the CPU build");
+  return SD_ERR_UNSUPPORTED;
+}
+extern "C" int sd_qkv_rope_wide_a8(const void*, const float*, const float*, const void*, int64_t, const void*,
+                                   void*, int64_t, const float*, int, void*, void*, const int32_t*, int,
+                                   const int32_t*, int, int, int, int, int, int, int,
+                                   const sd_rope_positions*, void*, size_t, sd_stream_t) {
+  set_error("sd_qkv_rope_wide_a8: not available in the CPU build");
+  return SD_ERR_UNSUPPORTED;
+}
 extern "C" size_t sd_linear_wide_workspace_bytes(int, int, int, int) { return 16; }
 extern "C" int sd_linear_wide(const void* W, const float* ws, const void* x, int64_t ldx,
                               const void* bias, const void* residual, void* out, int64_t ldo, int M,

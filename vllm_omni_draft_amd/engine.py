@@ -116,6 +116,10 @@ class EngineConfig:
     # target's and the draft's narrow-family passes.  Same bits either way.
     target_read_ahead_mb: int = 0
     draft_read_ahead_mb: int = 0
+    # fp8 models only: passes of the wide family (prompt chunks; every pass of a wide engine)
+    # quantise their activations to fp8 per token row and multiply on the fp8 matrix
+    # instruction (W8A8).  Applies to target and draft alike where their weights are fp8.
+    fp8_activations: bool = False
 
 
 def acceptance_pattern(accept_prob: float, k: int, length: int = 16, rotate: int = 0) -> List[int]:
@@ -203,7 +207,8 @@ class SpecEngine:
             raise ValueError("rows must be 'auto', 'narrow' or 'wide'")
         self.wide = cfg.rows == "wide" or (cfg.rows == "auto" and B * q_max > MAX_ROWS)
         self.target = DecoderModel(target, self.max_ctx, cfg.split_tokens, tp_group=tp_group,
-                                   wide=self.wide, read_ahead_mb=cfg.target_read_ahead_mb)
+                                   wide=self.wide, read_ahead_mb=cfg.target_read_ahead_mb,
+                                   fp8_activations=cfg.fp8_activations and bool(getattr(target, "fp8", False)))
         if cfg.draft_rows not in ("auto", "same", "narrow", "wide"):
             raise ValueError("draft_rows must be 'auto', 'same', 'narrow' or 'wide'")
         if cfg.draft_rows == "auto":
@@ -214,7 +219,8 @@ class SpecEngine:
                                    wide=draft_wide, tp_group=tp_group if draft_tp else None,
                                    fused_pairs=cfg.draft_fused_pairs,
                                    fused_layers=bool(cfg.draft_fused_layers) and not cfg.draft_fused_pairs
-                                   and not draft_tp, read_ahead_mb=cfg.draft_read_ahead_mb)
+                                   and not draft_tp, read_ahead_mb=cfg.draft_read_ahead_mb,
+                                   fp8_activations=cfg.fp8_activations and bool(getattr(draft, "fp8", False)))
                       if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
         self._lanes: List[torch.cuda.Stream] = []

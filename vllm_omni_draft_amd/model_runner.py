@@ -30,7 +30,7 @@ class DecoderModel:
     def __init__(self, weights: ModelWeights, max_ctx: int, split_tokens: int = 256,
                  tp_group=None, wide: bool = False, wide_prefill: bool = True,
                  fused_pairs: bool = False, fused_layers: bool = False,
-                 read_ahead_mb: int = 0):
+                 read_ahead_mb: int = 0, fp8_activations: bool = False):
         """tp_group (parallel.TensorParallelGroup or any object with rank, allreduce_ptr,
         ctx_ptr): `weights` is then this rank's shard (weights.shard_state_dict)."""
         self.weights = weights  # keeps the device tensors alive
@@ -53,6 +53,11 @@ class DecoderModel:
         # MiB of the next launches' weights that every layer's attention launch reads ahead on
         # its idle compute units (sd_forward_args.read_ahead_mb); results do not change
         self.read_ahead_mb = int(read_ahead_mb)
+        # passes of the wide family quantise their activations to fp8 per token row and multiply
+        # on the fp8 matrix instruction (sd_forward_args.wide_a8); fp8 weights only
+        if fp8_activations and not fp8:
+            raise ValueError("fp8_activations needs fp8 weights")
+        self.fp8_activations = bool(fp8_activations)
         lib = _lib.load()
         # fused_layers (draft models): passes of up to ops.DRAFT_LAYER_MAX_ROWS rows run every
         # layer as three launches (sd_draft_attn_oproj, sd_draft_mlp); they need the down
@@ -174,7 +179,8 @@ class DecoderModel:
                                 rope_delta=_ptr(rope_delta), tree_mask=_ptr(tree_mask),
                                 chain_state=_ptr(self.chain_state) if workspace is None else None,
                                 draft_fused=int(self.fused_layers),
-                                read_ahead_mb=int(self.read_ahead_mb))
+                                read_ahead_mb=int(self.read_ahead_mb),
+                                wide_a8=int(self.fp8_activations))
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
                                           ops._stream())

@@ -557,9 +557,21 @@ def layernorm(x, w, b, eps) -> torch.Tensor:
     return out
 
 
+def row_scales_fp8(x: torch.Tensor) -> torch.Tensor:
+    """f32 [2, M]: every row's fp8 scale max|x[m]| / 448 and its inverse factor (sd_row_scales_fp8)."""
+    _need(x, torch.bfloat16, "x")
+    M, K = x.shape
+    out = torch.empty(2, M, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sd_row_scales_fp8(_p(x), x.stride(0), M, K, _p(out), _stream()),
+               "sd_row_scales_fp8")
+    return out
+
+
 def linear_wide(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None,
-                workspace=None) -> torch.Tensor:
-    """linear() for up to 256 token rows (its own summation order; see sd_linear_wide)."""
+                workspace=None, fp8_activations: bool = False) -> torch.Tensor:
+    """linear() for up to 256 token rows (its own summation order; see sd_linear_wide).
+    fp8_activations (fp8 weights only): the rows are quantised to e4m3 with a scale per row and
+    multiplied on the fp8 matrix instruction (sd_linear_wide_a8)."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, epilogue)
     M, K = x.shape
@@ -570,6 +582,13 @@ def linear_wide(W, x, bias=None, residual=None, epilogue=EPI_STORE, out=None,
     need = int(_lib.load().sd_linear_wide_workspace_bytes(M, N, K, epilogue))
     if workspace is None:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    if fp8_activations:
+        sc = row_scales_fp8(x)
+        _lib.check(_lib.load().sd_linear_wide_a8(_p(Wt.data), _p(Wt.scale), _p(sc), _p(x), x.stride(0),
+                                                 _p(bias), _p(residual), _p(out), out.stride(0), M, N, K,
+                                                 epilogue, _p(workspace), workspace.numel(), _stream()),
+                   "sd_linear_wide_a8")
+        return out
     _lib.check(_lib.load().sd_linear_wide(_p(Wt.data), _p(Wt.scale), _p(x), x.stride(0), _p(bias),
                                           _p(residual),
                                           _p(out), out.stride(0), M, N, K, epilogue, _p(workspace),
@@ -597,8 +616,9 @@ def _rope_positions(rope_pos, rope_delta, mrope_section, rows):
 
 def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens, pos_offset, B,
                   q_len, Hq, Hkv, D, workspace=None, rope_pos=None, rope_delta=None,
-                  mrope_section=None) -> torch.Tensor:
-    """QKV projection + rotary embedding + cache append for up to 256 token rows; returns q."""
+                  mrope_section=None, fp8_activations: bool = False) -> torch.Tensor:
+    """QKV projection + rotary embedding + cache append for up to 256 token rows; returns q.
+    fp8_activations: as in linear_wide (sd_qkv_rope_wide_a8)."""
     _need(x, torch.bfloat16, "x")
     Wt = _tiled(W, EPI_STORE, D)
     M, K = x.shape
@@ -607,6 +627,15 @@ def qkv_rope_wide(W, x, bias, rope_cs, k_cache, v_cache, block_tables, seq_lens,
     need = int(_lib.load().sd_linear_wide_workspace_bytes(M, N, K, EPI_STORE))
     if workspace is None:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    if fp8_activations:
+        sc = row_scales_fp8(x)
+        _lib.check(_lib.load().sd_qkv_rope_wide_a8(
+            _p(Wt.data), _p(Wt.scale), _p(sc), _p(x), x.stride(0), _p(bias), _p(q), Hq * D, _p(rope_cs),
+            0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache), _p(block_tables),
+            block_tables.shape[1], _p(seq_lens), pos_offset, B, q_len, Hq, Hkv, D, K,
+            _rope_positions(rope_pos, rope_delta, mrope_section, M), _p(workspace),
+            workspace.numel(), _stream()), "sd_qkv_rope_wide_a8")
+        return q
     _lib.check(_lib.load().sd_qkv_rope_wide(
         _p(Wt.data), _p(Wt.scale), _p(x), x.stride(0), _p(bias), _p(q), Hq * D, _p(rope_cs),
         0 if rope_cs is None else rope_cs.shape[0], _p(k_cache), _p(v_cache), _p(block_tables),

@@ -509,6 +509,10 @@ class SpecDecodeConfig:
     # that yields more tokens per second than the plain target step at the current batch size
     # (EngineConfig.spec_policy); speculative_disable_by_batch_size stays a hard upper bound.
     speculative_policy: str = "always"
+    # With quantization="fp8": the wide kernel family (prompt chunks, large batches) also
+    # quantises its activations to fp8, per token row, and multiplies on the fp8 matrix
+    # instruction of gfx950 (W8A8; EngineConfig.fp8_activations).
+    fp8_activations: bool = False
     spec_decoding_acceptance_method: str = "rejection_sampler"  # or "typical_acceptance_sampler"
     typical_acceptance_sampler_posterior_threshold: float = 0.09
     typical_acceptance_sampler_posterior_alpha: float = 0.3
@@ -689,7 +693,7 @@ class SpecDecodeWorker:
             external_proposals=c.external_proposals,
             tree_candidates=c.speculative_tree_candidates, tree_nodes=c.speculative_tree_nodes,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
-            spec_policy=c.speculative_policy,
+            spec_policy=c.speculative_policy, fp8_activations=c.fp8_activations,
             acceptance_method=c.spec_decoding_acceptance_method,
             posterior_threshold=c.typical_acceptance_sampler_posterior_threshold,
             posterior_alpha=c.typical_acceptance_sampler_posterior_alpha,
