@@ -39,7 +39,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E datasheet peak
 
 
-PMC_FILE = "profiles/r2_pmc_hbm.json"
+PMC_FILE = "profiles/r3_pmc_hbm.json"
 
 
 def pmc_traffic(kernel_substr):

@@ -116,8 +116,15 @@ def main():
                 e["avg_us_eager"] = round(d_avg[lab][1], 2)
             entry["kernels"][lab] = e
         out["passes"][which] = entry
-    with open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm.json"), "w") as f:
-        json.dump(out, f, indent=1)
+    hbm_path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_hbm.json")
+    merged = {}
+    if os.path.exists(hbm_path):          # keep what profiles/collect_round.py put there
+        with open(hbm_path) as f:
+            merged = json.load(f)
+    merged["passes_unit_note"] = out["unit_note"]
+    merged["passes"] = out["passes"]
+    with open(hbm_path, "w") as f:
+        json.dump(merged, f, indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -4,7 +4,8 @@ gpurun_out/<round>_profile:
 
   <round>_bench_kernel_stats.csv     per-kernel statistics of the headline bench
   <round>_roofline_kernel_stats.csv  statistics of the two roofline kernels run alone
-  <round>_pmc_hbm.json               HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes
+  <round>_pmc_hbm.json               "kernels": HBM bytes per launch of the two roofline kernels from the
+                                     FETCH_SIZE / WRITE_SIZE passes ("passes": see collect_passes.py)
   <round>_step_breakdown.txt         kernels of one speculative step, grouped
   <round>_pmc_mfma.json              matrix-pipe utilisation of the roofline kernels
                                      (experiments/profile_mfma.sh), when that pass was run
@@ -76,7 +77,14 @@ def main():
     out = {"unit_note": "rocprofv3 FETCH_SIZE / WRITE_SIZE in KiB per dispatch; gfx950 FETCH_SIZE counts 128-B read "
                         "requests at 64 B, so HBM read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE is exact for 16-B stores",
            "kernels": kernels}
-    with open(os.path.join(dst, f"{rnd}_pmc_hbm.json"), "w") as f:
+    hbm_path = os.path.join(dst, f"{rnd}_pmc_hbm.json")
+    if os.path.exists(hbm_path):          # keep what profiles/collect_passes.py put there
+        with open(hbm_path) as f:
+            old = json.load(f)
+        for key in ("passes", "passes_unit_note"):
+            if key in old:
+                out[key] = old[key]
+    with open(hbm_path, "w") as f:
         json.dump(out, f, indent=1)
     mfma = {}
     for sub in ("pmc_linear_mfma", "pmc_attn_mfma"):
