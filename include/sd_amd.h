@@ -824,6 +824,13 @@ typedef struct {
    * token row (sd_row_scales_fp8 + the _a8 linear layers, LM head included).  Changes the
    * rounding of those passes: choose it for all wide passes of a model or none.          */
   int wide_a8;
+  /* Both non-NULL: the pass leaves the slice maxima of every row's logits here
+   * ([B*q_len, SD_ARGMAX_PARTS] each, for sd_propose_from_partials / sd_verify_from_partials
+   * / sd_argmax_from_partials) — straight from the LM head where its shape allows
+   * (sd_norm_linear_argmax; `logits` is then not written and may be NULL), else through
+   * `logits` (which must then be given) and sd_argmax_partial.                    */
+  float* argmax_val;
+  int32_t* argmax_idx;
 } sd_forward_args;
 
 size_t sd_model_workspace_bytes(const sd_model* m, int max_rows, int max_ctx,
@@ -938,7 +945,20 @@ int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32_t* tok_buf
  *    greedy acceptance against tok_buf[:, 2:2+k] (as sd_greedy_verify;
  *    out_ids and counters optional), then the state update and step record
  *    of sd_advance_state.  k == 0 is plain autoregressive decoding; k <= 15.  */
-#define SD_ARGMAX_PARTS 64
+#define SD_ARGMAX_PARTS 512
+/* The LM head of a greedy pass without the logits round trip: sd_norm_linear with the F32
+ * epilogue replaced by the first stage of the row argmax.  Every workgroup of the launch (at
+ * most SD_ARGMAX_PARTS) leaves the largest of the f32 logits it computed for token row m, and
+ * its column, in part_val / part_idx[m][workgroup]; slots no workgroup owns get -inf.  The
+ * logits are the F32 epilogue's bit for bit and ties go to the lowest column, so the consumers
+ * below finish the same argmax as after sd_argmax_partial (upstream samples from the logits
+ * tensor: vllm/model_executor/layers/sampler.py; its greedy branch is an argmax over the row).
+ * Shapes as sd_norm_linear (M <= 16 rows that fit LDS: sd_model_forward falls back to logits +
+ * sd_argmax_partial otherwise).                                                */
+int sd_norm_linear_argmax(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                          const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                          float* part_val, int32_t* part_idx, int M, int N, int K,
+                          sd_stream_t stream);
 int sd_argmax_partial(const float* logits, int64_t ld, float* part_val,
                       int32_t* part_idx, int R, int V, sd_stream_t stream);
 /* Distributed argmax of a vocabulary-parallel head.  part_val / part_idx hold

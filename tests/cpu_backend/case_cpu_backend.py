@@ -87,8 +87,8 @@ def test_acceptance_entry_points_match_the_oracle():
     assert counters.tolist() == list(gctr)
     x = rng.standard_normal((6, 1000)).astype(np.float32)
     assert ops.argmax_rows(t(x)).tolist() == sampling.argmax_rows(x).tolist()
-    pv = torch.empty(6, 64)
-    pi = torch.empty(6, 64, dtype=torch.int32)
+    pv = torch.empty(6, ops.ARGMAX_PARTS)
+    pi = torch.empty(6, ops.ARGMAX_PARTS, dtype=torch.int32)
     ops.argmax_partial(t(x), pv, pi)
     assert ops.argmax_from_partials(pv, pi, 6).tolist() == sampling.argmax_rows(x).tolist()
 

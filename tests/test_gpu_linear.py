@@ -464,6 +464,48 @@ def test_w8a8_wide_qkv_rope_against_the_bf16_activation_form():
         assert (a.float() - b.float()).abs().max().item() < b.float().abs().max().item() / 16
 
 
+# ------------------------------------------------------------------ LM head with the argmax inside
+@pytest.mark.parametrize("ln", [False, True])
+@pytest.mark.parametrize("M,N,K", [(1, 128256, 2048), (6, 128256, 4096), (2, 300, 256), (16, 1000, 512),
+                                   (3, 8192, 896)])
+def test_lm_head_argmax_epilogue_equals_argmax_of_its_logits(M, N, K, ln):
+    """sd_norm_linear_argmax: every row's first argmax from the slice maxima the head's workgroups
+    leave equals the first argmax of the f32 logits the F32 epilogue writes (same kernel, same
+    bits), also with exact ties (duplicated weight rows: the lowest column wins) and fp8 weights."""
+    ops = _ops()
+    if ln and K > 4096:
+        pytest.skip("LayerNorm rows beyond 4096 columns are not fused")
+    gen = torch.Generator(device="cuda").manual_seed(M * 31 + N)
+    x = torch.randn(M, K, generator=gen, device="cuda").to(torch.bfloat16)
+    g = (1 + 0.1 * torch.randn(K, generator=gen, device="cuda")).to(torch.bfloat16)
+    b = (0.1 * torch.randn(K, generator=gen, device="cuda")).to(torch.bfloat16) if ln else None
+    W = (torch.randn(N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    for variant in ("bf16", "ties", "fp8"):
+        if variant == "ties":      # the row maxima appear two and three times
+            logits = ops.norm_linear(ops.tile_weights(W), x, g, b, 1e-5, ln, None, ops.EPI_F32)
+            top = logits.argmax(-1)
+            for m in range(M):
+                t = int(top[m])
+                for dst in ((t + 97) % N, (t + N // 2) % N):
+                    W[dst] = W[t]
+        if variant == "fp8":
+            q, sc = ops.quantize_fp8(W)
+            Wt = ops.tile_weights(q, ops.TILE_PLAIN, scale=sc)
+        else:
+            Wt = ops.tile_weights(W)
+        logits = ops.norm_linear(Wt, x, g, b, 1e-5, ln, None, ops.EPI_F32)
+        pv, pi = ops.norm_linear_argmax(Wt, x, g, b, 1e-5, ln)
+        got = ops.argmax_from_partials(pv, pi, M)
+        want = ops.argmax_rows(logits)
+        assert got.tolist() == want.tolist(), variant
+        assert torch.equal(pv.max(dim=1).values, logits.max(dim=1).values)
+        if variant == "ties":
+            mx = logits.max(dim=1, keepdim=True).values
+            first = (logits == mx).float().argmax(dim=1)
+            assert got.tolist() == first.tolist()
+            assert ((logits == mx).sum(1) >= 2).float().mean().item() >= 0.5   # (rows may overwrite each other's copies)
+
+
 # ------------------------------------------------------------------ 17..256 token rows
 @pytest.mark.parametrize("M", [17, 32, 50, 192, 256])
 @pytest.mark.parametrize("N,K", [(64, 512), (130, 768), (1024, 4096), (257, 896), (96, 14336)])

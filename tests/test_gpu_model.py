@@ -259,6 +259,35 @@ def test_fp8_activations_on_the_wide_family(use_graph):
         DecoderModel(_product(tcfg, _bf(random_state(tcfg, seed=21))), 128, 128, fp8_activations=True)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_forward_leaves_the_slice_maxima_of_its_logits(wide):
+    """A pass asked for the slice maxima (argmax_parts) gives the argmax of the logits a plain pass
+    writes: from the LM head itself on the narrow family (no logits written), through the logits
+    on the wide one."""
+    from vllm_omni_draft_amd import ops
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    cfg = MODELS["llama3_rope_gqa4"]
+    w = _product(cfg, _bf(random_state(cfg, seed=12)))
+    toks = torch.randint(0, cfg.vocab, (30,), generator=torch.Generator().manual_seed(4)).tolist()
+    ref = _logits_via_engine(w, toks, [8, 8, 8, 6], wide=wide)
+    model = DecoderModel(w, max_ctx=128, split_tokens=128, wide=wide)
+    kv = PagedKVCache(cfg, 16, 1, 128, "cuda")
+    kv.ensure_capacity(0, len(toks))
+    tok = torch.tensor(toks, dtype=torch.int32, device="cuda")
+    zero = torch.zeros(1, dtype=torch.int32, device="cuda")
+    got, c0 = [], 0
+    for q in (8, 8, 8, 6):
+        pv = torch.empty(q, ops.ARGMAX_PARTS, dtype=torch.float32, device="cuda")
+        pi = torch.empty(q, ops.ARGMAX_PARTS, dtype=torch.int32, device="cuda")
+        lg = torch.full((q, cfg.vocab), float("nan"), dtype=torch.float32, device="cuda")
+        model.forward(kv, tok, 0, c0, zero, c0, 1, q, lg, 128, argmax_parts=(pv, pi))
+        got += ops.argmax_from_partials(pv, pi, q).tolist()
+        assert bool(lg.isnan().all()) == (not wide)      # narrow: the head wrote no logits
+        c0 += q
+    assert got == ref.argmax(-1).tolist()
+
+
 def test_chunking_is_bit_invariant():
     """Logits of a token do not depend on how many rows shared its pass."""
     ocfg = MODELS["llama"]

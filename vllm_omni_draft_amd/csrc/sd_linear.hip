@@ -30,6 +30,7 @@ namespace {
 enum { NORM_NONE = 0, NORM_RMS = 1, NORM_LAYER = 2, STAGE_ATTN_MERGE = 3, NORM_RMS_ADD = 4 };
 constexpr int kMergeMaxSplits = 8;
 constexpr int EPI_QKV_ROPE = 100;  // internal: sd_norm_qkv_rope
+constexpr int EPI_ARGMAX = 101;    // internal: sd_norm_linear_argmax (slice maxima instead of logits)
 constexpr int kLinThreads = 512;
 constexpr int kLinWaves = kLinThreads / SD_WAVE;
 constexpr int kSeg = 8;            // k-steps per segment
@@ -81,6 +82,7 @@ struct LinArgs {
   const float* add;        // NORM_RMS_ADD: [M][ld_add] f32
   int64_t ld_add;
   bf16_t* x_out;           // NORM_RMS_ADD: [M][ldx] bf16 = x + add, or NULL
+  int32_t* part_idx;       // EPI_ARGMAX: [M][SD_ARGMAX_PARTS] beside out = part_val (f32)
 };
 
 // HALF: a work unit is 8 of a tile's 16 rows (lanes of the other 8 rows load nothing and
@@ -394,6 +396,10 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
   const int nl = 4 * (tid >> 6) + (tid & 3), m = (tid >> 2) & 15;
   const bool epi_live = tid < 256 && m < M && (!HALF || (nl >> 3) == row_half);
   // Inputs of the epilogue are fetched while the weights stream, not after the sum.
+  // EPI_ARGMAX: this thread's largest output so far and its column (columns come in increasing
+  // order, so the first maximum wins)
+  float best_v = -INFINITY;
+  int best_i = 0x7fffffff;
   int q_pos = -1, q_page = 0, q_b = 0;
   if (QKV && epi_live) {
     const RopeArgs& rp = a.rope;
@@ -542,7 +548,12 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
         if (n < a.N) {
           const float y = total(tid) * sc0 + pre0;
           const size_t o = (size_t)m * a.ldo + n;
-          if (EPI == SD_EPI_F32) {
+          if (EPI == EPI_ARGMAX) {
+            if (y > best_v) {
+              best_v = y;
+              best_i = n;
+            }
+          } else if (EPI == SD_EPI_F32) {
             reinterpret_cast<float*>(a.out)[o] = y;
           } else {
             bf16_t* ob = reinterpret_cast<bf16_t*>(a.out);
@@ -557,6 +568,47 @@ __global__ __launch_bounds__(kLinThreads) void linear_kernel(LinArgs a) {
     LSTAMP(4);
     // No barrier here: the next tile writes the other half of `red`, and no wave
     // can get two tiles ahead of a reader because of the barrier above.
+  }
+  if (EPI == EPI_ARGMAX) {
+    // The workgroup's maximum per token row -> slot blockIdx.x of the row's slice maxima (values
+    // are the f32 logits the F32 epilogue would have stored; ties go to the lowest column).
+    // A token's 16 tile rows sit in lanes 4m..4m+3 of waves 0..3.
+    auto take = [&](float ov, int oi) {
+      if (ov > best_v || (ov == best_v && oi < best_i)) {
+        best_v = ov;
+        best_i = oi;
+      }
+    };
+    take(__shfl_xor(best_v, 1, 64), __shfl_xor(best_i, 1, 64));
+    take(__shfl_xor(best_v, 2, 64), __shfl_xor(best_i, 2, 64));
+    __syncthreads();  // the last tile's sums have been read
+    float* s_v = red;                                      // [4][16]
+    int* s_i = reinterpret_cast<int*>(red + 64);           // [4][16]
+    if (tid < 256 && (tid & 3) == 0) {
+      s_v[(tid >> 6) * 16 + m] = best_v;
+      s_i[(tid >> 6) * 16 + m] = best_i;
+    }
+    __syncthreads();
+    if (tid < 16 && tid < M) {
+      float bv = s_v[tid];
+      int bi = s_i[tid];
+      for (int w = 1; w < 4; ++w) {
+        const float ov = s_v[w * 16 + tid];
+        const int oi = s_i[w * 16 + tid];
+        if (ov > bv || (ov == bv && oi < bi)) {
+          bv = ov;
+          bi = oi;
+        }
+      }
+      float* pv = reinterpret_cast<float*>(a.out) + (size_t)tid * SD_ARGMAX_PARTS;
+      int32_t* pi = a.part_idx + (size_t)tid * SD_ARGMAX_PARTS;
+      pv[blockIdx.x] = bv;
+      pi[blockIdx.x] = bi;
+      for (int slot = blockIdx.x + gridDim.x; slot < SD_ARGMAX_PARTS; slot += gridDim.x) {
+        pv[slot] = -INFINITY;     // slots no workgroup owns
+        pi[slot] = 0x7fffffff;
+      }
+    }
   }
 }
 
@@ -632,6 +684,11 @@ int launch_n(LinArgs& a, int epi, hipStream_t st) {
     if (epi == SD_EPI_STORE) return launch_one<SD_EPI_STORE, NORM>(a, st);
     if (epi == SD_EPI_RESIDUAL) return launch_one<SD_EPI_RESIDUAL, NORM>(a, st);
     sd_set_error("sd_linear_attn_merge: epilogue %d not available", epi);
+    return SD_ERR_UNSUPPORTED;
+  }
+  if (epi == EPI_ARGMAX) {
+    if constexpr (NORM == NORM_RMS || NORM == NORM_LAYER) return launch_one<EPI_ARGMAX, NORM>(a, st);
+    sd_set_error("sd_norm_linear_argmax: needs a fused norm");
     return SD_ERR_UNSUPPORTED;
   }
   switch (epi) {
@@ -1041,6 +1098,20 @@ extern "C" int sd_norm_linear_adds(const void* W, const float* w_scale, const vo
   const int rc = apply_adds(a, adds, &norm, "sd_norm_linear_adds");
   if (rc != SD_OK) return rc;
   return linear_common(a, epilogue, norm, (hipStream_t)stream);
+}
+
+extern "C" int sd_norm_linear_argmax(const void* W, const float* w_scale, const void* x, int64_t ldx,
+                                     const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                                     float* part_val, int32_t* part_idx, int M, int N, int K,
+                                     sd_stream_t stream) {
+  SD_REQUIRE(part_val && part_idx, SD_ERR_INVALID, "sd_norm_linear_argmax: null pointer");
+  LinArgs a{};
+  a.W = (const bf16_t*)W; a.x = (const bf16_t*)x; a.ldx = ldx;
+  a.out = part_val; a.part_idx = part_idx; a.ldo = N; a.M = M; a.N = N; a.K = K;
+  a.w_scale = w_scale;
+  a.n_tiles = tiles_for(N, EPI_ARGMAX);
+  a.norm_w = (const bf16_t*)norm_w; a.norm_b = (const bf16_t*)norm_b; a.eps = eps;
+  return linear_common(a, EPI_ARGMAX, layer_norm ? NORM_LAYER : NORM_RMS, (hipStream_t)stream);
 }
 
 extern "C" int sd_norm_qkv_rope(const void* W, const float* w_scale, const void* x, int64_t ldx,

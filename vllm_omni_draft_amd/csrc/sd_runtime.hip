@@ -283,6 +283,12 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       SD_TRY(sd_norm_linear_adds(d.lm_head, nullptr, h_cur, H, d.final_norm_w, nullptr, d.norm_eps, 0,
                                  nullptr, a->logits, lm_vocab, rows, lm_vocab, H, SD_EPI_F32, &fin, stream));
     }
+    if (a->argmax_val && a->argmax_idx) {  // (this head takes an additive input: through its logits)
+      const int lm_vocab = d.lm_vocab > 0 ? d.lm_vocab : d.vocab;
+      SD_REQUIRE(a->logits, SD_ERR_INVALID,
+                 "sd_model_forward: a three-launch pass needs `logits` for the slice maxima");
+      SD_TRY(sd_argmax_partial(a->logits, lm_vocab, a->argmax_val, a->argmax_idx, rows, lm_vocab, stream));
+    }
     return SD_OK;
   }
   for (int li = 0; li < d.n_layers; ++li) {
@@ -461,6 +467,11 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       SD_TRY(sd_linear_wide(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
                             SD_EPI_F32, base + w.wide_ws, w.wide_ws_bytes, stream));
     }
+  } else if (a->argmax_val && a->argmax_idx && !fused3 && sd_fused_norm_fits(rows, H, !llama)) {
+    // greedy pass: the head's workgroups leave the slice maxima themselves, no logits
+    SD_TRY(sd_norm_linear_argmax(d.lm_head, d.lm_head_s, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps,
+                                 !llama, a->argmax_val, a->argmax_idx, rows, lm_vocab, H, stream));
+    return SD_OK;
   } else if (a->logits) {
     if (sd_fused_norm_fits(rows, H, !llama)) {
       SD_TRY(sd_norm_linear(d.lm_head, d.lm_head_s, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
@@ -471,6 +482,11 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
       SD_TRY(sd_linear(d.lm_head, d.lm_head_s, xn, H, nullptr, nullptr, a->logits, lm_vocab, rows, lm_vocab, H,
                        SD_EPI_F32, stream));
     }
+  }
+  if (a->argmax_val && a->argmax_idx) {  // (the head could not leave the slice maxima itself)
+    SD_REQUIRE(a->logits, SD_ERR_INVALID,
+               "sd_model_forward: this pass's shape needs `logits` for the slice maxima");
+    SD_TRY(sd_argmax_partial(a->logits, lm_vocab, a->argmax_val, a->argmax_idx, rows, lm_vocab, stream));
   }
   return SD_OK;
 }

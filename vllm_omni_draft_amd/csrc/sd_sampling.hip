@@ -1226,19 +1226,20 @@ __global__ void advance_state_kernel(const int64_t* __restrict__ out_ids,
 
 constexpr int kArgmaxParts = SD_ARGMAX_PARTS;
 
-// Stage 1 of a split row argmax: block (part, row) scans one 1/64 slice of the row.
-__global__ __launch_bounds__(256) void argmax_partial_kernel(
+// Stage 1 of a split row argmax: wave (part, row) scans one of the row's kArgmaxParts slices.
+// (The LM head of a greedy pass can leave the same slots itself: sd_norm_linear_argmax, one slot
+// per workgroup of its launch, which is why there are as many slots as that launch has
+// workgroups at most.)
+__global__ __launch_bounds__(SD_WAVE) void argmax_partial_kernel(
     const float* __restrict__ logits, int64_t ld, float* __restrict__ part_val,
     int32_t* __restrict__ part_idx, int V) {
-  __shared__ float s_f[4];
-  __shared__ int s_i[4];
   const int part = blockIdx.x, r = blockIdx.y;
   const int chunk = ((V + kArgmaxParts - 1) / kArgmaxParts + 3) & ~3;
   const int lo = part * chunk, hi = min(lo + chunk, V);
   const float* row = logits + (size_t)r * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+  for (int i = lo + threadIdx.x * 4; i < hi; i += SD_WAVE * 4) {
     if (i + 3 < hi) {
       const float4 v = *reinterpret_cast<const float4*>(row + i);
       const float e[4] = {v.x, v.y, v.z, v.w};
@@ -1256,23 +1257,24 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(
     const int oi = __shfl_xor(bi, o, 64);
     if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s_f[wave] = best; s_i[wave] = bi; }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (s_f[w] > best || (s_f[w] == best && s_i[w] < bi)) { best = s_f[w]; bi = s_i[w]; }
     part_val[(size_t)r * kArgmaxParts + part] = best;
     part_idx[(size_t)r * kArgmaxParts + part] = bi;
   }
 }
 
-// Stage 2, one wave per row: the smallest index among the row's maxima.
+// Stage 2, one wave per row: the smallest index among the row's maxima (slots in any order).
 __device__ __forceinline__ int wave_argmax_finish(const float* __restrict__ part_val,
                                                   const int32_t* __restrict__ part_idx, int row,
                                                   int lane) {
-  float best = part_val[(size_t)row * kArgmaxParts + lane];
-  int bi = part_idx[(size_t)row * kArgmaxParts + lane];
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < kArgmaxParts / SD_WAVE; ++j) {
+    const float v = part_val[(size_t)row * kArgmaxParts + j * SD_WAVE + lane];
+    const int id = part_idx[(size_t)row * kArgmaxParts + j * SD_WAVE + lane];
+    if (v > best || (v == best && id < bi)) { best = v; bi = id; }
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const float ov = __shfl_xor(best, o, 64);
@@ -1782,7 +1784,7 @@ extern "C" int sd_argmax_partial(const float* logits, int64_t ld, float* part_va
   SD_REQUIRE(ld >= V && ld % 4 == 0 && sd_aligned16(logits), SD_ERR_INVALID,
              "sd_argmax_partial: rows must be 16-byte aligned");
   if (R == 0) return SD_OK;
-  hipLaunchKernelGGL(argmax_partial_kernel, dim3(kArgmaxParts, R), dim3(256), 0,
+  hipLaunchKernelGGL(argmax_partial_kernel, dim3(kArgmaxParts, R), dim3(SD_WAVE), 0,
                      (hipStream_t)stream, logits, ld, part_val, part_idx, V);
   SD_CHECK_LAUNCH("sd_argmax_partial");
   return SD_OK;

@@ -1027,6 +1027,17 @@ extern "C" int sd_norm_linear(const void* W, const float* ws, const void* x, int
   return linear_any(W, ws, x, ldx, norm_w, norm_b, eps, layer_norm, bias, nullptr, out, ldo, M, N, K, epi,
                     "sd_norm_linear");
 }
+extern "C" int sd_norm_linear_argmax(const void* W, const float* ws, const void* x, int64_t ldx,
+                                     const void* norm_w, const void* norm_b, float eps, int layer_norm,
+                                     float* part_val, int32_t* part_idx, int M, int N, int K,
+                                     sd_stream_t st) {
+  REQUIRE(part_val && part_idx, SD_ERR_INVALID, "sd_norm_linear_argmax: null pointer");
+  std::vector<float> logits((size_t)std::max(M, 0) * N);
+  const int rc = sd_norm_linear(W, ws, x, ldx, norm_w, norm_b, eps, layer_norm, nullptr, logits.data(), N, M,
+                                N, K, SD_EPI_F32, st);
+  if (rc) return rc;
+  return sd_argmax_partial(logits.data(), N, part_val, part_idx, M, N, st);
+}
 extern "C" int sd_linear_attn_merge(const void*, const float*, const void*, size_t, const int32_t*, int,
                                     int, int, int, int, int, int, int, const void*, const void*, void*,
                                     int64_t, int, int, sd_stream_t) {
@@ -1224,6 +1235,9 @@ extern "C" int sd_model_forward(sd_model* m, const sd_kv_cache* kv, const sd_for
     rc = sd_linear(l.down_w, nullptr, act, F, l.down_b, h, h, H, rows, H, F, SD_EPI_RESIDUAL, st);
     if (rc) return rc;
   }
+  if (a->argmax_val && a->argmax_idx)   // the slice maxima of the rows' logits (logits optional)
+    return sd_norm_linear_argmax(d.lm_head, nullptr, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps,
+                                 !llama, a->argmax_val, a->argmax_idx, rows, d.vocab, H, st);
   if (a->logits)
     return sd_norm_linear(d.lm_head, nullptr, h, H, d.final_norm_w, d.final_norm_b, d.norm_eps, !llama,
                           nullptr, a->logits, d.vocab, rows, d.vocab, H, SD_EPI_F32, st);

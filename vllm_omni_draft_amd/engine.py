@@ -942,10 +942,13 @@ class SpecEngine:
 
     # ------------------------------------------------------------------ passes
     def _forward(self, model: DecoderModel, kv: PagedKVCache, tokens, tok_stride, tok_offset,
-                 seq_lens, pos_offset, B, q_len, logits, slot0: int = 0, tree=None) -> None:
+                 seq_lens, pos_offset, B, q_len, logits, slot0: int = 0, tree=None,
+                 parts: bool = False) -> None:
         """One model pass over B sequences x q_len tokens, in sub-batches of at
         most max_rows token rows.  tree: (ancestor masks, rotary positions), each with one entry
-        per token row, for a pass over token trees."""
+        per token row, for a pass over token trees.  parts: the pass also leaves the slice maxima
+        of its rows' logits in part_val / part_idx (greedy steps: the LM head writes them itself
+        where it can, and no logits)."""
         per = max(1, model.max_rows // q_len)
         starts = list(range(0, B, per))
         lanes = len(starts) > 1 and model is self.draft and bool(self._lanes)
@@ -969,6 +972,8 @@ class SpecEngine:
             extra = {}
             if tree is not None:
                 extra = dict(tree_mask=tree[0].view(-1)[b0 * q_len:], rope_pos=tree[1][b0 * q_len:])
+            if parts:
+                extra["argmax_parts"] = (self.part_val[b0 * q_len:], self.part_idx[b0 * q_len:])
             with _rt.stream_ctx(stream if lanes else None):
                 model.forward(view, tokens.view(-1)[b0 * tok_stride:] if tok_stride else tokens,
                               tok_stride, tok_offset, seq_lens[b0:], pos_offset, nb, q_len, sub_logits,
@@ -1034,8 +1039,16 @@ class SpecEngine:
                           self.gen_tokens[:B], self.gen_counts[:B], k, self._records[self._parity, :B])
 
     # -- the target's logits after a pass of n rows (whole, or one vocabulary slice per rank)
+    def _target_head_fused(self) -> bool:
+        """Whether a greedy target pass may leave the slice maxima itself (no logits): nothing
+        downstream needs the logits (no logit masks, no log-probabilities, whole vocabulary on
+        this rank)."""
+        return not self.sampling and not self.vp and self.bias is None and self.logprobs_top is None
+
     def _target_partials(self, n: int) -> None:
         """Slice maxima of rows 0..n-1 over the whole vocabulary -> part_val / part_idx."""
+        if self._target_head_fused():
+            return                       # the pass left them there (_forward(parts=True))
         self._partials(self.t_out, n, self.vp)
 
     def _partials(self, out: torch.Tensor, n: int, split: bool) -> None:
@@ -1070,7 +1083,7 @@ class SpecEngine:
     def _enqueue_ar_step(self) -> None:
         B = self.active
         self._forward(self.target, self.t_kv, self.tok_buf, 2, 1, self.seq_lens, -1, B, 1,
-                      self.t_out)
+                      self.t_out, parts=self._target_head_fused())
         self._apply_bias(B, 1)
         if self.sampling:
             self._target_full_rows(B)
@@ -1205,20 +1218,22 @@ class SpecEngine:
         pass instead of three, and no draft_ids gather."""
         B, k = self.active, self.k
         stride = k + 2
+        head_fused = fused and not self.d_vp     # the draft's head leaves the slice maxima itself
         for i in range(k):
             if i == 0:
                 self._forward(self.draft, self.d_kv, self.tok_buf, stride, 0, self.seq_lens, -2, B, 2,
-                              self.d_out)
+                              self.d_out, parts=head_fused)
                 off, step = 1, 2
             else:
                 self._forward(self.draft, self.d_kv, self.tok_buf, stride, 1 + i, self.seq_lens,
-                              -1 + i, B, 1, self.d_out)
+                              -1 + i, B, 1, self.d_out, parts=head_fused)
                 off, step = 0, 1
             if self.d_vp and (self.sampling or not fused):
                 self._gather_rows(self.d_out, self.d_logits, B * step)   # whole rows on every rank
             rows = (self.d_out if self.d_map is not None else self.d_logits)[:B * step]
             if fused:
-                self._partials(self.d_out, B * step, self.d_vp)
+                if not head_fused:
+                    self._partials(self.d_out, B * step, self.d_vp)
                 ops.propose_from_partials(self.part_val, self.part_idx, off, step,
                                           self.tok_buf[:B], k, i)
                 if self.d_map is not None:
@@ -1329,7 +1344,7 @@ class SpecEngine:
         t_logits [B*(k+1), V], plus target_ids (greedy) or t_probs / bonus_ids."""
         B, k = self.active, self.k
         self._forward(self.target, self.t_kv, self.tok_buf, k + 2, 1, self.seq_lens, -1, B, k + 1,
-                      self.t_out)
+                      self.t_out, parts=fused and self._target_head_fused())
         self._apply_bias(B * (k + 1), k + 1)
         rows = self.t_logits[:B * (k + 1)]
         if fused:
@@ -1526,7 +1541,7 @@ class SpecEngine:
         lib = _lib.load()
         if self.cfg.use_graph and _rt.on_gpu():   # (the CPU build has no stream capture)
             key = (B, k, self.truth is not None, self._ctx, self._spec_disabled(), self._parity,
-                   self.bias is not None, self.bias is not None and self.logprobs_top is not None)
+                   self.bias is not None, self.logprobs_top is not None)
             # (a tree step has one shape too: every sequence's tree is padded to tree_nodes rows)
             g = self._graphs.get(key)
             if g is None:

@@ -126,7 +126,8 @@ class DecoderModel:
                 rope_pos: Optional[torch.Tensor] = None,
                 rope_delta: Optional[torch.Tensor] = None,
                 workspace: Optional[torch.Tensor] = None,
-                tree_mask: Optional[torch.Tensor] = None) -> None:
+                tree_mask: Optional[torch.Tensor] = None,
+                argmax_parts: Optional[tuple] = None) -> None:
         """Enqueues one pass over B*q_len token rows on the current stream.
         Token t of sequence b is token_ids[b*tok_stride + tok_offset + t] at
         position seq_lens[b] + pos_offset + t.  `logits` ([B*q_len, vocab] f32)
@@ -137,7 +138,11 @@ class DecoderModel:
         the size of self.workspace, for passes that run concurrently on several streams.
         Token trees: tree_mask (int64 [B*q_len], bit j of entry b*q_len+t: row t attends new
         row j) with rope_pos = the rows' rotary positions (int32 [B*q_len]); rotary models
-        without mrope_section only."""
+        without mrope_section only.  argmax_parts (part_val f32, part_idx i32, each
+        [B*q_len, ops.ARGMAX_PARTS]): the pass leaves the slice maxima of every row's logits there
+        (greedy consumers: ops.propose_from_partials / verify_from_partials /
+        argmax_from_partials), straight from the LM head where the pass's shape allows (then
+        `logits` is not written), else through `logits`, which must then be given."""
         ws = self.workspace if workspace is None else workspace
         if ws.numel() < self.workspace.numel() or ws.dtype != torch.uint8:
             raise _lib.SdError("workspace must be a uint8 tensor of at least self.workspace's size")
@@ -159,6 +164,12 @@ class DecoderModel:
             raise _lib.SdError("rope_pos must be a contiguous int32 [3, B*q_len] tensor")
         if rope_delta is not None and (rope_delta.dtype != torch.int32 or rope_delta.numel() < B):
             raise _lib.SdError("rope_delta must be an int32 tensor of at least B entries")
+        if argmax_parts is not None:
+            pv, pi = argmax_parts
+            if (pv.dtype != torch.float32 or pi.dtype != torch.int32 or not pv.is_contiguous()
+                    or not pi.is_contiguous() or pv.numel() < rows * ops.ARGMAX_PARTS
+                    or pi.numel() < rows * ops.ARGMAX_PARTS):
+                raise _lib.SdError("argmax_parts: contiguous (f32, i32) tensors of [B*q_len, ARGMAX_PARTS]")
         if ((rope_pos is not None and tree_mask is None) or rope_delta is not None) and not self.cfg.mrope_section:
             raise _lib.SdError("rotary positions given to a model without mrope_section")
         if token_ids.dtype != torch.int32 or seq_lens.dtype != torch.int32:
@@ -180,7 +191,9 @@ class DecoderModel:
                                 chain_state=_ptr(self.chain_state) if workspace is None else None,
                                 draft_fused=int(self.fused_layers),
                                 read_ahead_mb=int(self.read_ahead_mb),
-                                wide_a8=int(self.fp8_activations))
+                                wide_a8=int(self.fp8_activations),
+                                argmax_val=_ptr(argmax_parts[0]) if argmax_parts else None,
+                                argmax_idx=_ptr(argmax_parts[1]) if argmax_parts else None)
         rc = _lib.load().sd_model_forward(self._handle, C.byref(kvd), C.byref(args),
                                           ws.data_ptr(), ws.numel(),
                                           ops._stream())

@@ -746,7 +746,7 @@ def advance_state(out_ids, seq_lens, tok_buf, gen_tokens, gen_counts, k, step_ou
         _stream()), "sd_advance_state")
 
 
-ARGMAX_PARTS = 64
+ARGMAX_PARTS = 512
 
 
 def argmax_partial(logits, part_val, part_idx) -> None:
@@ -831,6 +831,24 @@ def norm_linear(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, bias=None
                                           int(layer_norm), _p(bias), _p(out), N, M, N, K, epilogue,
                                           _stream()), "sd_norm_linear")
     return out
+
+
+def norm_linear_argmax(W, x, norm_w, norm_b=None, eps=1e-5, layer_norm=False, part_val=None,
+                       part_idx=None):
+    """The LM head of a greedy pass without logits: the slice maxima (part_val f32, part_idx i32,
+    [M, ARGMAX_PARTS]) of norm(x) @ W^T, for argmax_from_partials / propose_from_partials /
+    verify_from_partials (sd_norm_linear_argmax)."""
+    _need(x, torch.bfloat16, "x")
+    Wt = _tiled(W, EPI_F32)
+    M, K = x.shape
+    if part_val is None:
+        part_val = torch.empty(M, ARGMAX_PARTS, dtype=torch.float32, device=x.device)
+        part_idx = torch.empty(M, ARGMAX_PARTS, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().sd_norm_linear_argmax(_p(Wt.data), _p(Wt.scale), _p(x), x.stride(0), _p(norm_w),
+                                                 _p(norm_b), float(eps), int(layer_norm), _p(part_val),
+                                                 _p(part_idx), M, Wt.N, K, _stream()),
+               "sd_norm_linear_argmax")
+    return part_val, part_idx
 
 
 def norm_qkv_rope(W, x, norm_w, norm_b, eps, layer_norm, bias, rope_cs, k_cache, v_cache,
