@@ -256,6 +256,76 @@ def test_token_trees_on_the_cpu_build():
     assert eng.tree_mask[0, :n].tolist() == otree.ancestor_masks(p)
 
 
+def test_draft_grown_trees_on_the_cpu_build():
+    """draft_tree_branches: the draft's b best first tokens, each continued greedily to depth k
+    by tree-masked draft passes, verified in one target pass.  The stream is the autoregressive
+    one; with draft == target the first branch IS the target's continuation, so every step accepts
+    k tokens (which needs the draft's cache compacted like the target's); the tokens of the tree
+    equal what the draft model gives for each branch's prefix on its own (sd_topk_tokens picks
+    the b largest in order, the level passes see their own branch only)."""
+    from vllm_omni_draft_amd import ops
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    oc = OracleConfig(arch="llama", n_layers=2, hidden=128, n_heads=4, n_kv_heads=2, head_dim=64, ffn=256,
+                      vocab=256, max_pos=160)
+    w = _product(oc, _bf(random_state(oc, seed=3)))
+    d = _product(oc, _bf(random_state(oc, seed=4)))
+    rng = np.random.default_rng(8)
+    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in (7, 1, 19)]
+
+    def run(draft, n_new=30, **kw):
+        eng = SpecEngine(w, draft, EngineConfig(max_batch=3, max_seq_len=120, split_tokens=128, **kw))
+        outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+        steps = 0
+        while min(len(o) for o in outs) < n_new:
+            for o, new in zip(outs, eng.step()):
+                o.extend(new)
+            steps += 1
+        return [o[:n_new] for o in outs], steps, eng
+
+    ar, _, _ = run(None, k=0)
+    got, steps, eng = run(w, k=3, draft_tree_branches=3)
+    assert eng.tree and eng.tree_nodes == 9 and got == ar
+    m = eng.metrics()
+    assert m["accepted"] == 3 * 3 * steps, m             # the first branch stands whole, every step
+    got, steps_tree, eng = run(d, k=3, draft_tree_branches=3)
+    assert got == ar
+    _, steps_chain, _ = run(d, k=3)
+    assert steps_tree <= steps_chain                      # branch 0 is the chain the draft proposes alone
+    # the tree of the last step, branch by branch, against the draft run on that branch's prefix
+    eng.prepare_step()
+    root_len = eng.seq_lens[:3].tolist()
+    eng._enqueue_step()
+    tok = eng.tree_tok[:3].tolist()
+    from vllm_omni_draft_amd.model_runner import DecoderModel, PagedKVCache
+    model = DecoderModel(d, 160, 128)
+    for b in range(3):
+        # (the engine's own stream up to the root)
+        prefix = (prompts[b] + eng.gen_tokens[b, :eng.gen_counts[b].item()].tolist())[:root_len[b]]
+        assert prefix[-1] == tok[b][0]
+        kv = PagedKVCache(oc, PagedKVCache.pages_for(oc, 1, 160), 1, 160, "cpu")
+        kv.ensure_capacity(0, 160)
+
+        def next_logits(seq):
+            t = torch.tensor(seq, dtype=torch.int32)
+            lg = torch.empty(len(seq), oc.vocab)
+            model.forward(kv, t, 0, 0, torch.zeros(1, dtype=torch.int32), 0, 1, len(seq), lg, 160)
+            return lg[-1]
+        first = torch.sort(next_logits(prefix), descending=True, stable=True).indices[:3].tolist()
+        assert [tok[b][1 + c] for c in range(3)] == first
+        for c in range(3):
+            seq = prefix + [first[c]]
+            for depth in (2, 3):
+                nxt = int(next_logits(seq).argmax())
+                assert tok[b][1 + (depth - 1) * 3 + c] == nxt, (b, c, depth)
+                seq.append(nxt)
+    with pytest.raises(ValueError):
+        run(w, k=3, draft_tree_branches=3, tree_candidates=2)
+    with pytest.raises(ValueError):
+        run(None, k=3, draft_tree_branches=3, ngram_max=2)
+    with pytest.raises(ValueError):
+        run(w, k=8, draft_tree_branches=4)               # 32 nodes: more than a verify pass holds
+
+
 def test_tree_sampling_walk_matches_the_oracle():
     """sd_tree_accept_sample of the CPU build against the oracle (ids, rows and counters equal),
     and a sampling engine with prompt-lookup trees steps through it."""

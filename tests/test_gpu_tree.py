@@ -445,3 +445,171 @@ def test_tree_mode_refuses_what_it_cannot_do():
     ow = _product(ocfg, _bf(random_state(ocfg, seed=3)))
     with pytest.raises(ValueError):
         _engine(ow, None, 3, ngram_max=2, tree_candidates=2)              # learned positions
+
+
+# --------------------------------------------------------------------------- draft-grown trees
+@pytest.mark.parametrize("V", [50, 1000, 128256])
+def test_topk_tokens_against_a_stable_sort(V):
+    """sd_topk_tokens: the b largest entries of strided rows, largest first, equal values in
+    index order (what a stable descending sort gives), written as int32 tokens at a column of a
+    strided table; b = 1 is the arg-max with the lowest index among equals."""
+    from vllm_omni_draft_amd import ops
+    g = torch.Generator().manual_seed(V)
+    R = 11
+    x = torch.randn(R, V, generator=g)
+    x[1] = torch.round(x[1] * 2) / 2                    # many exact ties
+    x[2] = 0.0                                          # all equal: tokens 0..b-1
+    x[3, V - 1], x[3, 0] = 9.0, 9.0
+    x[4] = float("-inf")
+    x[4, V // 2] = -3.0                                 # one finite entry, then -inf ties
+    xd = x.cuda()
+    for b, off, step in ((1, 0, 1), (3, 1, 2), (8, 2, 3), (4, 0, 5)):
+        n = (R - off + step - 1) // step
+        out = torch.full((n, 12), -5, dtype=torch.int32).cuda()
+        ops.topk_tokens(xd, b, out, 2, row_offset=off, row_step=step)
+        torch.cuda.synchronize()
+        want = torch.sort(x[off::step], dim=1, descending=True, stable=True).indices[:, :b]
+        assert out[:, 2:2 + b].cpu().tolist() == want.tolist(), (b, off, step)
+        assert (out[:, :2] == -5).all() and (out[:, 2 + b:] == -5).all()
+    with pytest.raises(Exception):
+        ops.topk_tokens(xd, ops.TOPK_TOKENS_MAX + 1, torch.zeros(R, 12, dtype=torch.int32).cuda(), 0)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("rows", ["narrow", "wide"])
+def test_draft_grown_trees_streams_equal_autoregressive(use_graph, rows):
+    """draft_tree_branches: b branches of depth k grown by the draft model and verified in one
+    target pass.  Streams are the autoregressive ones; a tree step never accepts less than the
+    chain the same draft proposes alone (branch 0 is that chain), so it takes no more steps; with
+    draft == target branch 0 is the target's own continuation and every step accepts k tokens,
+    which also needs the draft's cache compacted to the accepted path."""
+    oc = MODELS["llama"]
+    dc = OracleConfig(**{**vars(oc), "n_layers": 1})
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    dw = _product(dc, _bf(random_state(dc, seed=23)))
+    rng = np.random.default_rng(4)
+    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in (9, 1, 33)]
+    n_new = 40
+    ar = [_generate(_engine(tw, None, 0, rows=rows), [p], n_new)[0] for p in prompts]
+
+    def run(eng):
+        outs, steps = [[eng.add_request(i, p)] for i, p in enumerate(prompts)], 0
+        while min(len(o) for o in outs) < n_new:
+            for o, new in zip(outs, eng.step()):
+                o.extend(new)
+            steps += 1
+        return [o[:n_new] for o in outs], steps
+
+    kw = dict(max_batch=3, use_graph=use_graph, rows=rows, draft_rows="same")
+    got_chain, steps_chain = run(_engine(tw, dw, 3, **kw))
+    assert got_chain == ar
+    eng = _engine(tw, dw, 3, draft_tree_branches=4, **kw)
+    assert eng.tree and eng.tree_nodes == 12
+    got, steps = run(eng)
+    assert got == ar and steps <= steps_chain
+    m = eng.metrics()
+    assert m["emitted"] - m["accepted"] == 3 * steps
+    same = _engine(tw, tw, 3, draft_tree_branches=3, **kw)
+    got, steps = run(same)
+    assert got == ar and same.metrics()["accepted"] == 9 * steps
+
+
+def test_draft_grown_tree_holds_each_branchs_own_continuation():
+    """The tree a step verifies, node by node: depth 1 holds the draft's b most likely next
+    tokens in order, and every deeper node is the draft's arg-max after its own branch's prefix
+    (computed here by chain passes of the draft over a fresh cache), for sequences whose roots
+    sit at different cache positions."""
+    from vllm_omni_draft_amd.kv_cache import PagedKVCache
+    from vllm_omni_draft_amd.model_runner import DecoderModel
+    oc = MODELS["llama"]
+    dc = OracleConfig(**{**vars(oc), "n_layers": 1})
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    dw = _product(dc, _bf(random_state(dc, seed=23)))
+    prompts = [[5, 9, 200, 31, 7], list(range(40, 57))]
+    nb, k = 4, 3
+    eng = _engine(tw, dw, k, max_batch=2, draft_tree_branches=nb)
+    outs = [[eng.add_request(i, p)] for i, p in enumerate(prompts)]
+    for _ in range(5):
+        for o, new in zip(outs, eng.step()):
+            o.extend(new)
+    eng.prepare_step()
+    root_len = eng.seq_lens[:2].tolist()
+    with torch.cuda.stream(eng.stream):
+        eng._enqueue_step()
+    torch.cuda.synchronize()
+    tok = eng.tree_tok[:2].tolist()
+    model = DecoderModel(dw, 200, 128, wide=True)
+
+    def fresh():
+        kv = PagedKVCache(dc, PagedKVCache.pages_for(dc, 1, 200), 1, 200, "cuda")
+        kv.ensure_capacity(0, 200)
+        return kv
+
+    def next_logits(seq):
+        return _chain_logits(model, fresh, seq, [], 200)
+
+    for b in range(2):
+        prefix = (prompts[b] + outs[b])[:root_len[b]]
+        assert prefix[-1] == tok[b][0]
+        lg = next_logits(prefix)
+        first = torch.sort(lg, descending=True, stable=True).indices[:nb].tolist()
+        assert tok[b][1:1 + nb] == first
+        for c in range(nb):
+            seq = prefix + [first[c]]
+            for depth in range(2, k + 1):
+                lg = next_logits(seq)
+                got = tok[b][1 + (depth - 1) * nb + c]
+                # (a chain pass and a tree pass may differ in the last bf16 step: accept a
+                # runner-up that is as good to that precision)
+                assert got == int(lg.argmax()) or lg[got] >= lg.max() - 0.02 * lg.abs().max(), (b, c, depth)
+                seq.append(got)
+
+
+def test_draft_grown_tree_sampling_follows_the_target_distribution():
+    """Draft-grown trees under sampling (T = 1): the nodes are deterministic functions of the
+    draft, i.e. point-mass proposals; every emitted token is distributed as the ORACLE's
+    target distribution given its predecessor (the tolerance stated for the sampling path)."""
+    from tests.test_gpu_model import _check_transitions, _markov_pair, _transition_matrix
+    from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine
+    cfg, (ts, ds) = _markov_pair()
+    P = _transition_matrix(cfg, ts, 1.0)
+    Q = _transition_matrix(cfg, ds, 1.0)
+    B = 4
+    eng = SpecEngine(_product(cfg, ts), _product(cfg, ds),
+                     EngineConfig(k=3, max_batch=B, max_seq_len=900, split_tokens=128, temperature=1.0,
+                                  seed=17, draft_tree_branches=4))
+    assert eng.tree and eng.sampling and eng.tree_nodes == 12
+    counts = np.zeros((cfg.vocab, cfg.vocab))
+    rounds = 0
+    while counts.sum() < 21000:
+        eng.reset()
+        seqs = [[(5 * b + rounds) % cfg.vocab] for b in range(B)]
+        for b in range(B):
+            seqs[b].append(eng.add_request(b, seqs[b]))
+        for _ in range(200):
+            for b, new in enumerate(eng.step()):
+                assert 1 <= len(new) <= 4 and all(0 <= t < cfg.vocab for t in new)
+                seqs[b].extend(new)
+        for sq in seqs:
+            np.add.at(counts, (sq[:-1], sq[1:]), 1)
+        rounds += 1
+    m = eng.metrics()
+    assert m["accepted"] > 500 and m["emitted"] - m["accepted"] > 500
+    _check_transitions(counts, P)
+    with pytest.raises(AssertionError):
+        _check_transitions(counts, Q)
+
+
+def test_draft_grown_trees_refuse_what_they_cannot_do():
+    oc = MODELS["llama"]
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    with pytest.raises(ValueError):
+        _engine(tw, None, 3, ngram_max=2, draft_tree_branches=3)          # no draft model
+    with pytest.raises(ValueError):
+        _engine(tw, tw, 3, draft_tree_branches=9)                         # more than the top-b kernel ranks
+    with pytest.raises(ValueError):
+        _engine(tw, tw, 8, draft_tree_branches=8)                         # more nodes than a verify pass holds
+    ocfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": oc.vocab})
+    ow = _product(ocfg, _bf(random_state(ocfg, seed=3)))
+    with pytest.raises(ValueError):
+        _engine(tw, ow, 3, draft_tree_branches=3)                         # a draft with learned positions

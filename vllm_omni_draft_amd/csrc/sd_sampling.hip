@@ -320,6 +320,49 @@ __global__ __launch_bounds__(SD_WAVE) void tree_prepare_kernel(
     rope_pos[(size_t)b * q_len + t] = seq_lens[b] + pos_offset + tree_depth[(size_t)b * q_len + t];
 }
 
+// The b largest entries of a logits row as tokens (largest first; ties: lowest index), one
+// workgroup per sequence: b sweeps over the row, each skipping the winners so far.  Feeds the
+// first level of a tree grown by the draft model.
+__global__ __launch_bounds__(kSampleThreads) void topk_tokens_kernel(
+    const float* __restrict__ logits, int64_t ld, int V, int row_offset, int row_step, int b,
+    int32_t* __restrict__ out_tok, int64_t out_stride, int out_col) {
+  __shared__ float s_f[kSampleWaves];
+  __shared__ int s_i[kSampleWaves];
+  __shared__ int s_win[SD_TOPK_TOKENS_MAX];
+  const int seq = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* row = logits + (size_t)(row_offset + seq * row_step) * ld;
+  for (int c = 0; c < b; ++c) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += kSampleThreads) {
+      const float v = row[i];
+      bool taken = false;
+      for (int e = 0; e < c; ++e) taken |= s_win[e] == i;
+      if (!taken && v > best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { s_f[wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kSampleWaves; ++w)
+        if (s_f[w] > best || (s_f[w] == best && s_i[w] < bi)) { best = s_f[w]; bi = s_i[w]; }
+      // (a row with fewer than b finite entries repeats nothing: the free indices follow)
+      if (bi == 0x7fffffff) {
+        bi = 0;
+        for (int e = 0; e < c; ++e) if (s_win[e] == bi) { ++bi; e = -1; }
+      }
+      s_win[c] = bi;
+      out_tok[(size_t)seq * out_stride + out_col + c] = bi;
+    }
+    __syncthreads();
+  }
+}
+
 // One wave per sequence: the walk is a chain of dependent steps, each step a wave-wide
 // search for the child that carries the target's token.
 __global__ __launch_bounds__(SD_WAVE) void tree_accept_greedy_kernel(
@@ -1487,6 +1530,21 @@ extern "C" int sd_tree_accept_sample(const float* target_probs, int64_t ld, cons
                      target_probs, ld, tree_tok, tree_parent, tree_len, q_len, k, u_accept, u_final, V,
                      out_ids, path, n_path, (unsigned long long*)counters);
   SD_CHECK_LAUNCH("sd_tree_accept_sample");
+  return SD_OK;
+}
+
+extern "C" int sd_topk_tokens(const float* logits, int64_t ld, int V, int row_offset, int row_step,
+                              int b, int32_t* out_tok, int64_t out_stride, int out_col, int B,
+                              sd_stream_t stream) {
+  SD_REQUIRE(logits && out_tok && V >= 1 && ld >= V && row_offset >= 0 && row_step >= 1 && B >= 0,
+             SD_ERR_INVALID, "sd_topk_tokens: bad arguments (B=%d V=%d)", B, V);
+  SD_REQUIRE(b >= 1 && b <= SD_TOPK_TOKENS_MAX && b <= V && out_col >= 0 && out_stride >= out_col + b,
+             SD_ERR_INVALID, "sd_topk_tokens: b=%d outside 1..%d or the row is too short", b,
+             SD_TOPK_TOKENS_MAX);
+  if (B == 0) return SD_OK;
+  hipLaunchKernelGGL(topk_tokens_kernel, dim3(B), dim3(kSampleThreads), 0, (hipStream_t)stream, logits,
+                     ld, V, row_offset, row_step, b, out_tok, out_stride, out_col);
+  SD_CHECK_LAUNCH("sd_topk_tokens");
   return SD_OK;
 }
 

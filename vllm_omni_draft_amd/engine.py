@@ -100,6 +100,12 @@ class EngineConfig:
     # proposals (sd_tree_accept_sample).  1 = a single chain of k proposals.
     tree_candidates: int = 1
     tree_nodes: int = 0
+    # > 1: the DRAFT MODEL grows the tree.  Its first pass's b most likely tokens become b
+    # branches under the root; every branch is continued greedily to depth k by tree-masked
+    # draft passes (all branches of a sequence in one pass per level), and one target pass
+    # verifies the b*k nodes (greedy walk, or sampling with the nodes as point-mass proposals).
+    # (b*k + 1) * (query heads per KV head) <= 64 on the target.
+    draft_tree_branches: int = 0
     # Draft passes of <= 4 rows with two linear layers per launch (DecoderModel fused_pairs):
     # same proposals bit for bit, three launches per layer instead of five.  Off by default:
     # measured slower than the five launches on MI355X.
@@ -185,10 +191,20 @@ class SpecEngine:
         dev = target.embed.device
         self.device = dev
         B, k = cfg.max_batch, cfg.k
-        self.tree = cfg.tree_candidates > 1
+        self.draft_tree = int(cfg.draft_tree_branches) if cfg.draft_tree_branches > 1 else 0
+        if self.draft_tree:
+            if draft is None or cfg.k < 1 or cfg.tree_candidates > 1:
+                raise ValueError("draft_tree_branches needs a draft model, k >= 1 and tree_candidates == 1")
+            if self.draft_tree > ops.TOPK_TOKENS_MAX:
+                raise ValueError(f"draft_tree_branches must be at most {ops.TOPK_TOKENS_MAX}")
+            if (draft.cfg.arch != "llama" or draft.cfg.mrope_section or d_sub or draft_tp
+                    or tp_group is not None or draft.cfg.lm_vocab):
+                raise ValueError("a draft-grown tree needs a rotary draft without mrope_section, with a "
+                                 "whole-vocabulary head, on one rank")
+        self.tree = cfg.tree_candidates > 1 or bool(self.draft_tree)
         self.tree_nodes = 0
         if self.tree:
-            if not self.host_props:
+            if not self.host_props and not self.draft_tree:
                 raise ValueError("tree_candidates > 1 needs host-made proposals (prompt lookup or "
                                  "external_proposals) and no draft model")
             if cfg.temperature > 0.0 and cfg.acceptance_method != "rejection_sampler":
@@ -197,7 +213,13 @@ class SpecEngine:
             if target.cfg.arch != "llama" or target.cfg.mrope_section:
                 raise ValueError("token trees need a rotary target without mrope_section")
             cap = min(64 // (target.cfg.n_heads // target.cfg.n_kv_heads) - 1, 63)
-            self.tree_nodes = min(cfg.tree_nodes or cfg.tree_candidates * k, cap)
+            if self.draft_tree:
+                self.tree_nodes = self.draft_tree * k
+                if self.tree_nodes > cap:
+                    raise ValueError(f"{self.draft_tree} branches of depth {k} are {self.tree_nodes} tree "
+                                     f"nodes; this target verifies at most {cap}")
+            else:
+                self.tree_nodes = min(cfg.tree_nodes or cfg.tree_candidates * k, cap)
             if self.tree_nodes < k:
                 raise ValueError(f"a tree of {self.tree_nodes} nodes cannot hold a chain of k={k}")
         q_max = max(k, self.tree_nodes) + 1           # rows of a verify pass per sequence
@@ -223,6 +245,11 @@ class SpecEngine:
                                    fp8_activations=cfg.fp8_activations and bool(getattr(draft, "fp8", False)))
                       if k > 0 and draft is not None else None)
         self.max_rows = self.target.max_rows
+        if self.draft_tree:
+            rows = self.draft_tree * (k - 1)          # the widest level pass, per sequence
+            if rows > self.draft.max_rows or rows * (draft.cfg.n_heads // draft.cfg.n_kv_heads) > 64:
+                raise ValueError(f"the draft's level passes would carry {rows} rows per sequence: more "
+                                 "than its kernels take (draft_rows='wide' lifts the first bound)")
         self._lanes: List[torch.cuda.Stream] = []
         self._lane_ws: List[torch.Tensor] = []
         # (collectives of one communicator must stay on one stream: no lanes for a sharded draft)
@@ -265,7 +292,8 @@ class SpecEngine:
         self._prompt_rows: Optional[torch.Tensor] = None   # [max_batch, max_seq_len], batched prefill
         self.t_logits = torch.empty(max(MAX_ROWS, B * q_max), self.V,
                                     dtype=torch.float32, device=dev)
-        self.d_logits = torch.empty(max(MAX_ROWS, 2 * B), self.V, dtype=torch.float32, device=dev)
+        self.d_logits = torch.empty(max(MAX_ROWS, 2 * B, B * self.draft_tree * (k - 1)), self.V,
+                                    dtype=torch.float32, device=dev)
         self.ids_tmp = torch.zeros(max(B, 1), dtype=torch.int64, device=dev)
         self.target_ids = torch.zeros(B, k + 1, dtype=torch.int64, device=dev)
         self.draft_ids = torch.zeros(B, max(k, 1), dtype=torch.int64, device=dev)
@@ -290,6 +318,28 @@ class SpecEngine:
             self.tree_ids = torch.zeros(B * q, dtype=torch.int64, device=dev)
             self.tree_path = torch.zeros(B, k, **i32)
             self.tree_npath = torch.zeros(B, **i32)
+            if self.draft_tree:
+                # The topology never changes: row 1 + (d-1)*b + c is branch c at depth d, its
+                # parent the same branch one level up (the root for d = 1).  Uploaded once; the
+                # tokens are written on the device by the draft's passes.
+                nb = self.draft_tree
+                h_tok, h_par, h_dep, h_len, h_mask = self._tree_np
+                masks = [1]
+                for r in range(1, q):
+                    par = 0 if r <= nb else r - nb
+                    h_par[:, r], h_dep[:, r] = par, (r - 1) // nb + 1
+                    masks.append(masks[par] | (1 << r))
+                h_len[:] = q
+                h_mask[:] = [m - (1 << 64) if m >= (1 << 63) else m for m in masks]
+                self._tree_dev.copy_(self._tree_host)
+                # The draft's pass of level d covers tree rows 1..d*b: its ancestor masks are the
+                # tree's without the root bit (the root is context there), its rotary positions
+                # the rows' (copied into a buffer of the pass's own row stride in every step).
+                self.dtree_mask, self.dtree_rope = [None], [None]
+                for d in range(1, k):
+                    m = torch.tensor([masks[t + 1] >> 1 for t in range(d * nb)], dtype=torch.int64)
+                    self.dtree_mask.append(m.repeat(B).contiguous().to(dev))
+                    self.dtree_rope.append(torch.zeros(B, d * nb, **i32))
         self.part_val = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.float32, device=dev)
         self.part_idx = torch.empty(n_rows, ops.ARGMAX_PARTS, dtype=torch.int32, device=dev)
         # Vocabulary-parallel target head (tensor parallelism): a pass leaves this rank's
@@ -1011,6 +1061,8 @@ class SpecEngine:
         B, k, q = self.active, self.k, self.tree_nodes + 1
         ops.tree_prepare(self.tok_buf[:B], 1, self.tree_tok[:B], self.tree_depth[:B],
                          self.seq_lens[:B], -1, self.tree_rope)
+        if self.draft_tree:
+            self._enqueue_grow_tree()
         self._forward(self.target, self.t_kv, self.tree_tok, q, 0, self.seq_lens, -1, B, q,
                       self.t_out, tree=(self.tree_mask, self.tree_rope))
         self._apply_bias(B * q, q)
@@ -1031,12 +1083,37 @@ class SpecEngine:
             ops.tree_accept_greedy(self.tree_ids, self.tree_tok[:B], self.tree_parent[:B],
                                    self.tree_len[:B], k, self.out_ids[:B], self.tree_path[:B],
                                    self.tree_npath[:B], self.counters)
-        kv, c = self.t_kv, self.target.cfg
-        ops.kv_compact(kv.k, kv.v, kv.layer_stride_bytes, c.n_layers, kv.block_tables[:B],
-                       self.seq_lens[:B], -1, self.tree_path[:B], self.tree_npath[:B],
-                       c.n_kv_heads, c.head_dim)
+        caches = [(self.t_kv, self.target.cfg)]
+        if self.draft_tree:               # the draft's cache holds the same rows at the same slots
+            caches.append((self.d_kv, self.draft.cfg))
+        for kv, c in caches:
+            ops.kv_compact(kv.k, kv.v, kv.layer_stride_bytes, c.n_layers, kv.block_tables[:B],
+                           self.seq_lens[:B], -1, self.tree_path[:B], self.tree_npath[:B],
+                           c.n_kv_heads, c.head_dim)
         ops.advance_state(self.out_ids[:B], self.seq_lens[:B], self.tok_buf[:B],
                           self.gen_tokens[:B], self.gen_counts[:B], k, self._records[self._parity, :B])
+
+    def _enqueue_grow_tree(self) -> None:
+        """The draft model fills in the tree's tokens (the topology is fixed: draft_tree branches of
+        depth k).  Pass 0 feeds the last two tokens as every proposal pass does; the b most likely
+        next tokens are the nodes of depth 1.  The pass of level d then covers tree rows 1..d*b
+        (cached at slot root + row, rotated at root + depth, each row attending its own branch)
+        and the arg-max after each of its last b rows is that branch's node of depth d + 1.
+        Rows of shallower levels are computed again, with the same bits: a pass over the new
+        rows alone would see the other branches' cache entries as context."""
+        B, k, nb, q = self.active, self.k, self.draft_tree, self.tree_nodes + 1
+        self._forward(self.draft, self.d_kv, self.tok_buf, k + 2, 0, self.seq_lens, -2, B, 2, self.d_out)
+        ops.topk_tokens(self.d_out[:2 * B], nb, self.tree_tok, 1, row_offset=1, row_step=2, B=B)
+        rope = self.tree_rope.view(-1, q)
+        for d in range(1, k):
+            qd = d * nb
+            d_rope = self.dtree_rope[d]
+            d_rope[:B].copy_(rope[:B, 1:1 + qd])
+            self._forward(self.draft, self.d_kv, self.tree_tok, q, 1, self.seq_lens, 0, B, qd,
+                          self.d_out, tree=(self.dtree_mask[d], d_rope.view(-1)))
+            for c in range(nb):
+                ops.topk_tokens(self.d_out[:B * qd], 1, self.tree_tok, 1 + qd + c,
+                                row_offset=qd - nb + c, row_step=qd, B=B)
 
     # -- the target's logits after a pass of n rows (whole, or one vocabulary slice per rank)
     def _target_head_fused(self) -> bool:
@@ -1485,7 +1562,9 @@ class SpecEngine:
         # contexts on the single-split path (no partials, no merge kernel).  The split
         # boundaries stay at fixed absolute positions, so results do not depend on the bound.
         self._ctx = self._ctx_bucket()
-        if self.tree:
+        if self.draft_tree:
+            pass                          # the draft grows the tree inside the step
+        elif self.tree:
             pending, self._pending_props = self._pending_props, None
             cands = []
             for b in range(B):

@@ -377,6 +377,21 @@ def tree_prepare(tok_buf, tok_col, tree_tok, tree_depth, seq_lens, pos_offset, r
                                            q_len, _stream()), "sd_tree_prepare")
 
 
+TOPK_TOKENS_MAX = 8
+
+
+def topk_tokens(logits, b: int, out_tok, out_col: int, *, row_offset: int = 0, row_step: int = 1,
+                B: Optional[int] = None) -> None:
+    """out_tok[s, out_col + c] = the c-th largest entry of logits row row_offset + s*row_step as a
+    token (largest first; ties: lowest index), c < b <= TOPK_TOKENS_MAX."""
+    _need(logits, torch.float32, "logits")
+    _need(out_tok, torch.int32, "out_tok")
+    n = out_tok.shape[0] if B is None else B
+    _lib.check(_lib.load().sd_topk_tokens(_p(logits), logits.stride(0), logits.shape[1], row_offset,
+                                          row_step, b, _p(out_tok), out_tok.stride(0), out_col, n,
+                                          _stream()), "sd_topk_tokens")
+
+
 def tree_accept_greedy(target_ids, tree_tok, tree_parent, tree_len, k, out_ids, path, n_path,
                        counters=None) -> None:
     """Greedy acceptance walk over a token tree (see sd_tree_accept_greedy)."""

@@ -496,6 +496,8 @@ class SpecDecodeConfig:
     # EngineConfig.tree_candidates
     speculative_tree_candidates: int = 1
     speculative_tree_nodes: int = 0
+    # > 1: the draft model proposes a tree of this many branches (EngineConfig.draft_tree_branches)
+    speculative_draft_tree_branches: int = 0
     max_num_seqs: int = 1
     max_model_len: int = 2048
     temperature: float = 0.0
@@ -692,6 +694,7 @@ class SpecDecodeWorker:
             ngram_max=c.ngram_prompt_lookup_max, ngram_min=c.ngram_prompt_lookup_min,
             external_proposals=c.external_proposals,
             tree_candidates=c.speculative_tree_candidates, tree_nodes=c.speculative_tree_nodes,
+            draft_tree_branches=c.speculative_draft_tree_branches,
             disable_by_batch_size=c.speculative_disable_by_batch_size,
             spec_policy=c.speculative_policy, fp8_activations=c.fp8_activations,
             acceptance_method=c.spec_decoding_acceptance_method,
