@@ -34,13 +34,24 @@ STAMP_LIB := $(STAMP_DIR)/libsd_amd_stamps.so
 STAMP_OBJS := $(patsubst $(CSRC)/%.hip,$(STAMP_DIR)/%.o,$(SRCS))
 $(STAMP_DIR)/%.o: $(CSRC)/%.hip $(CSRC)/sd_common.h include/sd_amd.h
 	@mkdir -p $(STAMP_DIR)
-	$(HIPCC) $(FLAGS) -DSD_ATTN_STAMPS -DSD_LIN_STAMPS -DSD_CHAIN_STAMPS -DSD_DRAFT_STAMPS -c $< -o $@
+	$(HIPCC) $(FLAGS) -DSD_ATTN_STAMPS -DSD_LIN_STAMPS -DSD_CHAIN_STAMPS -DSD_DRAFT_STAMPS -DSD_WIDE_STAMPS -c $< -o $@
 $(STAMP_LIB): $(STAMP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(STAMP_OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 stamps: $(STAMP_LIB)
 
+# The library with a run-time switch between the two many-row linear kernels
+# (experiments/bench_wide_shapes.py, experiments/bench_batch.py WIDE_FOUR=0): same sources,
+# sd_linear_wide.hip compiled with -DSD_WIDE_SWITCH.
+SWITCH_LIB := build/exp/libsd_amd_switch.so
+$(SWITCH_LIB): $(OBJS)
+	@mkdir -p build/exp
+	$(HIPCC) $(FLAGS) -DSD_WIDE_SWITCH -c $(CSRC)/sd_linear_wide.hip -o build/exp/sd_linear_wide_switch.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(filter-out $(CSRC)/sd_linear_wide.o,$(OBJS)) \
+		build/exp/sd_linear_wide_switch.o -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+wide-switch: $(SWITCH_LIB)
+
 clean:
 	rm -f $(OBJS) $(LIB) $(CPU_LIB)
-	rm -rf $(STAMP_DIR)
+	rm -rf $(STAMP_DIR) build/exp/*.o build/exp/*.so
 
-.PHONY: all clean stamps
+.PHONY: all clean stamps wide-switch

@@ -5,7 +5,8 @@ autoregressive baseline on the same kernels.
 Environment: K = proposals per step (default 5); IMAGE = placeholder tokens of one synthetic image
 at the start of every prompt (a target with rotary sections, e.g. qwen2-vl-7b: image rows are
 random, positions come from multimodal.prepare_prompt); RAGGED=1: prompt lengths uniform in
-64..prompt_len (seed 7) instead of all equal.
+64..prompt_len (seed 7) instead of all equal; WIDE_FOUR=0|1 with a library built with
+-DSD_WIDE_SWITCH (SD_AMD_LIB): the many-row linear kernel never / wherever built on four waves.
 """
 import os
 import sys
@@ -17,6 +18,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vllm_omni_draft_amd import config, weights  # noqa: E402
 from vllm_omni_draft_amd.engine import EngineConfig, SpecEngine  # noqa: E402
 
+if os.environ.get("WIDE_FOUR"):
+    from vllm_omni_draft_amd import _lib  # noqa: E402
+    _lib.load().sd_debug_wide_four_waves(int(os.environ["WIDE_FOUR"]))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 DRAFT_ROWS = sys.argv[3] if len(sys.argv) > 3 else "auto"

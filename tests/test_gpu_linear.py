@@ -544,6 +544,80 @@ def test_wide_linear_f32_accuracy_and_row_independence():
         assert torch.equal(part, full[m0:m0 + M]), (M, m0)
 
 
+@pytest.mark.parametrize("K", [512, 1792, 640])
+def test_many_row_passes_on_four_waves_keep_every_bit(K):
+    """Matrices of 1024..2047 weight tiles run their passes of 65..256 rows on the four-wave
+    kernel (loads spread through the MFMA stream) when K is a multiple of 256 (K = 640: the
+    fallback to the eight-wave kernel).  Its rows equal, bit for bit, the same rows computed in
+    passes of at most 64 rows, which the eight-wave kernel serves: every epilogue it has, bf16
+    and fp8 weights, row counts that are no multiple of 16, a last tile that is partly outside
+    N; and the reference within the tolerance of the other wide tests."""
+    ops = _ops()
+    gen = torch.Generator(device="cuda").manual_seed(K)
+    N, Ng = 16424, 8204                 # 1027 plain tiles; 1026 gated tiles (the last one half used)
+    W = (torch.randn(N, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    W2 = (torch.randn(2 * Ng, K, generator=gen, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    bias_all = (torch.randn(N, generator=gen, device="cuda") * 0.1).to(torch.bfloat16)
+    bias = bias_all[:2 * Ng].contiguous()
+    x_all = torch.randn(256, K, generator=gen, device="cuda").to(torch.bfloat16)
+    res_all = torch.randn(256, N, generator=gen, device="cuda").to(torch.bfloat16)
+    q, sc = ops.quantize_fp8(W)
+    q2, sc2 = ops.quantize_fp8(W2)
+    forms = [(ops.tile_weights(W), ops.tile_weights(W2, ops.TILE_GATED), True),
+             (ops.tile_weights(q, ops.TILE_PLAIN, scale=sc), ops.tile_weights(q2, ops.TILE_GATED, scale=sc2), False)]
+    for M in (65, 100, 192, 250, 256):
+        x, res = x_all[:M].contiguous(), res_all[:M].contiguous()
+        for Wt, Wg, check_ref in forms:
+            for epi in (ops.EPI_STORE, ops.EPI_RESIDUAL, ops.EPI_F32):
+                b = bias_all if epi != ops.EPI_F32 else None
+                r = res if epi == ops.EPI_RESIDUAL else None
+                got = ops.linear_wide(Wt, x, b, r, epi)
+                few = torch.cat([ops.linear_wide(Wt, x[i:i + 64].contiguous(), b,
+                                                 None if r is None else r[i:i + 64].contiguous(), epi)
+                                 for i in range(0, M, 64)])
+                assert torch.equal(got, few), (M, epi)
+                if check_ref and M in (65, 256):
+                    torch.testing.assert_close(got.float(), _ref_linear(W, x, b, res, epi, ops), rtol=2e-2, atol=2e-2)
+            got = ops.linear_wide(Wg, x, bias, None, ops.EPI_SILU_MUL)
+            few = torch.cat([ops.linear_wide(Wg, x[i:i + 64].contiguous(), bias, None, ops.EPI_SILU_MUL)
+                             for i in range(0, M, 64)])
+            assert torch.equal(got, few), M
+            if check_ref and M in (65, 256):
+                torch.testing.assert_close(got.float(), _ref_linear(W2, x, bias, None, ops.EPI_SILU_MUL, ops),
+                                           rtol=3e-2, atol=3e-2)
+
+
+def test_many_row_qkv_rope_on_four_waves_keeps_every_bit():
+    """The fused QKV + rotary + cache-append epilogue on the four-wave kernel (a projection of
+    1024 tiles, 96 rows): queries and both caches equal the same tokens run as two passes of 48
+    rows, which the eight-wave kernel serves."""
+    ops = _ops()
+    from vllm_omni_draft_amd.config import create_model_config, rope_table
+    Hq, Hkv, D, H = 96, 16, 128, 512
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    B, q_len = 16, 6
+    cfg = create_model_config(None, head_dim=D, n_heads=Hq, n_kv_heads=Hkv, max_pos=128)
+    cs = rope_table(cfg).cuda()
+    x = torch.randn(B * q_len, H, generator=gen, device="cuda").to(torch.bfloat16)
+    W = (torch.randn((Hq + 2 * Hkv) * D, H, generator=gen, device="cuda") * H ** -0.5).to(torch.bfloat16)
+    Wt = ops.tile_weights(W, ops.TILE_ROTARY, D)
+    bias = (0.1 * torch.randn((Hq + 2 * Hkv) * D, generator=gen, device="cuda")).to(torch.bfloat16)
+    bt = torch.randperm(B * 3, generator=gen, device="cuda").to(torch.int32).view(B, 3).contiguous()
+    seq_lens = torch.randint(1, 30, (B,), generator=gen, device="cuda").to(torch.int32)
+    outs = []
+    for parts in (1, 2):
+        kc = torch.zeros(B * 3, Hkv, D * 16, dtype=torch.bfloat16, device="cuda")
+        vc = torch.zeros_like(kc)
+        nb = B // parts
+        q = torch.cat([ops.qkv_rope_wide(Wt, x[b0 * q_len:(b0 + nb) * q_len].contiguous(), bias, cs, kc, vc,
+                                         bt[b0:b0 + nb].contiguous(), seq_lens[b0:b0 + nb].contiguous(), -1, nb,
+                                         q_len, Hq, Hkv, D) for b0 in range(0, B, nb)])
+        outs.append((q, kc, vc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert outs[0][1].abs().sum() > 0 and outs[0][2].abs().sum() > 0
+
+
 @pytest.mark.parametrize("Hq,Hkv,D,H,rope", [(32, 8, 128, 4096, True), (12, 12, 64, 768, False),
                                               (14, 2, 64, 896, True)])
 def test_wide_qkv_rope_append_matches_narrow_ops(Hq, Hkv, D, H, rope):

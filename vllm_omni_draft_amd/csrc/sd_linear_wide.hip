@@ -17,6 +17,7 @@
 // applies the epilogue, so a row's arithmetic depends on (N, K) only: never on how many rows
 // share the pass.
 #include <mutex>
+#include <type_traits>
 
 #include "sd_common.h"
 
@@ -33,7 +34,11 @@ constexpr int kPairTiles = 2048;
 constexpr int kChunkSteps = 4;                              // k-steps (32 columns) per LDS chunk
 constexpr int kChunkCols = kChunkSteps * 32;
 constexpr int kXLD = kChunkCols + 8;                        // padded LDS row (elements)
-constexpr int kBRing = 4;                                   // B fragments in flight per wave
+#ifndef SD_WIDE_BRING
+#define SD_WIDE_BRING 4
+#endif
+constexpr int kBRing = SD_WIDE_BRING;                       // B fragments in flight per wave
+constexpr int kFourWaveMT = 8;                              // token tiles from which 8-tile groups run on 4 waves
 constexpr int EPI_QKV_ROPE = 100;
 
 __device__ __forceinline__ float silu_w(float v) { return v / (1.0f + __expf(-v)); }
@@ -79,18 +84,32 @@ struct WideArgs {
 
 constexpr int EPI_PARTIAL = -1;  // several K splits: partial sums to the workspace
 
+#ifdef SD_WIDE_STAMPS
+// Debug build only: ticks (10 ns) wave 0 of workgroup 0 spent per phase, summed over the chunks:
+// [0] waiting for the chunk's weights, [1] LDS reads + MFMAs, [2] waiting for the next chunk's x,
+// [3] storing it, [4] the barrier, [5] issuing the next chunk's loads, [6] whole loop, [7] the
+// loop in core clock cycles.
+__device__ unsigned long long sd_wide_stamps[8][8];  // [wave][phase]
+#define SD_WSTAMP(var) \
+  __builtin_amdgcn_sched_barrier(0); \
+  const unsigned long long var = wall_clock64(); \
+  __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // W8: fp8 (e4m3) weight tiles, two k-steps per 16-byte lane load, converted to bf16 when a
 // chunk's fragments are taken out of the prefetch registers; the row scales are applied by the
 // epilogue.
 template <int MT, int EPI, int TPW, bool W8>  // MT token tiles of 16 rows; TPW tiles per wave
 __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
+  constexpr int kThreads = kWideThreads;
+  constexpr int WAVES = kWideWaves;
   constexpr int kTilesPerWave = TPW;
   constexpr int kALoads = W8 ? kChunkSteps / 2 : kChunkSteps;  // 16-byte loads per tile and chunk
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   bf16_t* xs = reinterpret_cast<bf16_t*>(smem_raw);  // [2][MT*16][kXLD]
   constexpr int kRows = MT * 16;
-  constexpr int kPieces = kRows * (kChunkCols / 8) / kWideThreads;  // 16-byte pieces per thread
-  static_assert(kRows * (kChunkCols / 8) % kWideThreads == 0, "MT must be even");
+  constexpr int kPieces = kRows * (kChunkCols / 8) / kThreads;  // 16-byte pieces per thread
+  static_assert(kRows * (kChunkCols / 8) % kThreads == 0, "MT must be even");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,9 +120,9 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
   const int n_chunks = (ks_hi - ks_lo + kChunkSteps - 1) / kChunkSteps;
   // tile t of this wave: group base + wave + 8 t, if inside the group and the matrix
   const int tile0 = blockIdx.x * a.group_tiles + wave;
-  auto tile_of = [&](int t) { return tile0 + t * kWideWaves; };
+  auto tile_of = [&](int t) { return tile0 + t * WAVES; };
   auto tile_ok = [&](int t) {
-    return wave + t * kWideWaves < a.group_tiles && tile_of(t) < a.n_tiles;
+    return wave + t * WAVES < a.group_tiles && tile_of(t) < a.n_tiles;
   };
 
   // Every load below is unconditional on a clamped address: a load inside a branch makes the
@@ -116,7 +135,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
     const int col0 = (ks_lo + chunk * kChunkSteps) * 32;
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
-      const int p = tid + i * kWideThreads;
+      const int p = tid + i * kThreads;
       const int row = min(p / (kChunkCols / 8), a.M - 1);
       const int col = col0 + (p % (kChunkCols / 8)) * 8;
       x_stage[i] = *reinterpret_cast<const bf16x8*>(a.x + (size_t)row * a.ldx + min(col, a.K - 8));
@@ -126,7 +145,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
     const int col0 = (ks_lo + chunk * kChunkSteps) * 32;
 #pragma unroll
     for (int i = 0; i < kPieces; ++i) {
-      const int p = tid + i * kWideThreads;
+      const int p = tid + i * kThreads;
       const int row = p / (kChunkCols / 8), c8 = p % (kChunkCols / 8);
       const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
       *reinterpret_cast<bf16x8*>(xs + ((size_t)buf * kRows + row) * kXLD + c8 * 8) =
@@ -159,7 +178,18 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
   store_x(0, 0);
   __syncthreads();
   const int xc = lane & 15, xq = lane >> 4;
+#ifdef SD_WIDE_STAMPS
+  unsigned long long w_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long w_begin = wall_clock64();
+  const unsigned long long w_cyc0 = clock64();
+#endif
   for (int c = 0; c < n_chunks; ++c) {
+#ifdef SD_WIDE_STAMPS
+    SD_WSTAMP(w0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SD_WSTAMP(w1);
+    w_acc[0] += w1 - w0;
+#endif
     bf16x8 a_cur[kTilesPerWave][kChunkSteps];
 #pragma unroll
     for (int t = 0; t < kTilesPerWave; ++t)
@@ -179,6 +209,10 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       load_a(c + 1);
     }
+#ifdef SD_WIDE_STAMPS
+    SD_WSTAMP(w1b);
+    w_acc[5] += w1b - w1;
+#endif
     const bf16_t* xb = xs + (size_t)(c & 1) * kRows * kXLD + (size_t)xc * kXLD + 8 * xq;
     // The chunk's B fragments, (k-step j, token tile mt) in order, through a ring of kBRing
     // registers: a fragment is requested kBRing MFMA pairs before its use, so the LDS latency
@@ -210,9 +244,30 @@ __global__ __launch_bounds__(kWideThreads) void wide_gemm_kernel(WideArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < kBRing; ++i) __builtin_amdgcn_sched_group_barrier(0x008, kTilesPerWave, 0);
+#ifdef SD_WIDE_STAMPS
+    SD_WSTAMP(w2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kTilesPerWave * kALoads) : "memory");
+    SD_WSTAMP(w3);
+    if (c + 1 < n_chunks) store_x((c + 1) & 1, c + 1);
+    SD_WSTAMP(w4);
+    __syncthreads();
+    SD_WSTAMP(w5);
+    w_acc[1] += w2 - w1b;
+    w_acc[2] += w3 - w2;
+    w_acc[3] += w4 - w3;
+    w_acc[4] += w5 - w4;
+#else
     if (c + 1 < n_chunks) store_x((c + 1) & 1, c + 1);
     __syncthreads();
+#endif
   }
+#ifdef SD_WIDE_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+    for (int i = 0; i < 6; ++i) sd_wide_stamps[wave][i] = w_acc[i];
+    sd_wide_stamps[wave][6] = wall_clock64() - w_begin;
+    sd_wide_stamps[wave][7] = clock64() - w_cyc0;  // core clock cycles of the loop
+  }
+#endif
 
   // acc[t][mt][reg] = sum of (tile row 4*(lane>>4)+reg of tile tile0+t, token 16*mt + lane&15)
   if (EPI == EPI_PARTIAL) {
@@ -311,6 +366,31 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
     }
   } else if (EPI == SD_EPI_SILU_MUL) {
     const int n0 = tile * 8 + r0;
+    if (n0 + 3 < a.N && ((a.ldo | a.N) & 3) == 0) {  // four outputs in one store
+      f32x4 g = lo, up = hi;
+      if (a.w_scale) {
+        const f32x4 sg = *reinterpret_cast<const f32x4*>(a.w_scale + n0);
+        const f32x4 su = *reinterpret_cast<const f32x4*>(a.w_scale + a.N + n0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g[j] *= sg[j];
+          up[j] *= su[j];
+        }
+      }
+      if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          g[j] += (float)a.bias[n0 + j];
+          up[j] += (float)a.bias[a.N + n0 + j];
+        }
+      }
+      bf16x4 r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        r[j] = (bf16_t)(round_bf16(silu_w(round_bf16(g[j]))) * round_bf16(up[j]));
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + (size_t)m * a.ldo + n0) = r;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + j;
@@ -378,6 +458,235 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ many rows: four waves
+// Passes of 65..256 rows over matrices whose 8-tile groups cover all of K (K % 256 == 0).  In
+// the eight-wave kernel above a chunk's loads are issued in one burst ahead of its MFMAs: 80 KiB
+// per chunk and CU (48 KiB of activations that every workgroup re-reads from L2, 32 KiB of
+// weights) go through the CU's one 64 B/clk vector memory path, the burst holds the issuing
+// waves for about as long as the chunk's MFMAs take (in-kernel clocks: 0.5 us of 2.1 per chunk
+// at 192 rows), and the LDS stores of the next chunk follow as a third phase (0.4 us).  Here a
+// group runs on FOUR waves, one per SIMD, with two tiles per wave (a B fragment read from LDS
+// feeds two MFMAs: half the LDS reads per CU), and everything else a chunk needs is spread
+// through its MFMA stream at fixed places:
+//   * weights are prefetched two chunks ahead into the registers they are consumed from: the
+//     fragments of k-step j of chunk c + 2 are requested right after the MFMAs of k-step j of
+//     chunk c (two register sets, the chunk loop unrolled by two: no copies);
+//   * activations are loaded two chunks ahead and stored one chunk ahead: piece i of chunk c + 1
+//     (in registers since chunk c - 1) is stored to the idle LDS buffer and piece i of chunk
+//     c + 2 requested into the same registers, one piece every four B fragments;
+//   * loads past the last chunk re-read the last chunk (the same lines, just fetched);
+//   * the chunk loop is unrolled by two, so a split must hold an even number of chunks.
+// The sums of a tile run over the same chunks in the same order as in the kernel above: same
+// bits (experiments/bench_wide_shapes.py compares them).  Measured (192 rows, Llama-3-8B gate/up):
+// 1.6 us per chunk against 2.1-2.7; what is left over the 0.95 us of its 96 MFMAs is the issue
+// time of its 20 vector memory instructions, which a single wave per SIMD cannot hide.  Tried on
+// the same structure and dropped: eight waves (slower: twice the LDS reads), four tiles per wave
+// for 16-tile groups (every register; 5-10 % slower than the eight-wave kernel), the output
+// staged in LDS and written in whole lines (no gain: the gated epilogue's time is its
+// arithmetic), B rings of 8 and 12 fragments (no change).
+template <int MT, int EPI, int TPW, bool W8, int WAVES>
+__global__ __launch_bounds__(WAVES * SD_WAVE) void wide_gemm4_kernel(WideArgs a) {
+  constexpr int kW = WAVES;
+  constexpr int kXP = MT * 16 * 16 / (WAVES * SD_WAVE);        // 16-byte x pieces per thread and chunk
+  constexpr int kXRows = WAVES * SD_WAVE / 16;                 // token rows one piece index covers
+  static_assert(MT * 256 % (WAVES * SD_WAVE) == 0 && kChunkSteps * MT % kXP == 0, "MT must be even");
+#ifdef SD_WIDE_STAMPS
+  const unsigned long long w_kernel = wall_clock64();
+#endif
+  constexpr int kALoads = W8 ? kChunkSteps / 2 : kChunkSteps;  // 16-byte loads per tile and chunk
+  constexpr int kRows = MT * 16;
+  constexpr int kReads = kChunkSteps * MT;                     // B fragments per chunk
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int KS = a.K / 32;
+  const int NR = a.n_tiles * 16;
+  const int ks_lo = blockIdx.y * a.ks_per_split;
+  const int ks_hi = min(ks_lo + a.ks_per_split, KS);
+  const int n_chunks = (ks_hi - ks_lo) / kChunkSteps;          // whole chunks: K % 128 == 0
+  const int tile0 = blockIdx.x * a.group_tiles + wave;
+  auto tile_of = [&](int t) { return tile0 + t * kW; };
+  auto tile_ok = [&](int t) { return wave + t * kW < a.group_tiles && tile_of(t) < a.n_tiles; };
+
+  // x: piece i of a thread is the 16 bytes at token row kXRows i + (tid >> 4), columns
+  // 8 (tid & 15).. of the chunk; rows >= M re-read row M - 1 (their sums are never stored)
+  const int xr = tid >> 4, xc8 = tid & 15;
+  uint32_t x_off[kXP];
+#pragma unroll
+  for (int i = 0; i < kXP; ++i)
+    x_off[i] = (uint32_t)(((size_t)min(kXRows * i + xr, a.M - 1) * a.ldx + xc8 * 8) * sizeof(bf16_t));
+  const char* x_base = reinterpret_cast<const char*>(a.x) + (size_t)ks_lo * 32 * sizeof(bf16_t);
+  bf16x8 x_stage[kXP];
+  auto load_x = [&](int i, int chunk) {
+    const char* base = x_base + (size_t)min(chunk, n_chunks - 1) * (kChunkCols * sizeof(bf16_t));
+    x_stage[i] = *reinterpret_cast<const bf16x8*>(base + x_off[i]);
+  };
+  const uint32_t xs_store = (uint32_t)((xr * kXLD + xc8 * 8) * sizeof(bf16_t));
+  auto store_x = [&](int i, int buf) {
+    *reinterpret_cast<bf16x8*>(smem_raw + xs_store +
+                               (size_t)(buf * kRows + kXRows * i) * kXLD * sizeof(bf16_t)) = x_stage[i];
+  };
+
+  // weights: fragment (t, j) of a chunk is one 16-byte lane load at a wave-uniform base
+  const uint32_t w_off = lane * 16;
+  const char* w_base[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = __builtin_amdgcn_readfirstlane(min(tile_of(t), a.n_tiles - 1));
+    w_base[t] = reinterpret_cast<const char*>(a.W) +
+                ((size_t)tile * (W8 ? KS / 2 : KS) + (W8 ? ks_lo / 2 : ks_lo)) * 1024;
+  }
+  bf16x8 a_set[2][TPW][kALoads];
+  auto load_w = [&](int set, int t, int j, int chunk) {
+    const char* base = w_base[t] + ((size_t)min(chunk, n_chunks - 1) * kALoads + j) * 1024;
+    a_set[set][t][j] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(base + w_off));
+  };
+
+  f32x4 acc[TPW][MT];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int i = 0; i < kXP; ++i) load_x(i, 0);
+#pragma unroll
+  for (int set = 0; set < 2; ++set)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+      for (int j = 0; j < kALoads; ++j) load_w(set, t, j, set);
+#pragma unroll
+  for (int i = 0; i < kXP; ++i) store_x(i, 0);
+#pragma unroll
+  for (int i = 0; i < kXP; ++i) load_x(i, 1);
+  __syncthreads();
+
+  const int xc = lane & 15, xq = lane >> 4;
+  const uint32_t xs_read = (uint32_t)((xc * kXLD + 8 * xq) * sizeof(bf16_t));
+#ifdef SD_WIDE_STAMPS
+  unsigned long long w_acc[6] = {0, 0, 0, 0, 0, 0};
+  const unsigned long long w_begin = wall_clock64();
+  const unsigned long long w_cyc0 = clock64();
+  unsigned long long w_last = w_begin;
+#endif
+  // One chunk: reads LDS buffer P and register set P; stores chunk c + 1 to buffer P ^ 1.
+  auto chunk_body = [&](int c, auto parity) {
+    constexpr int P = decltype(parity)::value;
+    const char* xb = smem_raw + xs_read + (size_t)P * kRows * kXLD * sizeof(bf16_t);
+    auto read_b = [&](int idx) {
+      return *reinterpret_cast<const bf16x8*>(xb + ((size_t)(idx % MT) * 16 * kXLD + (idx / MT) * 32) *
+                                                        sizeof(bf16_t));
+    };
+    bf16x8 ring[kBRing];
+#pragma unroll
+    for (int i = 0; i < kBRing; ++i) ring[i] = read_b(i);
+    bf16x8 a_k[TPW];
+#pragma unroll
+    for (int idx = 0; idx < kReads; ++idx) {
+      const int j = idx / MT, mt = idx % MT;
+      if (mt == 0) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          if constexpr (W8) {
+            const u32x4 raw = __builtin_bit_cast(u32x4, a_set[P][t][j >> 1]);
+            a_k[t] = fp8x8_to_bf16(raw[2 * (j & 1)], raw[2 * (j & 1) + 1]);
+          } else {
+            a_k[t] = a_set[P][t][j];
+          }
+        }
+      }
+      const bf16x8 b = ring[idx % kBRing];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+        acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_k[t], b, acc[t][mt], 0, 0, 0);
+      if (idx + kBRing < kReads) ring[idx % kBRing] = read_b(idx + kBRing);
+      if (idx % (kReads / kXP) == 1) {  // one piece every kReads / kXP fragments
+        store_x(idx / (kReads / kXP), P ^ 1);
+        load_x(idx / (kReads / kXP), c + 2);
+      }
+      if (mt == MT - 1 && (!W8 || (j & 1))) {  // the registers of this k-step's fragments are free
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) load_w(P, t, W8 ? j >> 1 : j, c + 2);
+      }
+    }
+    // the same order for the instruction scheduler
+#pragma unroll
+    for (int i = 0; i < kBRing; ++i) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int idx = 0; idx < kReads; ++idx) {
+      __builtin_amdgcn_sched_group_barrier(0x008, TPW, 0);
+      if (idx + kBRing < kReads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      if (idx % (kReads / kXP) == 1) {
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      if (idx % MT == MT - 1 && (!W8 || ((idx / MT) & 1))) __builtin_amdgcn_sched_group_barrier(0x020, TPW, 0);
+    }
+#ifdef SD_WIDE_STAMPS
+    SD_WSTAMP(w1);
+    __syncthreads();
+    SD_WSTAMP(w2);
+    w_acc[1] += w1 - w_last;
+    w_acc[4] += w2 - w1;
+    w_last = w2;
+#else
+    __syncthreads();
+#endif
+  };
+  for (int c = 0; c < n_chunks; c += 2) {  // an even number of chunks (the host checks)
+    chunk_body(c, std::integral_constant<int, 0>{});
+    chunk_body(c + 1, std::integral_constant<int, 1>{});
+  }
+#ifdef SD_WIDE_STAMPS
+  const unsigned long long w_loop_end = wall_clock64();
+  const unsigned long long w_cyc1 = clock64();
+#endif
+
+  // acc[t][mt][reg] = sum of (tile row 4*(lane>>4)+reg of tile tile0+4t, token 16*mt + lane&15)
+  if (EPI == EPI_PARTIAL) {
+    float* part = a.part + (size_t)blockIdx.y * a.M * NR;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if (!tile_ok(t)) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + xc;
+        if (m < a.M)
+          *reinterpret_cast<f32x4*>(part + (size_t)m * NR + (size_t)tile_of(t) * 16 + 4 * xq) = acc[t][mt];
+      }
+    }
+  } else {
+    constexpr bool PAIRED = EPI == SD_EPI_SILU_MUL || EPI == EPI_QKV_ROPE;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const bool t_ok = tile_ok(t);  // wave-uniform
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + xc;
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f};
+        if (PAIRED) {  // rows r+8 sit 32 lanes up
+#pragma unroll
+          for (int j = 0; j < 4; ++j) hi[j] = __shfl(acc[t][mt][j], (lane + 32) & 63, 64);
+        }
+        if (t_ok && m < a.M && (!PAIRED || xq < 2))
+          emit_unit<EPI == EPI_PARTIAL ? 0 : EPI>(a.epi, m, tile_of(t), 4 * xq, acc[t][mt], hi);
+      }
+    }
+  }
+#ifdef SD_WIDE_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {
+    for (int i = 0; i < 6; ++i) sd_wide_stamps[wave][i] = w_acc[i];
+    sd_wide_stamps[wave][0] = (w_begin - w_kernel) * (unsigned long long)n_chunks;      // prologue (per launch)
+    sd_wide_stamps[wave][2] = (wall_clock64() - w_loop_end) * (unsigned long long)n_chunks;  // epilogue
+    sd_wide_stamps[wave][6] = w_loop_end - w_begin;
+    sd_wide_stamps[wave][7] = w_cyc1 - w_cyc0;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ fp8 activations (W8A8)
@@ -688,15 +997,70 @@ int launch_gemm_a8(const WideArgs& a, int S, hipStream_t st) {
 
 template <int MT, int EPI, int TPW>
 int launch_gemm_t(const WideArgs& a, int S, hipStream_t st) {
-  if (a.x_inv) return launch_gemm_a8<MT, EPI, TPW>(a, S, st);
+#ifdef SD_WIDE_EXP  // experiments: a quick build of the few instantiations under study
+  return launch_gemm_w<MT, EPI, TPW, false>(a, S, st);
+#else
   return a.epi.w_scale ? launch_gemm_w<MT, EPI, TPW, true>(a, S, st)
                        : launch_gemm_w<MT, EPI, TPW, false>(a, S, st);
+#endif
 }
+
+template <int MT, int EPI, int TPW, bool W8, int WAVES>
+int launch_gemm4_w(const WideArgs& a, int S, hipStream_t st) {
+  const size_t lds = (size_t)2 * MT * 16 * kXLD * sizeof(bf16_t);
+  static std::once_flag attr_once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(attr_once, [] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(wide_gemm4_kernel<MT, EPI, TPW, W8, WAVES>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  if (attr_err != hipSuccess) {
+    sd_set_error("sd_linear_wide: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+    return SD_ERR_HIP;
+  }
+  const int groups = (a.n_tiles + a.group_tiles - 1) / a.group_tiles;
+  hipLaunchKernelGGL((wide_gemm4_kernel<MT, EPI, TPW, W8, WAVES>), dim3(groups, S), dim3(WAVES * SD_WAVE),
+                     lds, st, a);
+  SD_CHECK_LAUNCH("sd_linear_wide");
+  return SD_OK;
+}
+
+template <int MT, int EPI, int TPW, int WAVES>
+int launch_gemm4(const WideArgs& a, int S, hipStream_t st) {
+#ifdef SD_WIDE_EXP
+  return launch_gemm4_w<MT, EPI, TPW, false, WAVES>(a, S, st);
+#else
+  return a.epi.w_scale ? launch_gemm4_w<MT, EPI, TPW, true, WAVES>(a, S, st)
+                       : launch_gemm4_w<MT, EPI, TPW, false, WAVES>(a, S, st);
+#endif
+}
+
+#if defined(SD_WIDE_STAMPS) || defined(SD_WIDE_SWITCH)
+#define SD_WIDE_HAS_SWITCH 1
+int g_wide_four_waves = -1;  // experiments: -1 the library's choice, 0 never the four-wave kernel
+#endif
 
 template <int MT, int EPI>
 int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
-  return a.group_tiles == kWideWaves ? launch_gemm_t<MT, EPI, 1>(a, S, st)
-                                     : launch_gemm_t<MT, EPI, 2>(a, S, st);
+  const bool pair = a.group_tiles != kWideWaves;  // 16-tile groups
+#ifndef SD_WIDE_EXP
+  if (a.x_inv) return pair ? launch_gemm_a8<MT, EPI, 2>(a, S, st) : launch_gemm_a8<MT, EPI, 1>(a, S, st);
+#endif
+  // The four-wave kernel where it was measured faster (same bits either way): many rows,
+  // 8-tile groups that cover the whole of K with the epilogue inside (the matrices of
+  // 1024..2047 tiles: a gated projection of 8192..16383 outputs, say), an even number of whole
+  // chunks.  Split-K groups run a handful of chunks each and gain nothing; 16-tile groups
+  // would need four tiles per wave and every register there is.
+  constexpr bool kHasFour = MT >= kFourWaveMT && EPI != EPI_PARTIAL && EPI != SD_EPI_RELU &&
+                            EPI != SD_EPI_GELU_TANH;
+  if constexpr (kHasFour) {
+    bool four = !pair && S == 1 && a.K % (2 * kChunkCols) == 0;
+#ifdef SD_WIDE_HAS_SWITCH
+    if (g_wide_four_waves >= 0) four = four && g_wide_four_waves != 0;
+#endif
+    if (four) return launch_gemm4<MT, EPI, 2, 4>(a, S, st);
+  }
+  return pair ? launch_gemm_t<MT, EPI, 2>(a, S, st) : launch_gemm_t<MT, EPI, 1>(a, S, st);
 }
 
 template <int EPI>
@@ -730,10 +1094,12 @@ int gemm_by_kind(const WideArgs& a, int epi, int S, hipStream_t st) {
     case SD_EPI_STORE: return launch_gemm<MT, SD_EPI_STORE>(a, S, st);
     case SD_EPI_RESIDUAL: return launch_gemm<MT, SD_EPI_RESIDUAL>(a, S, st);
     case SD_EPI_SILU_MUL: return launch_gemm<MT, SD_EPI_SILU_MUL>(a, S, st);
+#ifndef SD_WIDE_EXP
     case SD_EPI_RELU: return launch_gemm<MT, SD_EPI_RELU>(a, S, st);
     case SD_EPI_F32: return launch_gemm<MT, SD_EPI_F32>(a, S, st);
     case SD_EPI_GELU_TANH: return launch_gemm<MT, SD_EPI_GELU_TANH>(a, S, st);
     case EPI_QKV_ROPE: return launch_gemm<MT, EPI_QKV_ROPE>(a, S, st);
+#endif
   }
   sd_set_error("sd_linear_wide: unknown epilogue %d", epi);
   return SD_ERR_INVALID;
@@ -741,11 +1107,15 @@ int gemm_by_kind(const WideArgs& a, int epi, int S, hipStream_t st) {
 
 template <bool DIRECT>
 int gemm_by_rows(const WideArgs& a, int mt, int epi, int S, hipStream_t st) {
+#ifdef SD_WIDE_EXP
+  return gemm_by_kind<12, DIRECT>(a, epi, S, st);
+#else
   if (mt <= 2) return gemm_by_kind<2, DIRECT>(a, epi, S, st);
   if (mt <= 4) return gemm_by_kind<4, DIRECT>(a, epi, S, st);
   if (mt <= 8) return gemm_by_kind<8, DIRECT>(a, epi, S, st);
   if (mt <= 12) return gemm_by_kind<12, DIRECT>(a, epi, S, st);
   return gemm_by_kind<16, DIRECT>(a, epi, S, st);
+#endif
 }
 
 int wide_common(const void* W, const void* x, int64_t ldx, int M, int K, int n_tiles, int epi,
@@ -900,3 +1270,12 @@ extern "C" int sd_qkv_rope_wide_a8(const void* W, const float* w_scale, const fl
                              v_cache, block_tables, max_blocks_per_seq, seq_lens, pos_offset, B, q_len,
                              Hq, Hkv, D, K, rope_pos, workspace, workspace_bytes, stream);
 }
+
+#ifdef SD_WIDE_HAS_SWITCH
+extern "C" void sd_debug_wide_four_waves(int v) { g_wide_four_waves = v; }
+#endif
+#ifdef SD_WIDE_STAMPS
+extern "C" int sd_debug_read_wide_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sd_wide_stamps), sizeof(sd_wide_stamps));
+}
+#endif
