@@ -66,12 +66,14 @@ def case(name, N, K, kind, Ms=(96, 128, 192, 256), L=6, fp8=False):
 
 
 if __name__ == "__main__":
-    if "--quick" in sys.argv:      # 192 rows only (also what experiments/build_wide_exp.sh builds)
+    if "--quick" in sys.argv:      # one row count (192: what experiments/build_wide_exp.sh builds)
+        Ms = (int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 192,)
         for _ in range(2):
-            case("llama gate/up", 14336, 4096, "gated", Ms=(192,))
-        case("llama down", 4096, 14336, "res", Ms=(192,))
-        case("qwen gate/up", 18944, 3584, "gated", Ms=(192,))
-        case("llama head", 128256, 4096, "plain", Ms=(192,), L=2)
+            case("llama gate/up", 14336, 4096, "gated", Ms=Ms)
+        case("llama down", 4096, 14336, "res", Ms=Ms)
+        case("qwen gate/up", 18944, 3584, "gated", Ms=Ms)
+        case("llama head", 128256, 4096, "plain", Ms=Ms, L=2)
+        case("qwen head", 152064, 3584, "plain", Ms=Ms, L=2)
         sys.exit(0)
     case("llama gate/up", 14336, 4096, "gated")
     case("llama qkv", 6144, 4096, "plain")

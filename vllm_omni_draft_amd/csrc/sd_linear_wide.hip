@@ -1059,6 +1059,19 @@ int launch_gemm(const WideArgs& a, int S, hipStream_t st) {
     if (g_wide_four_waves >= 0) four = four && g_wide_four_waves != 0;
 #endif
     if (four) return launch_gemm4<MT, EPI, 2, 4>(a, S, st);
+    // 16-tile groups at 256 rows: the eight-wave kernel needs more registers than a wave of
+    // eight has (it spills); the same tiles in 8-tile groups on four waves, in more rounds.
+    if constexpr (MT == 16) {
+      bool split_pairs = pair && S == 1 && a.K % (2 * kChunkCols) == 0;
+#ifdef SD_WIDE_HAS_SWITCH
+      if (g_wide_four_waves >= 0) split_pairs = split_pairs && g_wide_four_waves != 0;
+#endif
+      if (split_pairs) {
+        WideArgs b = a;
+        b.group_tiles = kWideWaves;
+        return launch_gemm4<MT, EPI, 2, 4>(b, S, st);
+      }
+    }
   }
   return pair ? launch_gemm_t<MT, EPI, 2>(a, S, st) : launch_gemm_t<MT, EPI, 1>(a, S, st);
 }
@@ -1108,7 +1121,10 @@ int gemm_by_kind(const WideArgs& a, int epi, int S, hipStream_t st) {
 template <bool DIRECT>
 int gemm_by_rows(const WideArgs& a, int mt, int epi, int S, hipStream_t st) {
 #ifdef SD_WIDE_EXP
-  return gemm_by_kind<12, DIRECT>(a, epi, S, st);
+#ifndef SD_WIDE_EXP_MT
+#define SD_WIDE_EXP_MT 12
+#endif
+  return gemm_by_kind<SD_WIDE_EXP_MT, DIRECT>(a, epi, S, st);
 #else
   if (mt <= 2) return gemm_by_kind<2, DIRECT>(a, epi, S, st);
   if (mt <= 4) return gemm_by_kind<4, DIRECT>(a, epi, S, st);
