@@ -328,14 +328,16 @@ int sd_tree_prepare(const int32_t* tok_buf, int64_t tok_stride, int tok_col,
                     int32_t* tree_tok, const int32_t* tree_depth,
                     const int32_t* seq_lens, int pos_offset, int32_t* rope_pos, int B,
                     int q_len, sd_stream_t stream);
-/* First level of a tree grown by the draft model: the b largest entries of logits row
- * row_offset + s*row_step of every sequence s as tokens, largest first (ties: lowest index),
- * into out_tok[s*out_stride + out_col .. + b).  (Upstream's top-k proposers: the Medusa /
- * EAGLE-style top-k candidate selection of vllm/spec_decode; no draft distribution is kept:
- * the candidates are verified as point masses.)                                    */
+/* Levels of a tree grown by the draft model: for every sequence s and r < rows the b largest
+ * entries of logits row row_offset + s*row_step + r as tokens, largest first (ties: lowest
+ * index), into out_tok[s*out_stride + out_col + r*b .. + b).  The first level takes rows = 1,
+ * b = the branches; a deeper level rows = the branches, b = 1 (every branch's arg-max).
+ * (Upstream's top-k proposers: the Medusa / EAGLE-style top-k candidate selection of
+ * vllm/spec_decode; no draft distribution is kept: the candidates are verified as point
+ * masses.)                                                                          */
 #define SD_TOPK_TOKENS_MAX 8
 int sd_topk_tokens(const float* logits, int64_t ld, int V, int row_offset, int row_step,
-                   int b, int32_t* out_tok, int64_t out_stride, int out_col, int B,
+                   int rows, int b, int32_t* out_tok, int64_t out_stride, int out_col, int B,
                    sd_stream_t stream);
 /* Greedy acceptance over a tree.  target_ids [B*q_len] i64: the target's argmax
  * after every row.  tree_tok / tree_parent [B, q_len] i32 (parent row of rows

@@ -471,8 +471,19 @@ def test_topk_tokens_against_a_stable_sort(V):
         want = torch.sort(x[off::step], dim=1, descending=True, stable=True).indices[:, :b]
         assert out[:, 2:2 + b].cpu().tolist() == want.tolist(), (b, off, step)
         assert (out[:, :2] == -5).all() and (out[:, 2 + b:] == -5).all()
+    # several consecutive rows per sequence in one launch (a level of a draft-grown tree: every
+    # branch's arg-max): sequence s takes rows 1 + 4 s + r, r < 3, two tokens each
+    out = torch.full((2, 12), -5, dtype=torch.int32).cuda()
+    ops.topk_tokens(xd, 2, out, 1, row_offset=1, row_step=4, rows=3, B=2)
+    torch.cuda.synchronize()
+    want = torch.sort(x, dim=1, descending=True, stable=True).indices[:, :2]
+    for s in range(2):
+        assert out[s, 1:7].cpu().tolist() == want[1 + 4 * s:4 + 4 * s].reshape(-1).tolist()
+        assert out[s, 0].item() == -5 and (out[s, 7:] == -5).all()
     with pytest.raises(Exception):
         ops.topk_tokens(xd, ops.TOPK_TOKENS_MAX + 1, torch.zeros(R, 12, dtype=torch.int32).cuda(), 0)
+    with pytest.raises(Exception):
+        ops.topk_tokens(xd, 1, torch.zeros(R, 12, dtype=torch.int32).cuda(), 0, row_step=2, rows=3)   # rows overlap
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

@@ -139,7 +139,7 @@ SIGNATURES = {
     "sd_qkv_rope_wide": (i32, [vp, vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,
                                i32, i32, i32, i32, i32, C.POINTER(RopePositions), vp, C.c_size_t, vp]),
     "sd_row_scales_fp8": (i32, [vp, i64, i32, i32, vp, vp]),
-    "sd_topk_tokens": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
+    "sd_topk_tokens": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, i64, i32, i32, vp]),
     "sd_norm_linear_argmax": (i32, [vp, vp, vp, i64, vp, vp, C.c_float, i32, vp, vp, i32, i32, i32, vp]),
     "sd_linear_wide_a8": (i32, [vp, vp, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, C.c_size_t, vp]),
     "sd_qkv_rope_wide_a8": (i32, [vp, vp, vp, vp, i64, vp, vp, i64, vp, i32, vp, vp, vp, i32, vp, i32, i32,

@@ -321,11 +321,13 @@ __global__ __launch_bounds__(SD_WAVE) void tree_prepare_kernel(
 }
 
 // The b largest entries of a logits row as tokens (largest first; ties: lowest index), one
-// workgroup per sequence: b sweeps over the row, each skipping the winners so far.  Feeds the
-// first level of a tree grown by the draft model.
+// workgroup per sequence and row: b sweeps over the row, each skipping the winners so far.
+// Feeds the levels of a tree grown by the draft model.
 __global__ __launch_bounds__(kSampleThreads) void topk_tokens_kernel(
     const float* __restrict__ logits, int64_t ld, int V, int row_offset, int row_step, int b,
     int32_t* __restrict__ out_tok, int64_t out_stride, int out_col) {
+  row_offset += blockIdx.y;
+  out_col += blockIdx.y * b;
   __shared__ float s_f[kSampleWaves];
   __shared__ int s_i[kSampleWaves];
   __shared__ int s_win[SD_TOPK_TOKENS_MAX];
@@ -1534,16 +1536,18 @@ extern "C" int sd_tree_accept_sample(const float* target_probs, int64_t ld, cons
 }
 
 extern "C" int sd_topk_tokens(const float* logits, int64_t ld, int V, int row_offset, int row_step,
-                              int b, int32_t* out_tok, int64_t out_stride, int out_col, int B,
-                              sd_stream_t stream) {
-  SD_REQUIRE(logits && out_tok && V >= 1 && ld >= V && row_offset >= 0 && row_step >= 1 && B >= 0,
-             SD_ERR_INVALID, "sd_topk_tokens: bad arguments (B=%d V=%d)", B, V);
-  SD_REQUIRE(b >= 1 && b <= SD_TOPK_TOKENS_MAX && b <= V && out_col >= 0 && out_stride >= out_col + b,
-             SD_ERR_INVALID, "sd_topk_tokens: b=%d outside 1..%d or the row is too short", b,
+                              int rows, int b, int32_t* out_tok, int64_t out_stride, int out_col,
+                              int B, sd_stream_t stream) {
+  SD_REQUIRE(logits && out_tok && V >= 1 && ld >= V && row_offset >= 0 && row_step >= 1 && B >= 0 &&
+                 rows >= 1 && rows <= row_step,
+             SD_ERR_INVALID, "sd_topk_tokens: bad arguments (B=%d V=%d rows=%d)", B, V, rows);
+  SD_REQUIRE(b >= 1 && b <= SD_TOPK_TOKENS_MAX && b <= V && out_col >= 0 &&
+                 out_stride >= out_col + (int64_t)rows * b,
+             SD_ERR_INVALID, "sd_topk_tokens: b=%d outside 1..%d or the output row is too short", b,
              SD_TOPK_TOKENS_MAX);
   if (B == 0) return SD_OK;
-  hipLaunchKernelGGL(topk_tokens_kernel, dim3(B), dim3(kSampleThreads), 0, (hipStream_t)stream, logits,
-                     ld, V, row_offset, row_step, b, out_tok, out_stride, out_col);
+  hipLaunchKernelGGL(topk_tokens_kernel, dim3(B, rows), dim3(kSampleThreads), 0, (hipStream_t)stream,
+                     logits, ld, V, row_offset, row_step, b, out_tok, out_stride, out_col);
   SD_CHECK_LAUNCH("sd_topk_tokens");
   return SD_OK;
 }

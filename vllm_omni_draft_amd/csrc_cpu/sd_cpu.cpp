@@ -1335,14 +1335,16 @@ extern "C" int sd_advance_state(const int64_t* out_ids, int32_t* seq_lens, int32
   return SD_OK;
 }
 
-extern "C" int sd_topk_tokens(const float* logits, int64_t ld, int V, int row_offset, int row_step, int b,
-                              int32_t* out_tok, int64_t out_stride, int out_col, int B, sd_stream_t) {
+extern "C" int sd_topk_tokens(const float* logits, int64_t ld, int V, int row_offset, int row_step, int rows,
+                              int b, int32_t* out_tok, int64_t out_stride, int out_col, int B, sd_stream_t) {
   REQUIRE(logits && out_tok && V >= 1 && ld >= V && row_offset >= 0 && row_step >= 1 && B >= 0 && b >= 1 &&
-              b <= SD_TOPK_TOKENS_MAX && b <= V && out_col >= 0 && out_stride >= out_col + b,
+              rows >= 1 && rows <= row_step && b <= SD_TOPK_TOKENS_MAX && b <= V && out_col >= 0 &&
+              out_stride >= out_col + (int64_t)rows * b,
           SD_ERR_INVALID, "sd_topk_tokens: bad arguments");
 #pragma omp parallel for
-  for (int s = 0; s < B; ++s) {
-    const float* row = logits + (size_t)(row_offset + s * row_step) * ld;
+  for (int sr = 0; sr < B * rows; ++sr) {
+    const int s = sr / rows, r = sr % rows;
+    const float* row = logits + (size_t)(row_offset + s * row_step + r) * ld;
     int win[SD_TOPK_TOKENS_MAX];
     for (int c = 0; c < b; ++c) {
       float best = -INFINITY;
@@ -1357,7 +1359,7 @@ extern "C" int sd_topk_tokens(const float* logits, int64_t ld, int V, int row_of
         for (int e = 0; e < c; ++e) if (win[e] == bi) { ++bi; e = -1; }
       }
       win[c] = bi;
-      out_tok[(size_t)s * out_stride + out_col + c] = bi;
+      out_tok[(size_t)s * out_stride + out_col + r * b + c] = bi;
     }
   }
   return SD_OK;

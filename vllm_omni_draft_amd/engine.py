@@ -1111,9 +1111,8 @@ class SpecEngine:
             d_rope[:B].copy_(rope[:B, 1:1 + qd])
             self._forward(self.draft, self.d_kv, self.tree_tok, q, 1, self.seq_lens, 0, B, qd,
                           self.d_out, tree=(self.dtree_mask[d], d_rope.view(-1)))
-            for c in range(nb):
-                ops.topk_tokens(self.d_out[:B * qd], 1, self.tree_tok, 1 + qd + c,
-                                row_offset=qd - nb + c, row_step=qd, B=B)
+            ops.topk_tokens(self.d_out[:B * qd], 1, self.tree_tok, 1 + qd, row_offset=qd - nb, row_step=qd,
+                            rows=nb, B=B)
 
     # -- the target's logits after a pass of n rows (whole, or one vocabulary slice per rank)
     def _target_head_fused(self) -> bool:
@@ -1562,9 +1561,7 @@ class SpecEngine:
         # contexts on the single-split path (no partials, no merge kernel).  The split
         # boundaries stay at fixed absolute positions, so results do not depend on the bound.
         self._ctx = self._ctx_bucket()
-        if self.draft_tree:
-            pass                          # the draft grows the tree inside the step
-        elif self.tree:
+        if self.tree and not self.draft_tree:   # (a draft-grown tree is filled in inside the step)
             pending, self._pending_props = self._pending_props, None
             cands = []
             for b in range(B):

@@ -381,14 +381,14 @@ TOPK_TOKENS_MAX = 8
 
 
 def topk_tokens(logits, b: int, out_tok, out_col: int, *, row_offset: int = 0, row_step: int = 1,
-                B: Optional[int] = None) -> None:
-    """out_tok[s, out_col + c] = the c-th largest entry of logits row row_offset + s*row_step as a
-    token (largest first; ties: lowest index), c < b <= TOPK_TOKENS_MAX."""
+                rows: int = 1, B: Optional[int] = None) -> None:
+    """out_tok[s, out_col + r*b + c] = the c-th largest entry of logits row row_offset + s*row_step + r
+    as a token (largest first; ties: lowest index), r < rows, c < b <= TOPK_TOKENS_MAX."""
     _need(logits, torch.float32, "logits")
     _need(out_tok, torch.int32, "out_tok")
     n = out_tok.shape[0] if B is None else B
     _lib.check(_lib.load().sd_topk_tokens(_p(logits), logits.stride(0), logits.shape[1], row_offset,
-                                          row_step, b, _p(out_tok), out_tok.stride(0), out_col, n,
+                                          row_step, rows, b, _p(out_tok), out_tok.stride(0), out_col, n,
                                           _stream()), "sd_topk_tokens")
 
 
