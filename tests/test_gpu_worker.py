@@ -133,16 +133,18 @@ def test_typical_acceptance_sampler_module():
     assert [ts.num_accepted_tokens, ts.num_emitted_tokens, ts.num_draft_tokens] == total.tolist()
 
 
-@pytest.mark.parametrize("option", ["ngram", "disable_by_batch_size", "typical_never", "fp8"])
+@pytest.mark.parametrize("option", ["ngram", "disable_by_batch_size", "typical_never", "fp8", "draft_tree"])
 def test_worker_options_keep_the_greedy_stream(option):
     """Options that keep upstream's names, through the worker: prompt lookup without a draft
     model, speculation switched off above a batch size, a typical-acceptance threshold nothing
-    passes (every step emits the target's most likely token), fp8 weights: the stream stays the
-    target's own greedy stream."""
+    passes (every step emits the target's most likely token), fp8 weights, a tree of three
+    branches grown by a (rotary) draft model: the stream stays the target's own greedy stream."""
     from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SequenceGroupMetadata,
                                                         SpecDecodeConfig, SpecDecodeWorker)
     tcfg = MODELS["llama"]
     dcfg = OracleConfig(**{**vars(MODELS["opt"]), "vocab": tcfg.vocab})
+    if option == "draft_tree":
+        dcfg = OracleConfig(**{**vars(tcfg), "n_layers": 1})
     fp8 = option == "fp8"
     tw = _product(tcfg, _bf(random_state(tcfg, seed=21)), fp8=fp8)
     dw = _product(dcfg, _bf(random_state(dcfg, seed=22)), fp8=fp8)
@@ -154,6 +156,8 @@ def test_worker_options_keep_the_greedy_stream(option):
         kw.update(draft=None, ngram_prompt_lookup_max=3, ngram_prompt_lookup_min=1)
     elif option == "disable_by_batch_size":
         kw.update(speculative_disable_by_batch_size=1)
+    elif option == "draft_tree":
+        kw.update(speculative_draft_tree_branches=3)
     elif option == "typical_never":
         kw.update(temperature=1.0, spec_decoding_acceptance_method="typical_acceptance_sampler",
                   typical_acceptance_sampler_posterior_threshold=2.0,
@@ -161,6 +165,8 @@ def test_worker_options_keep_the_greedy_stream(option):
     w = SpecDecodeWorker(SpecDecodeConfig(**kw))
     w.init_device()
     w.load_model()
+    if option == "draft_tree":
+        assert w.engine.tree and w.engine.tree_nodes == 9
     got = {r: [] for r in prompts}
     out = w.execute_model(ExecuteModelRequest(
         [SequenceGroupMetadata(r, True, p) for r, p in prompts.items()]))
