@@ -624,3 +624,43 @@ def test_draft_grown_trees_refuse_what_they_cannot_do():
     ow = _product(ocfg, _bf(random_state(ocfg, seed=3)))
     with pytest.raises(ValueError):
         _engine(tw, ow, 3, draft_tree_branches=3)                         # a draft with learned positions
+
+
+def test_draft_grown_trees_with_sequences_joining_and_leaving():
+    """Slots are reused while a draft-tree engine runs (a sequence leaves, the last slot moves
+    down, another prompt joins, also with a one-token prompt): every stream stays the
+    autoregressive one.  The tree's topology is the same for every slot; what must follow a
+    sequence to its new slot is both caches."""
+    oc = MODELS["llama"]
+    dc = OracleConfig(**{**vars(oc), "n_layers": 1})
+    tw = _product(oc, _bf(random_state(oc, seed=21)))
+    dw = _product(dc, _bf(random_state(dc, seed=23)))
+    rng = np.random.default_rng(11)
+    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in (12, 5, 1, 20, 3)]
+    ar = [_generate(_engine(tw, None, 0), [p], 30)[0] for p in prompts]
+    eng = _engine(tw, dw, 3, max_batch=3, draft_tree_branches=3, use_graph=True)
+    live = {}                       # slot -> [prompt index, tokens so far]
+    for i in range(3):
+        live[i] = [i, [eng.add_request(i, prompts[i])]]
+    waiting, done = [3, 4], {}
+    while live:
+        outs = eng.step()
+        for slot in sorted(live):
+            live[slot][1].extend(outs[slot])
+        for slot in sorted(live, reverse=True):
+            idx, toks = live[slot]
+            if len(toks) >= 30 or (idx == 1 and len(toks) >= 9):     # (one leaves early)
+                done[idx] = toks
+                last = max(live)
+                eng.remove_request(slot)
+                if slot != last:
+                    live[slot] = live[last]
+                del live[last]
+                if waiting:
+                    j = waiting.pop(0)
+                    s = eng.active
+                    live[s] = [j, [eng.add_request(s, prompts[j])]]
+    for idx, toks in done.items():
+        n = min(len(toks), 30)
+        assert toks[:n] == ar[idx][:n], idx
+    assert len(done) == 5
