@@ -390,7 +390,7 @@ def test_tree_sampling_walk_matches_the_oracle():
     assert eng.metrics()["emitted"] >= 40
 
 
-@pytest.mark.parametrize("seed", [0, 2, 3])
+@pytest.mark.parametrize("seed", [0, 2, 3, 105])
 def test_random_v1_schedules_on_the_cpu_build(seed, monkeypatch):
     """The randomised V1 schedule of tests/test_gpu_fuzz.py (prompts whole and in pieces,
     preemption and return, finishes anywhere, log-probabilities) through the CPU build: every

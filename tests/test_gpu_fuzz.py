@@ -181,7 +181,10 @@ def test_scheduled_streams_match_the_oracle_golden(rows):
 
 @pytest.mark.parametrize("seed,use_graph,rows,temperature", [
     (0, True, "wide", 0.0), (1, True, "wide", 0.0), (2, False, "wide", 0.0), (3, True, "wide", 0.0),
-    (3, True, "narrow", 0.0), (4, False, "narrow", 0.0), (5, True, "narrow", 0.8), (6, False, "wide", 0.8)])
+    (3, True, "narrow", 0.0), (4, False, "narrow", 0.0), (5, True, "narrow", 0.8), (6, False, "wide", 0.8),
+    # (seeds whose schedule resumes a request in the step right after the one that preempted it,
+    # with no step in between that leaves it out: the scheduler's flag alone tells the worker)
+    (105, True, "narrow", 0.0), (121, False, "wide", 0.0)])
 def test_random_v1_schedules_with_pieces_and_preemption(seed, use_graph, rows, temperature):
     """A random V1 scheduler over the worker: prompts arrive whole or in pieces of random sizes,
     running requests are preempted (left out of steps) and return whole or in pieces, requests

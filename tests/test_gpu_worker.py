@@ -557,3 +557,51 @@ def test_v1_preempted_requests_are_rebuilt_when_they_return():
     run(cached=["a"], finished=["b"])                    # "c" parked, "b" finished
     run(cached=["a"], finished=["c"])                    # finished while parked
     assert w.engine.active == 1 and set(w._tokens) == {"a"}
+
+
+@pytest.mark.parametrize("rows", ["wide", "narrow"])
+def test_v1_requests_restarted_without_a_step_in_between(rows):
+    """A scheduler that preempts a request and resumes it in its very next step (nothing else was
+    running, so no step went by without it) only sets resumed_from_preemption with zero computed
+    tokens: the worker takes the sequence out of its slot itself and rebuilds it, whole or in
+    pieces.  The same flag on a request whose prompt was still arriving in pieces starts its
+    prefill over.  Streams stay the autoregressive ones, bit for bit."""
+    from tests.test_host_logic import _NewRequestData, _sched
+    tw, dw = _llama_pair()
+    prompts = {"a": [5, 9, 200, 31, 7, 11, 2], "b": list(range(40, 73))}
+    want = {r: _generate(_engine(tw, None, 0, rows=rows), [p], 30)[0] for r, p in prompts.items()}
+    w = _worker(tw, dw, 3, True, rows=rows)
+    got = {r: [] for r in prompts}
+    N = lambda r: _NewRequestData(r, prompts[r], sampling_params={"temperature": 0.0})
+
+    def run(new=(), cached=(), pieces=None, finished=(), resumed=()):
+        so = _sched(new=list(new), cached=list(cached), finished=finished, resumed=resumed)
+        so.num_scheduled_tokens.update(pieces or {})
+        out = w.execute_model(so)
+        for r, toks in zip(out.req_ids, out.sampled_token_ids):
+            got[r].extend(toks)
+        return dict(zip(out.req_ids, out.sampled_token_ids))
+
+    run(new=[N("a")])
+    run(cached=["a"])
+    run(cached=["a"])
+    n_a = len(prompts["a"]) + len(got["a"])
+    o = run(cached=["a"], pieces={"a": n_a}, resumed={"a"})             # restarted whole, never left out
+    assert len(o["a"]) == 1 and w.engine.active == 1 and not w._parked
+    run(cached=["a"])
+    n_a = len(prompts["a"]) + len(got["a"])
+    o = run(cached=["a"], pieces={"a": n_a - 4}, resumed={"a"})         # restarted in two pieces
+    assert o["a"] == [] and w.engine.active == 0 and len(w._prefill_of) == 1
+    o = run(cached=["a"], pieces={"a": 4})
+    assert len(o["a"]) == 1 and w.engine.active == 1
+    # "b" arrives in pieces and is restarted half way: its prefill starts over, in other pieces
+    o = run(new=[N("b")], cached=["a"], pieces={"b": 10})
+    assert o["b"] == [] and len(w._prefill_of) == 1
+    o = run(cached=["a", "b"], pieces={"b": 20}, resumed={"b"})
+    assert o["b"] == [] and len(w._prefill_of) == 1 and w._prefill_left["b"] == len(prompts["b"]) - 20
+    o = run(cached=["a", "b"], pieces={"b": len(prompts["b"]) - 20})
+    assert len(o["b"]) == 1 and w.engine.active == 2 and not w._prefill_of
+    while min(len(got[r]) for r in prompts) < 30:
+        run(cached=["a", "b"])
+    for r in prompts:
+        assert got[r][:30] == want[r], r

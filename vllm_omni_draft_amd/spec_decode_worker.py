@@ -573,9 +573,10 @@ class _StepPlan:
     prompts: List[SequenceGroupMetadata]        # whole prompts
     finished: List[str]                         # running requests that end
     dropped: List[str]                          # half-prefilled requests that end
-    parked_now: List[str]                       # running requests the step left out
-    resumed: Set[str]                           # parked requests named again
+    parked_now: List[str]                       # running requests the step left out (or restarts)
+    resumed: Set[str]                           # requests the scheduler recomputes in this step
     mm_inputs: Dict[str, dict]
+    reprefilled: List[str] = field(default_factory=list)   # half-prefilled requests that start over
     asked: List[int] = field(default_factory=list)   # logprobs counts asked for by the step's requests
 
 
@@ -764,7 +765,7 @@ class SpecDecodeWorker:
         self._admit_pieces(plan, out, lp)
         return self._collect(plan, out, lp)
 
-    def _rebuilt(self, g: SequenceGroupMetadata) -> SequenceGroupMetadata:
+    def _rebuilt(self, g: SequenceGroupMetadata, leaving: bool = False) -> SequenceGroupMetadata:
         """The prompt-shaped request that rebuilds a parked sequence named again by the step:
         prompt + emitted tokens, prefilled whole (it then emits a token in this step) or, when
         the scheduler recomputes it from position 0 in pieces, in those pieces.  The tokens it
@@ -786,8 +787,8 @@ class SpecDecodeWorker:
             piece = None
         sp = first.sampling_params
         if sp.seed is not None:      # a stream of its own for every incarnation
-            sp = SamplingParams(**{**vars(sp), "seed": (sp.seed + 0x9E3779B1 * self._park_count[rid])
-                                   & 0x7FFFFFFFFFFFFFFF})
+            n_parked = self._park_count.get(rid, 0) + (1 if leaving else 0)   # (leaving: parked by this step)
+            sp = SamplingParams(**{**vars(sp), "seed": (sp.seed + 0x9E3779B1 * n_parked) & 0x7FFFFFFFFFFFFFFF})
         return SequenceGroupMetadata(
             rid, True, list(toks), sp, multi_modal_data=first.multi_modal_data,
             num_prompt_tokens=piece if piece is not None and 1 <= piece < len(toks) else None,
@@ -804,8 +805,22 @@ class SpecDecodeWorker:
         named = {g.request_id for g in metas}
         parked_now = [r for r in self._req_at if r not in named and r not in req.finished_requests_ids]
         resumed = {g.request_id for g in metas if not g.is_prompt and g.request_id in self._parked}
+        # A scheduler may also preempt a request and resume it without a step in between that
+        # leaves it out (nothing else was running, so there was no step): the flag says that it
+        # recomputes the request from its first token.  The sequence leaves its slot now and is
+        # rebuilt like any other returning request.
+        restarted = [g.request_id for g in metas
+                     if not g.is_prompt and g.resumed_from_preemption and g.request_id in self._slot_of
+                     and g.request_id not in req.finished_requests_ids]
+        parked_now += restarted
+        # ... or one whose prompt was still arriving in pieces: its prefill starts over
+        reprefilled = [g.request_id for g in metas
+                       if not g.is_prompt and g.resumed_from_preemption and g.request_id in self._prefill_of
+                       and g.request_id not in req.finished_requests_ids]
+        resumed |= set(restarted) | set(reprefilled)
         if resumed:
-            metas = [self._rebuilt(g) if g.request_id in resumed else g for g in metas]
+            metas = [self._rebuilt(g, leaving=g.request_id in restarted) if g.request_id in resumed else g
+                     for g in metas]
         # prompts that arrive in pieces (chunked prefill): first pieces and continuations
         continued = [g for g in metas if not g.is_prompt and g.request_id in self._prefill_of]
         running = [g for g in metas if not g.is_prompt and g.request_id not in self._prefill_of]
@@ -814,6 +829,7 @@ class SpecDecodeWorker:
         prompts = [g for g in metas if g.is_prompt and g not in pieces]
         finished = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._slot_of]
         dropped = [r for r in dict.fromkeys(req.finished_requests_ids) if r in self._prefill_of]
+        leaving = set(restarted) | set(reprefilled)      # (their slots are free before anything is admitted)
 
         have = getattr(getattr(eng, "cfg", None), "temperature", None)
         max_len = getattr(getattr(eng, "cfg", None), "max_seq_len", None)
@@ -863,8 +879,9 @@ class SpecDecodeWorker:
                                  f"min_p {sp.min_p} in [0, 1]")
             if g.request_id in self._parked and g.request_id not in resumed:
                 raise KeyError(f"request {g.request_id} is parked on this worker; finish it first")
-            if (g.request_id in self._slot_of and g.request_id not in finished) or (
-                    g.request_id in self._prefill_of and g.request_id not in dropped):
+            if g.request_id not in leaving and (
+                    (g.request_id in self._slot_of and g.request_id not in finished) or (
+                        g.request_id in self._prefill_of and g.request_id not in dropped)):
                 raise KeyError(f"request {g.request_id} is already running")
             n = len(g.prompt_token_ids)
             if n < 1 or (max_len is not None and n + 1 > max_len):
@@ -880,7 +897,7 @@ class SpecDecodeWorker:
             raise ValueError(f"{n_after} sequences are running but the step names {len(running)}")
         if parked_now and not all(r in self._tokens for r in parked_now):
             raise ValueError(f"requests {parked_now} are running but not named by the step")
-        n_prefilling = len(self._prefill_of) - len(dropped)
+        n_prefilling = len(self._prefill_of) - len(dropped) - len(reprefilled)
         if n_after + n_prefilling + len(prompts) + len(pieces) > eng.cfg.max_batch:
             raise RuntimeError("no free sequence slot (max_num_seqs reached)")
         if req.external_proposals is not None and not getattr(eng, "external", False):
@@ -889,7 +906,7 @@ class SpecDecodeWorker:
         # multimodal inputs (vision tower included) are prepared before the step as well
         mm_inputs = {g.request_id: self._multimodal_inputs(g) for g in prompts}
         return _StepPlan(req, metas, running, continued, pieces, prompts, finished, dropped,
-                         parked_now, resumed, mm_inputs)
+                         parked_now, resumed, mm_inputs, reprefilled)
 
     def _retire(self, plan: "_StepPlan") -> None:
         """Requests that leave: finished ones (running, parked or half prefilled) and the
@@ -907,6 +924,9 @@ class SpecDecodeWorker:
             eng.prefill_abort(self._prefill_of.pop(rid))
             self._prefill_left.pop(rid, None)
             self._forget(rid)
+        for rid in plan.reprefilled:         # starts over in this step: its token log stays
+            eng.prefill_abort(self._prefill_of.pop(rid))
+            self._prefill_left.pop(rid, None)
         # log-probabilities: computed for the whole step as soon as one of its requests asks
         for g in plan.prompts + plan.pieces:
             if g.sampling_params.logprobs is not None:
