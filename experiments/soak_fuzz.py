@@ -4,6 +4,7 @@
 import sys, itertools, traceback
 sys.path.insert(0, ".")
 import tests.test_gpu_fuzz as fz
+import tests.test_gpu_tree as tt
 bad = 0
 n = 0
 for seed in range(100, 124):
@@ -23,5 +24,12 @@ for seed in range(100, 124):
             bad += 1
             print("FAIL join", seed, rows, mb, k, graph, flush=True)
             traceback.print_exc()
+    try:
+        tt.test_draft_grown_trees_with_sequences_joining_and_leaving(seed)
+        n += 1
+    except Exception:
+        bad += 1
+        print("FAIL draft tree", seed, flush=True)
+        traceback.print_exc()
     print("seed", seed, "done", n, "ok", bad, "bad", flush=True)
 print("TOTAL ok", n, "bad", bad)

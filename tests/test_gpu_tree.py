@@ -626,7 +626,8 @@ def test_draft_grown_trees_refuse_what_they_cannot_do():
         _engine(tw, ow, 3, draft_tree_branches=3)                         # a draft with learned positions
 
 
-def test_draft_grown_trees_with_sequences_joining_and_leaving():
+@pytest.mark.parametrize("seed", [11, 12])
+def test_draft_grown_trees_with_sequences_joining_and_leaving(seed):
     """Slots are reused while a draft-tree engine runs (a sequence leaves, the last slot moves
     down, another prompt joins, also with a one-token prompt): every stream stays the
     autoregressive one.  The tree's topology is the same for every slot; what must follow a
@@ -635,10 +636,12 @@ def test_draft_grown_trees_with_sequences_joining_and_leaving():
     dc = OracleConfig(**{**vars(oc), "n_layers": 1})
     tw = _product(oc, _bf(random_state(oc, seed=21)))
     dw = _product(dc, _bf(random_state(dc, seed=23)))
-    rng = np.random.default_rng(11)
-    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in (12, 5, 1, 20, 3)]
+    rng = np.random.default_rng(seed)
+    lens = (12, 5, 1, 20, 3) if seed == 11 else tuple(int(n) for n in rng.integers(1, 40, 5))
+    prompts = [[int(t) for t in rng.integers(0, oc.vocab, n)] for n in lens]
     ar = [_generate(_engine(tw, None, 0), [p], 30)[0] for p in prompts]
-    eng = _engine(tw, dw, 3, max_batch=3, draft_tree_branches=3, use_graph=True)
+    eng = _engine(tw, dw, int(rng.integers(1, 5)) if seed != 11 else 3, max_batch=3,
+                  draft_tree_branches=int(rng.integers(2, 5)) if seed != 11 else 3, use_graph=bool(seed % 2))
     live = {}                       # slot -> [prompt index, tokens so far]
     for i in range(3):
         live[i] = [i, [eng.add_request(i, prompts[i])]]
