@@ -605,3 +605,51 @@ def test_v1_requests_restarted_without_a_step_in_between(rows):
         run(cached=["a", "b"])
     for r in prompts:
         assert got[r][:30] == want[r], r
+
+
+@pytest.mark.parametrize("kind", ["draft_tree", "lookup_tree"])
+def test_tree_workers_step_as_a_whole_without_the_graph(kind):
+    """A tree engine has no [B, k] proposal to hand to the scorer, so the worker runs its step as
+    one unit also when graphs are off (the piecewise propose / score / accept path serves chains).
+    Seen from outside: trees are really verified (with draft == target every step accepts k
+    tokens; prompt lookup accepts some), and the log-probability report names the emitted tokens
+    (its rows follow the accepted path of the tree step that ran)."""
+    from vllm_omni_draft_amd.spec_decode_worker import (ExecuteModelRequest, SamplingParams,
+                                                        SequenceGroupMetadata, SpecDecodeConfig,
+                                                        SpecDecodeWorker)
+    tcfg = MODELS["llama"]
+    tw = _product(tcfg, _bf(random_state(tcfg, seed=21)))
+    prompts = {"a": [5, 9, 200, 31, 7, 5, 9, 200, 31], "b": list(range(40, 52)) * 2}
+    want = {r: _generate(_engine(tw, None, 0), [p], 24)[0] for r, p in prompts.items()}
+    kw = dict(target=tw, draft=tw, num_speculative_tokens=3, max_num_seqs=2, max_model_len=200,
+              split_tokens=128, use_graph=False)
+    if kind == "draft_tree":
+        kw.update(speculative_draft_tree_branches=3)
+    else:
+        kw.update(draft=None, ngram_prompt_lookup_max=3, ngram_prompt_lookup_min=1, speculative_tree_candidates=3)
+    w = SpecDecodeWorker(SpecDecodeConfig(**kw))
+    w.init_device()
+    w.load_model()
+    assert w.engine.tree
+    sp = SamplingParams(temperature=0.0, logprobs=1)
+    got = {r: [] for r in prompts}
+    out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata(r, True, p, sp) for r, p in prompts.items()]))
+    steps = 0
+    while True:
+        lp = out.logprobs
+        for i, (r, toks) in enumerate(zip(out.req_ids, out.sampled_token_ids)):
+            for j, t in enumerate(toks):
+                n = lp.cu_num_generated_tokens[i] + j
+                assert lp.logprob_token_ids[n][0] == t and lp.sampled_token_ranks[n] == 1, (r, j)
+            got[r].extend(toks)
+        if min(len(t) for t in got.values()) >= 24:
+            break
+        out = w.execute_model(ExecuteModelRequest([SequenceGroupMetadata(r, False) for r in prompts]))
+        steps += 1
+    for r in prompts:
+        assert got[r][:24] == want[r], r
+    m = w.engine.metrics()
+    if kind == "draft_tree":
+        assert m["accepted"] == 3 * 2 * steps, m          # the first branch is the target's own continuation
+    else:
+        assert m["accepted"] > 0, m

@@ -383,6 +383,7 @@ class SpecEngine:
         self.rope_delta = torch.zeros(B, dtype=torch.int32, device=dev)
         self._records = _rt.pin(torch.full((2, B, k + 3), -1, dtype=torch.int32))
         self._parity = 0
+        self._tree_step = False  # whether the last step verified token trees (not chains)
         self._inflight = None   # (event, record parity, sequences) of a step not yet read back
         self._steps_pending = 0               # steps enqueued since the last read-back
         # speculate-or-not policy (EngineConfig.spec_policy)
@@ -981,7 +982,7 @@ class SpecEngine:
         B, k = self.active, self.k
         if k == 0 or self._spec_disabled():
             rows = [[b] if out[b] else [] for b in range(B)]
-        elif self.tree:
+        elif self._tree_step:                     # (the step that ran verified trees)
             q = self.tree_nodes + 1
             path = self.tree_path[:B].tolist()    # rows of the accepted nodes; the root is row 0
             rows = [[b * q + (0 if j == 0 else path[b][j - 1]) for j in range(len(out[b]))]
@@ -1599,12 +1600,14 @@ class SpecEngine:
             for b in range(self.active):
                 self.host_lens[b] += self.k + 1
             self._steps_pending += 1
+            self._tree_step = False      # (enqueued piecewise: propose, score, accept of chains)
             return self._read_back()
 
     def _step(self, sync: bool) -> Optional[List[List[int]]]:
         B, k = self.active, self.k
         if B == 0:
             return [] if sync else None
+        self._tree_step = self.tree      # (_enqueue_step verifies trees on a tree engine)
         self._prepare_step()
         if self._auto:
             import time

@@ -1060,8 +1060,10 @@ class SpecDecodeWorker:
         """propose -> score -> verify, as one replayed graph when enabled."""
         eng = self.engine
         if self._foreign_proposer is None and (eng.cfg.use_graph or eng._spec_disabled()
-                                               or getattr(eng, "_auto", False)):
-            return eng.step()        # (a policy engine decides inside the step whether to speculate)
+                                               or getattr(eng, "_auto", False) or getattr(eng, "tree", False)):
+            # (a policy engine decides inside the step whether to speculate; a tree step is one
+            # unit: its candidates are no [B, k] proposal for the scorer's interface)
+            return eng.step()
         eng.prepare_step()
         proposals = self.proposer.get_spec_proposals(req, frozenset())
         scores = self.scorer.score_proposals(req, proposals)
