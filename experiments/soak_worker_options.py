@@ -1,7 +1,7 @@
 """Soak run of the randomised V1 schedule (prompts in pieces, preemption and return, early
 finishes, log-probabilities) with worker options the test suite runs it without: the
 speculate-or-not policy, trees grown by the draft model, speculation switched off above a batch
-size, fp8 weights.  Greedy: every stream must stay the autoregressive one.
+size, fp8 weights, prompt-lookup proposals as chains and as trees.  Greedy: every stream must stay the autoregressive one.
     python experiments/soak_worker_options.py [first_seed] [n_seeds]
 """
 import sys
@@ -19,8 +19,7 @@ plain_weights = fz._weights
 
 def with_options(**opts):
     def init(self, *a, **k):
-        for name, v in opts.items():
-            k.setdefault(name, v)
+        k.update(opts)
         plain_init(self, *a, **k)
     return init
 
@@ -42,6 +41,10 @@ variants = {
     "draft tree": (dict(speculative_draft_tree_branches=3), plain_weights),
     "off above 1 sequence": (dict(speculative_disable_by_batch_size=1), plain_weights),
     "fp8 weights": ({}, fp8_weights),
+    "prompt lookup": (dict(draft=None, ngram_prompt_lookup_max=3, ngram_prompt_lookup_min=1), plain_weights),
+    "lookup trees": (dict(draft=None, ngram_prompt_lookup_max=3, ngram_prompt_lookup_min=1,
+                          speculative_tree_candidates=3), plain_weights),
+    "policy auto + off above 2": (dict(speculative_policy="auto", speculative_disable_by_batch_size=2), plain_weights),
 }
 ok = bad = 0
 for seed in range(first, first + count):
