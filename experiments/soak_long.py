@@ -1,7 +1,8 @@
 """Soak run at engine level over contexts that cross the context buckets of the step graphs and
 the attention split boundaries while sequences join and leave: prompts of 1..400 tokens, 60 new
 tokens each, random k and batch size, both kernel families, graphs on and off, chains and
-draft-grown trees.  Every stream must be the one the request gets alone.
+draft-grown trees, tokens read back after every step, after several steps, or one step late
+(overlapped).  Every stream must be the one the request gets alone.
     python experiments/soak_long.py [first_seed] [n_seeds]
 """
 import random
@@ -39,17 +40,34 @@ def case(seed):
             out.extend(solo.step()[0])
         want.append(out[:N_NEW])
     del solo
-    eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=slots, max_seq_len=480, split_tokens=split, rows=rows,
+    eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=slots, max_seq_len=500, split_tokens=split, rows=rows,
                                           use_graph=rnd.random() < 0.7, **kw))
+    mode = rnd.choice(["sync", "sync", "overlapped", "several"])   # how the host takes the tokens
+
+    def advance():
+        if mode == "sync":
+            return [eng.step()]
+        if mode == "several":        # a few steps without a read-back in between
+            for _ in range(rnd.randint(1, 3)):
+                eng.step(sync=False)
+            return [eng.read_back()]
+        got_now = []                 # overlapped: tokens arrive one call late; flush before the batch changes
+        for _ in range(rnd.randint(1, 4)):
+            o = eng.step_overlapped()
+            if o:
+                got_now.append(o)
+        got_now.append(eng.flush())
+        return got_now
+
     live, waiting, got = {}, list(range(n_req)), {}
     while live or waiting:
         while waiting and len(live) < slots and (not live or rnd.random() < 0.5):
             j = waiting.pop(0)
             s = eng.active
             live[s] = [j, [eng.add_request(s, prompts[j])]]
-        outs = eng.step()
-        for s in sorted(live):
-            live[s][1].extend(outs[s])
+        for outs in advance():
+            for s in sorted(live):
+                live[s][1].extend(outs[s])
         for s in sorted(live, reverse=True):
             j, toks = live[s]
             if len(toks) >= N_NEW:
@@ -60,7 +78,7 @@ def case(seed):
                     live[s] = live[last]
                 del live[last]
     for j in range(n_req):
-        assert got[j] == want[j], (seed, j, rows, slots, k, kw, split, len(prompts[j]))
+        assert got[j] == want[j], (seed, j, rows, slots, k, kw, split, mode, len(prompts[j]))
 
 
 ok = bad = 0
