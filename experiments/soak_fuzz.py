@@ -16,6 +16,14 @@ for seed in range(100, 124):
             bad += 1
             print("FAIL v1", seed, rows, graph, temp, flush=True)
             traceback.print_exc()
+    for rows, graph in (("narrow", True), ("wide", False)):      # sampling requests preempted too
+        try:
+            fz.test_random_v1_schedules_with_pieces_and_preemption(seed, graph, rows, 0.8, preempt_sampling=True)
+            n += 1
+        except Exception:
+            bad += 1
+            print("FAIL v1 sampling with preemption", seed, rows, graph, flush=True)
+            traceback.print_exc()
     for rows, mb, k, graph in (("narrow", 3, 3, True), ("wide", 6, 5, False), ("auto", 4, 1, True)):
         try:
             fz.test_random_join_leave_schedule(rows, mb, k, graph, seed)
