@@ -649,7 +649,7 @@ def _transition_matrix(cfg, state, temperature):
     return torch.stack(rows).numpy()
 
 
-# Stated tolerance of the sampling path ("Oracle and parity status"): over
+# Stated tolerance of the sampling path: over
 # N >= 2e4 emitted tokens, Pearson's chi-square of the (previous, next) token counts against
 # the oracle's conditional distribution, over the cells with an expected count >= 5, has a
 # p-value above 1e-5, and the count-weighted KL divergence of the empirical conditional
