@@ -5,7 +5,8 @@ autoregressive baseline on the same kernels.
 Environment: K = proposals per step (default 5); IMAGE = placeholder tokens of one synthetic image
 at the start of every prompt (a target with rotary sections, e.g. qwen2-vl-7b: image rows are
 random, positions come from multimodal.prepare_prompt); RAGGED=1: prompt lengths uniform in
-64..prompt_len (seed 7) instead of all equal; WIDE_FOUR=0|1 with a library built with
+64..prompt_len (seed 7) instead of all equal; DRAFT_SPLIT = keys per attention workgroup of the
+draft's passes (default: the target's), DRAFT_LANES = parallel streams of its sub-batches; WIDE_FOUR=0|1 with a library built with
 -DSD_WIDE_SWITCH (SD_AMD_LIB): the many-row linear kernel never / wherever built on four waves.
 """
 import os
@@ -84,7 +85,9 @@ for b in range(B):
 del ar
 torch.cuda.empty_cache()
 eng = SpecEngine(tw, dw, EngineConfig(k=k, max_batch=B, max_seq_len=max_seq, rows=rows,
-                                      draft_rows=DRAFT_ROWS, gen_capacity=n_new + 64))
+                                      draft_rows=DRAFT_ROWS, gen_capacity=n_new + 64,
+                                      draft_split_tokens=int(os.environ.get("DRAFT_SPLIT", "0")),
+                                      draft_lanes=int(os.environ.get("DRAFT_LANES", "4"))))
 eng.set_synthetic_acceptance(truth.cuda(), alpha, seed=3)
 out, n, dt = run(eng, steps, warm)
 exact = all(o[:min(len(o), len(a))] == a[:min(len(o), len(a))] for o, a in zip(out, ar_out))
