@@ -483,7 +483,9 @@ __device__ __forceinline__ void emit_unit(const WideEpiArgs& a, int m, int tile,
 // 1.6 us per chunk against 2.1-2.7; what is left over the 0.95 us of its 96 MFMAs is the issue
 // time of its 20 vector memory instructions, which a single wave per SIMD cannot hide.  Tried on
 // the same structure and dropped: eight waves (slower: twice the LDS reads), four tiles per wave
-// for 16-tile groups (every register; 5-10 % slower than the eight-wave kernel), the output
+// for 16-tile groups (every register; 5-10 % slower than the eight-wave kernel), three tiles per
+// wave with the 2049..3072-tile matrices cut into one round of 9..12-tile groups (78 against
+// 83 us at 192 rows: inside the spread between runs), the output
 // staged in LDS and written in whole lines (no gain: the gated epilogue's time is its
 // arithmetic), B rings of 8 and 12 fragments (no change).
 template <int MT, int EPI, int TPW, bool W8, int WAVES>
