@@ -1,5 +1,5 @@
 """Soak run of the randomised engine and V1-schedule tests over seeds the test suite does not use:
-    python experiments/soak_fuzz.py
+    python experiments/soak_fuzz.py [first_seed] [n_seeds]
 """
 import sys, itertools, traceback
 sys.path.insert(0, ".")
@@ -7,7 +7,9 @@ import tests.test_gpu_fuzz as fz
 import tests.test_gpu_tree as tt
 bad = 0
 n = 0
-for seed in range(100, 124):
+FIRST = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+COUNT = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+for seed in range(FIRST, FIRST + COUNT):
     for rows, graph, temp in (("narrow", True, 0.0), ("wide", False, 0.0), ("narrow", False, 0.8), ("wide", True, 0.8)):
         try:
             fz.test_random_v1_schedules_with_pieces_and_preemption(seed, graph, rows, temp)
@@ -90,7 +92,7 @@ def scheduler_case(seed):
         assert r.output_token_ids == exp, (seed, i)
 
 
-for seed in range(400, 480):
+for seed in range(4 * FIRST, 4 * FIRST + 3 * COUNT):
     try:
         scheduler_case(seed)
         n += 1
