@@ -12,10 +12,21 @@
 // (waves without a second tile still pay for it); 4-wave workgroups of 8 tiles, two per CU,
 // with 64-column chunks (the x staging latency of a chunk is then longer than the chunk).
 //
+// wide_gemm4_kernel (further down) serves the many-row passes of some matrices with another
+// chunk structure on four waves; same tiles, same sums, same bits.
+//
 // Matrices with few tiles split K over several workgroups.  Partial sums go to a workspace
 // as f32 [split][row][tile row] and wide_epilogue_kernel adds the splits in index order and
 // applies the epilogue, so a row's arithmetic depends on (N, K) only: never on how many rows
 // share the pass.
+//
+// Build switches, for diagnostic and experiment builds only (the product library defines none):
+//   SD_WIDE_STAMPS   in-kernel phase clocks of both GEMM kernels (make stamps,
+//                    experiments/wide_stamps.py)
+//   SD_WIDE_SWITCH   a run-time choice between the two many-row kernels (make wide-switch,
+//                    experiments/bench_wide_shapes.py)
+//   SD_WIDE_EXP      a quick build of one row count's bf16 instantiations (SD_WIDE_EXP_MT token
+//                    tiles, default 12; SD_WIDE_BRING sets the B ring): experiments/build_wide_exp.sh
 #include <mutex>
 #include <type_traits>
 
