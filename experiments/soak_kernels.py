@@ -1,6 +1,6 @@
 """Soak run of the kernel tests over random shapes the test suite does not list: the paged
 attention against the oracle (random batch, ragged contexts, new-token counts, head layouts,
-split sizes), the <= 16-row and the 17..256-row linear kernels against the rounding reference
+split sizes; random token trees for the masked variant), the <= 16-row and the 17..256-row linear kernels against the rounding reference
 (random M, N, K, every epilogue, bf16 and fp8 weights), and the row-count invariance of the
 wide family.
     python experiments/soak_kernels.py [seconds]
@@ -15,6 +15,7 @@ import torch
 sys.path.insert(0, ".")
 import tests.test_gpu_attention as ta  # noqa: E402
 import tests.test_gpu_linear as tl  # noqa: E402
+import tests.test_gpu_tree as tt  # noqa: E402
 from vllm_omni_draft_amd import ops  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
@@ -95,8 +96,20 @@ def wide_case():
     attempt(f"wide M={M} N={N} K={K} fp8={fp8}", run)
 
 
+def tree_attention_case():
+    D = rnd.choice([64, 128])
+    Hkv = rnd.choice([1, 2, 8])
+    G = rnd.choice([1, 2, 4])
+    n = rnd.randint(1, max(1, min(15, 64 // G - 1)))
+    parents = [rnd.randint(0, i) for i in range(n)]          # row i + 1 hangs under a row <= i
+    B = rnd.randint(1, 3)
+    ctx = [rnd.choice([1, 15, 16, 17, rnd.randint(1, 1200)]) for _ in range(B)]
+    attempt("tree attention", tt.test_tree_attention_matches_oracle, Hkv * G, Hkv, D, ctx, rnd.choice([128, 256]), parents)
+
+
 while time.time() < t_end:
     attention_case()
+    tree_attention_case()
     narrow_case()
     wide_case()
     if (n_ok + n_bad) % 30 == 0:
